@@ -1,0 +1,348 @@
+/* TEST INFRASTRUCTURE ONLY -- see buffer_oracle.h.
+ *
+ * Plain-C restatement of the reference's CPU cores (cpp_wrappers/) and of the
+ * external CUDA operators' documented semantics (pointnet2_ops, KNN_CUDA),
+ * written from the algorithm descriptions, not copied.  Build with
+ * -ffp-contract=off so that every distance is the reference's
+ * ((dx*dx + dy*dy) + dz*dz) in IEEE fp32.
+ *
+ * Pinning: orc_grid_subsample_batch / orc_radius_neighbors are checked against
+ * the reference's own compiled cores (oracle/_ref, built from /root/reference
+ * in place) by tests/test_oracle_vs_ref.py and against tests/golden/pyramid_*.npz.
+ * orc_fps / orc_ball_query / orc_three_nn / orc_knn restate third-party CUDA
+ * extensions that are NOT under /root/reference (pointnet2_ops unpinned git,
+ * KNN_CUDA 0.2): parity UNPINNED for those four.
+ */
+#include "buffer_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+void orc_free(void* p) { free(p); }
+
+/* ------------------------------------------------------------------ A1 ---- */
+typedef struct { uint64_t key; int idx; } key_idx_t;
+
+static int cmp_key_idx(const void* a, const void* b)
+{
+    const key_idx_t* x = (const key_idx_t*)a;
+    const key_idx_t* y = (const key_idx_t*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+/* grid_subsampling.cpp:24-31 (origin / grid dims), :51-56 (voxel key),
+ * :62-70 + grid_subsampling.h:95-100 (sum in input order), :85-87 (barycentre). */
+static int grid_subsample_one(const float* p, int n, float dl, float* out, uint64_t* out_key)
+{
+    if (n <= 0) return 0;
+    float mnx = p[0], mny = p[1], mnz = p[2], mxx = p[0], mxy = p[1], mxz = p[2];
+    for (int i = 0; i < n; i++) {          /* cloud.cpp:27-66 */
+        float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+        if (x < mnx) mnx = x;  if (y < mny) mny = y;  if (z < mnz) mnz = z;
+        if (x > mxx) mxx = x;  if (y > mxy) mxy = y;  if (z > mxz) mxz = z;
+    }
+    float inv = 1 / dl;                     /* (1/sampleDl) is a float division */
+    float ox = floorf(mnx * inv) * dl;
+    float oy = floorf(mny * inv) * dl;
+    float oz = floorf(mnz * inv) * dl;
+    uint64_t NX = (uint64_t)(int64_t)floorf((mxx - ox) / dl) + 1;
+    uint64_t NY = (uint64_t)(int64_t)floorf((mxy - oy) / dl) + 1;
+    (void)mxz;
+
+    key_idx_t* ki = (key_idx_t*)malloc(sizeof(key_idx_t) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        uint64_t iX = (uint64_t)(int64_t)floorf((p[3 * i] - ox) / dl);
+        uint64_t iY = (uint64_t)(int64_t)floorf((p[3 * i + 1] - oy) / dl);
+        uint64_t iZ = (uint64_t)(int64_t)floorf((p[3 * i + 2] - oz) / dl);
+        ki[i].key = iX + NX * iY + NX * NY * iZ;
+        ki[i].idx = i;
+    }
+    qsort(ki, (size_t)n, sizeof(key_idx_t), cmp_key_idx);
+    int m = 0;
+    for (int a = 0; a < n;) {
+        int b = a;
+        float sx = 0, sy = 0, sz = 0;
+        int count = 0;
+        while (b < n && ki[b].key == ki[a].key) {   /* ascending idx == input order */
+            const float* q = p + 3 * ki[b].idx;
+            sx += q[0]; sy += q[1]; sz += q[2];
+            count++; b++;
+        }
+        float w = (float)(1.0 / count);              /* PointXYZ * (double -> float) */
+        out[3 * m] = sx * w; out[3 * m + 1] = sy * w; out[3 * m + 2] = sz * w;
+        if (out_key) out_key[m] = ki[a].key;
+        m++;
+        a = b;
+    }
+    free(ki);
+    return m;
+}
+
+int orc_grid_subsample_batch(const float* pts, int n, const int* batches, int nb,
+                             float dl, int max_p, float* out_pts, int* out_b,
+                             uint64_t* out_key)
+{
+    if (max_p < 1) max_p = n;                        /* grid_subsampling.cpp:134-135 */
+    int sum_b = 0, m_tot = 0;
+    float* tmp = (float*)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+    uint64_t* tk = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    for (int b = 0; b < nb; b++) {
+        if (sum_b + batches[b] > n) { free(tmp); free(tk); return -1; }
+        int m = grid_subsample_one(pts + 3 * (size_t)sum_b, batches[b], dl, tmp, tk);
+        if (m > max_p) m = max_p;                    /* :186-200, in OUR row order */
+        memcpy(out_pts + 3 * (size_t)m_tot, tmp, sizeof(float) * 3 * (size_t)m);
+        if (out_key) memcpy(out_key + m_tot, tk, sizeof(uint64_t) * (size_t)m);
+        out_b[b] = m;
+        m_tot += m;
+        sum_b += batches[b];
+    }
+    free(tmp); free(tk);
+    return m_tot;
+}
+
+/* ------------------------------------------------------------------ A2 ---- */
+typedef struct { float d2; int idx; } dist_idx_t;
+
+static int cmp_dist_idx(const void* a, const void* b)
+{
+    const dist_idx_t* x = (const dist_idx_t*)a;
+    const dist_idx_t* y = (const dist_idx_t*)b;
+    if (x->d2 != y->d2) return x->d2 < y->d2 ? -1 : 1;   /* nanoflann.hpp:1286-1287 */
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);      /* tie order: ours (ref unspecified) */
+}
+
+/* Uniform-grid search instead of the reference's KD-tree: the accept test
+ * (d2 < r2, nanoflann.hpp:249-253) and d2 itself (nanoflann.hpp:433-441:
+ * result += diff*diff for x, y, z in turn, fp32) are what define the output. */
+int orc_radius_neighbors(const float* q, int nq, const float* s, int ns,
+                         const int* qb, const int* sb, int nb, float radius, int** out)
+{
+    float r2 = radius * radius;                     /* neighbors.cpp:228 */
+    dist_idx_t** rows = (dist_idx_t**)calloc((size_t)(nq > 0 ? nq : 1), sizeof(dist_idx_t*));
+    int* cnt = (int*)calloc((size_t)(nq > 0 ? nq : 1), sizeof(int));
+    int max_count = 0;
+    int sum_q = 0, sum_s = 0;
+    for (int b = 0; b < nb; b++) {
+        const float* S = s + 3 * (size_t)sum_s;
+        int nsb = sb[b], nqb = qb[b];
+        if (nsb > 0 && nqb > 0) {
+            /* cell grid over this element's supports, cell edge >= radius */
+            float mn[3] = { S[0], S[1], S[2] }, mx[3] = { S[0], S[1], S[2] };
+            for (int i = 0; i < nsb; i++) for (int c = 0; c < 3; c++) {
+                float v = S[3 * i + c];
+                if (v < mn[c]) mn[c] = v;
+                if (v > mx[c]) mx[c] = v;
+            }
+            double cell = radius > 0 ? (double)radius : 1.0;
+            int dim[3];
+            for (;;) {
+                double tot = 1;
+                for (int c = 0; c < 3; c++) {
+                    dim[c] = (int)floor(((double)mx[c] - mn[c]) / cell) + 1;
+                    tot *= dim[c];
+                }
+                if (tot <= 1.6e7) break;
+                cell *= 2;
+            }
+            int ncell = dim[0] * dim[1] * dim[2];
+            int* start = (int*)calloc((size_t)ncell + 1, sizeof(int));
+            int* cid = (int*)malloc(sizeof(int) * (size_t)nsb);
+            for (int i = 0; i < nsb; i++) {
+                int c[3];
+                for (int k = 0; k < 3; k++) {
+                    c[k] = (int)floor(((double)S[3 * i + k] - mn[k]) / cell);
+                    if (c[k] >= dim[k]) c[k] = dim[k] - 1;
+                }
+                cid[i] = c[0] + dim[0] * (c[1] + dim[1] * c[2]);
+                start[cid[i] + 1]++;
+            }
+            for (int c = 0; c < ncell; c++) start[c + 1] += start[c];
+            int* order = (int*)malloc(sizeof(int) * (size_t)nsb);
+            int* fill = (int*)calloc((size_t)ncell, sizeof(int));
+            for (int i = 0; i < nsb; i++) order[start[cid[i]] + fill[cid[i]]++] = i;
+            free(fill); free(cid);
+
+            for (int j = 0; j < nqb; j++) {
+                const float* Q = q + 3 * (size_t)(sum_q + j);
+                int lo[3], hi[3], skip = 0;
+                for (int k = 0; k < 3; k++) {
+                    double a = floor(((double)Q[k] - mn[k]) / cell) - 1;
+                    double z = floor(((double)Q[k] - mn[k]) / cell) + 1;
+                    if (z < 0 || a > dim[k] - 1) { skip = 1; break; }
+                    lo[k] = a < 0 ? 0 : (int)a;
+                    hi[k] = z > dim[k] - 1 ? dim[k] - 1 : (int)z;
+                }
+                int cap = 0, m = 0;
+                dist_idx_t* row = NULL;
+                if (!skip)
+                for (int cz = lo[2]; cz <= hi[2]; cz++)
+                for (int cy = lo[1]; cy <= hi[1]; cy++)
+                for (int cx = lo[0]; cx <= hi[0]; cx++) {
+                    int c = cx + dim[0] * (cy + dim[1] * cz);
+                    for (int t = start[c]; t < start[c + 1]; t++) {
+                        int i = order[t];
+                        float d2 = 0, diff;
+                        diff = Q[0] - S[3 * i];     d2 += diff * diff;
+                        diff = Q[1] - S[3 * i + 1]; d2 += diff * diff;
+                        diff = Q[2] - S[3 * i + 2]; d2 += diff * diff;
+                        if (d2 < r2) {
+                            if (m == cap) {
+                                cap = cap ? 2 * cap : 32;
+                                row = (dist_idx_t*)realloc(row, sizeof(dist_idx_t) * (size_t)cap);
+                            }
+                            row[m].d2 = d2;
+                            row[m].idx = i + sum_s;  /* neighbors.cpp:321 */
+                            m++;
+                        }
+                    }
+                }
+                if (m > 1) qsort(row, (size_t)m, sizeof(dist_idx_t), cmp_dist_idx);
+                rows[sum_q + j] = row;
+                cnt[sum_q + j] = m;
+                if (m > max_count) max_count = m;
+            }
+            free(order); free(start);
+        }
+        sum_q += qb[b];
+        sum_s += sb[b];
+    }
+    size_t tot = (size_t)nq * (size_t)max_count;
+    int* o = (int*)malloc(sizeof(int) * (tot ? tot : 1));
+    for (int j = 0; j < nq; j++) {
+        for (int k = 0; k < max_count; k++)
+            o[(size_t)j * max_count + k] = k < cnt[j] ? rows[j][k].idx : ns;  /* :322-324 */
+        free(rows[j]);
+    }
+    free(rows); free(cnt);
+    *out = o;
+    return max_count;
+}
+
+/* ------------------------------------------------------------------ A6 ---- */
+/* Upstream kernel shape [recalled]: T = min(512, 2^floor(log2 n)) threads stride
+ * over k; per thread strict '>' keeps its first maximum; the pairwise tree
+ * keeps the LOWER thread on equality. temp starts at 1e10; points with
+ * x*x+y*y+z*z <= 1e-3 (compared in double) never update or compete. */
+static int fps_threads(int n)
+{
+    int p = 1;
+    while (p * 2 <= n && p * 2 <= 512) p *= 2;
+    return p < 1 ? 1 : p;
+}
+
+void orc_fps(const float* xyz, int nbatch, int n, int m, int* idx)
+{
+    if (m <= 0) return;
+    float* temp = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int T = fps_threads(n);
+    float* tb = (float*)malloc(sizeof(float) * (size_t)T);
+    int* ti = (int*)malloc(sizeof(int) * (size_t)T);
+    for (int b = 0; b < nbatch; b++) {
+        const float* P = xyz + 3 * (size_t)b * n;
+        int* I = idx + (size_t)b * m;
+        for (int k = 0; k < n; k++) temp[k] = 1e10f;
+        int old = 0;
+        I[0] = 0;
+        for (int j = 1; j < m; j++) {
+            float x1 = P[3 * old], y1 = P[3 * old + 1], z1 = P[3 * old + 2];
+            for (int t = 0; t < T; t++) { tb[t] = -1.0f; ti[t] = 0; }
+            for (int k = 0; k < n; k++) {
+                float x2 = P[3 * k], y2 = P[3 * k + 1], z2 = P[3 * k + 2];
+                float mag = (x2 * x2) + (y2 * y2) + (z2 * z2);
+                if ((double)mag <= 1e-3) continue;
+                float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+                float d2 = d < temp[k] ? d : temp[k];
+                temp[k] = d2;
+                int t = k % T;
+                if (d2 > tb[t]) { tb[t] = d2; ti[t] = k; }
+            }
+            int bt = 0;
+            for (int t = 1; t < T; t++) if (tb[t] > tb[bt]) bt = t;
+            old = ti[bt];
+            I[j] = old;
+        }
+    }
+    free(temp); free(tb); free(ti);
+}
+
+/* ------------------------------------------------------------- A8 / A10 ---- */
+void orc_ball_query(const float* xyz, const float* new_xyz, int nbatch, int n, int m,
+                    float radius, int nsample, int* idx)
+{
+    float r2 = radius * radius;
+    memset(idx, 0, sizeof(int) * (size_t)nbatch * m * nsample);
+    for (int b = 0; b < nbatch; b++) {
+        const float* P = xyz + 3 * (size_t)b * n;
+        const float* Q = new_xyz + 3 * (size_t)b * m;
+        int* I = idx + (size_t)b * m * nsample;
+        for (int j = 0; j < m; j++) {
+            float qx = Q[3 * j], qy = Q[3 * j + 1], qz = Q[3 * j + 2];
+            int cnt = 0;
+            for (int k = 0; k < n && cnt < nsample; k++) {
+                float x = P[3 * k], y = P[3 * k + 1], z = P[3 * k + 2];
+                float d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+                if (d2 < r2) {
+                    if (cnt == 0) for (int l = 0; l < nsample; l++) I[(size_t)j * nsample + l] = k;
+                    I[(size_t)j * nsample + cnt] = k;
+                    cnt++;
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ A18 ---- */
+void orc_three_nn(const float* unknown, const float* known, int nbatch, int n, int m,
+                  float* dist, int* idx)
+{
+    for (int b = 0; b < nbatch; b++)
+    for (int j = 0; j < n; j++) {
+        const float* u = unknown + 3 * ((size_t)b * n + j);
+        double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+        int i1 = 0, i2 = 0, i3 = 0;
+        for (int k = 0; k < m; k++) {
+            const float* p = known + 3 * ((size_t)b * m + k);
+            float d = (u[0] - p[0]) * (u[0] - p[0]) + (u[1] - p[1]) * (u[1] - p[1]) +
+                      (u[2] - p[2]) * (u[2] - p[2]);
+            if (d < best1)      { best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = k; }
+            else if (d < best2) { best3 = best2; i3 = i2; best2 = d; i2 = k; }
+            else if (d < best3) { best3 = d; i3 = k; }
+        }
+        float* D = dist + 3 * ((size_t)b * n + j);
+        int* I = idx + 3 * ((size_t)b * n + j);
+        D[0] = sqrtf((float)best1); D[1] = sqrtf((float)best2); D[2] = sqrtf((float)best3);
+        I[0] = i1; I[1] = i2; I[2] = i3;
+    }
+}
+
+/* ------------------------------------------------------------------ A12 ---- */
+void orc_knn(const float* ref, const float* query, int nbatch, int n, int nq, int d, int k,
+             float* dist, int64_t* idx)
+{
+    float* bd = (float*)malloc(sizeof(float) * (size_t)k);
+    int64_t* bi = (int64_t*)malloc(sizeof(int64_t) * (size_t)k);
+    for (int b = 0; b < nbatch; b++)
+    for (int j = 0; j < nq; j++) {
+        const float* Q = query + (size_t)d * ((size_t)b * nq + j);
+        int have = 0;
+        for (int i = 0; i < n; i++) {
+            const float* R = ref + (size_t)d * ((size_t)b * n + i);
+            float ssd = 0;
+            for (int c = 0; c < d; c++) { float t = R[c] - Q[c]; ssd += t * t; }
+            /* ascending insertion, strict '<' keeps the earlier index on ties */
+            int pos = have;
+            while (pos > 0 && ssd < bd[pos - 1]) pos--;
+            if (pos >= k) continue;
+            int last = have < k ? have : k - 1;
+            for (int t = last; t > pos; t--) { bd[t] = bd[t - 1]; bi[t] = bi[t - 1]; }
+            bd[pos] = ssd; bi[pos] = i;
+            if (have < k) have++;
+        }
+        for (int t = 0; t < k; t++) {
+            dist[((size_t)b * nq + j) * k + t] = t < have ? sqrtf(bd[t]) : INFINITY;
+            idx[((size_t)b * nq + j) * k + t] = t < have ? bi[t] : 0;
+        }
+    }
+    free(bd); free(bi);
+}
