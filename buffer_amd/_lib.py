@@ -1,0 +1,72 @@
+"""ctypes binding of libbuffer_hip.so (the C ABI declared in include/buffer_hip.h).
+
+There is no CPU fallback: importing an operator without the built library, or calling one
+without a HIP device, raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbuffer_hip.so")
+
+BUF_OK = 0
+
+
+class BufferHipError(RuntimeError):
+    pass
+
+
+class buf_grid_t(C.Structure):
+    _fields_ = [
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("ns", C.c_int), ("nb", C.c_int),
+        ("cells_per_elem", C.c_int64),
+        ("radius", C.c_float),
+        ("desc", C.c_void_p), ("s_off", C.c_void_p), ("table", C.c_void_p),
+        ("sorted", C.c_void_p), ("order", C.c_void_p), ("scan_tmp", C.c_void_p),
+    ]
+
+
+_lib = None
+
+_vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+_SIGNATURES = {
+    "buf_last_error": (C.c_char_p, []),
+    "buf_version": (_i, []),
+    "buf_device_count": (_i, []),
+    "buf_grid_default_cells": (_i64, [_i, _i]),
+    "buf_grid_ws_bytes": (_sz, [_i, _i, _i64]),
+    "buf_grid_build": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _i, _f, _i64, _vp, _sz, _vp]),
+    "buf_grid_query": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
+    "buf_radius_neighbors": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "buf_grid_subsample_ws_bytes": (_sz, [_i, _i, _i64]),
+    "buf_grid_subsample_batch": (_i, [_vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+}
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BufferHipError(
+                f"{LIB_PATH} is missing: build it with `python -m buffer_amd.build` "
+                "(hipcc --offload-arch=gfx950). buffer_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != BUF_OK:
+        msg = lib().buf_last_error().decode(errors="replace")
+        raise BufferHipError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,39 @@
+"""Compile buffer_amd/csrc into buffer_amd/libbuffer_hip.so for gfx950 (in-tree, so the built
+library travels with the repository snapshot to the GPU box)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "buffer_hip.hip")
+OUT = os.path.join(HERE, "libbuffer_hip.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    for root in (os.path.join(HERE, "csrc"), os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            if os.path.getmtime(os.path.join(root, f)) > t:
+                return True
+    return False
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+           "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="-v" in sys.argv)
+    print(OUT)

@@ -1,0 +1,6 @@
+// Single translation unit of libbuffer_hip.so (gfx950).  Parts are plain includes so that the
+// kernels share the static helpers without relocatable device code.
+#include <stdlib.h>
+#include "core.hip"
+#include "radius.hip"
+#include "subsample.hip"

@@ -1,0 +1,196 @@
+// Error state, device probe and the int32 exclusive scan shared by the cell-grid builders.
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void buf_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* buf_last_error(void) { return g_err; }
+extern "C" int buf_version(void) { return 100; }
+
+extern "C" int buf_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        buf_set_error("hipGetDeviceCount -> %s", hipGetErrorString(e));
+        return BUF_ENODEVICE;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Exclusive scan: <=SCAN_BLOCKS workgroups each own a contiguous chunk; pass 1 reduces the
+// chunks, one workgroup scans the chunk sums, pass 2 rescans each chunk with its offset.
+// Reads the data twice and writes it once (12 B per element of HBM traffic).
+#define SCAN_BLOCKS 1024
+#define SCAN_THREADS 256
+
+size_t scan_tmp_ints() { return SCAN_BLOCKS + 8; }
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// inclusive scan across a 256-thread workgroup; returns inclusive value, *total = block sum
+__device__ __forceinline__ int block_incl_scan(int v, int* total)
+{
+    __shared__ int wsum[SCAN_THREADS / WAVE];
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    int inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == WAVE - 1) wsum[w] = inc;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_THREADS / WAVE; i++) {
+        int s = wsum[i];
+        if (i < w) add += s;
+        tot += s;
+    }
+    *total = tot;
+    return inc + add;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const int* __restrict__ data, long long n,
+                                                            long long chunk, int* __restrict__ sums)
+{
+    long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk;
+    if (hi > n) hi = n;
+    int acc = 0;
+    for (long long i = lo + threadIdx.x; i < hi; i += SCAN_THREADS) acc += data[i];
+    int tot;
+    block_incl_scan(acc, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(int* __restrict__ sums, int nblocks,
+                                                          int* __restrict__ total_out)
+{
+    // nblocks <= SCAN_BLOCKS = 4 * SCAN_THREADS
+    int v[4], acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = threadIdx.x * 4 + j;
+        v[j] = i < nblocks ? sums[i] : 0;
+        acc += v[j];
+    }
+    int tot;
+    int inc = block_incl_scan(acc, &tot);
+    int run = inc - acc;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = threadIdx.x * 4 + j;
+        if (i < nblocks) sums[i] = run;
+        run += v[j];
+    }
+    if (threadIdx.x == 0) {
+        sums[SCAN_BLOCKS] = tot;
+        if (total_out) *total_out = tot;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(int* __restrict__ data, long long n,
+                                                           long long chunk, const int* __restrict__ sums)
+{
+    long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk;
+    if (hi > n) hi = n;
+    int run = sums[blockIdx.x];
+    for (long long base = lo; base < hi; base += SCAN_THREADS) {
+        long long i = base + threadIdx.x;
+        int v = i < hi ? data[i] : 0;
+        int tot;
+        int inc = block_incl_scan(v, &tot);
+        if (i < hi) data[i] = run + inc - v;
+        run += tot;
+        __syncthreads();
+    }
+}
+
+int exclusive_scan_i32(int* data, long long n, int* tmp, int* total_out, hipStream_t stream)
+{
+    if (n <= 0) {
+        if (total_out) BUF_CHECK_HIP(hipMemsetAsync(total_out, 0, sizeof(int), stream));
+        return BUF_OK;
+    }
+    long long chunk = (n + SCAN_BLOCKS - 1) / SCAN_BLOCKS;
+    chunk = (chunk + SCAN_THREADS - 1) / SCAN_THREADS * SCAN_THREADS;
+    int nblocks = (int)((n + chunk - 1) / chunk);
+    k_scan_reduce<<<nblocks, SCAN_THREADS, 0, stream>>>(data, n, chunk, tmp);
+    k_scan_sums<<<1, SCAN_THREADS, 0, stream>>>(tmp, nblocks, total_out);
+    k_scan_apply<<<nblocks, SCAN_THREADS, 0, stream>>>(data, n, chunk, tmp);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Counting-sort tail shared by the cell grid (radius.hip) and the voxel grid (subsample.hip).
+// `table` holds exclusive cell starts on entry to k_cell_scatter and inclusive cell ends after.
+__global__ void __launch_bounds__(256) k_cell_scatter(const float* __restrict__ pts, int n, const int* __restrict__ cell_of,
+                                                    const int* __restrict__ err, int* __restrict__ table,
+                                                    float4* __restrict__ sorted)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (err && *err)) return;
+    int pos = atomicAdd(&table[cell_of[i]], 1);
+    sorted[pos] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], __int_as_float(i));
+}
+
+// The scatter order inside a cell depends on atomic arrival; every point ranks itself by input
+// index inside its (small) cell run, which makes the cell-ordered stream deterministic and, for the
+// voxel grid, puts every run in INPUT ORDER.
+__global__ void __launch_bounds__(256) k_cell_rank(const int* __restrict__ cell_of, const int* __restrict__ table,
+                                                 const float4* __restrict__ sorted_in, int n, const int* __restrict__ err,
+                                                 float4* __restrict__ sorted_out, int* __restrict__ order_out)
+{
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n || (err && *err)) return;
+    float4 me = sorted_in[p];
+    int i = __float_as_int(me.w);
+    int c = cell_of[i];
+    int s = c == 0 ? 0 : table[c - 1], e = table[c];
+    int rank = 0;
+    for (int t = s; t < e; t++) rank += (__float_as_int(sorted_in[t].w) < i) ? 1 : 0;
+    sorted_out[s + rank] = me;
+    order_out[s + rank] = i;
+}
+
+// Upload prefix offsets of a host batch-length array (tiny) and validate their sum.
+static int upload_offsets(int* dev, const int* lens_host, int nb, int expect_total, const char* what, hipStream_t s)
+{
+    int stackbuf[65];
+    int* off = nb + 1 <= 65 ? stackbuf : (int*)malloc(sizeof(int) * ((size_t)nb + 1));
+    off[0] = 0;
+    for (int b = 0; b < nb; b++) {
+        if (lens_host[b] < 0) { if (off != stackbuf) free(off); buf_set_error("%s: negative batch length", what); return BUF_EINVAL; }
+        off[b + 1] = off[b] + lens_host[b];
+    }
+    int tot = off[nb];
+    if (tot != expect_total) {
+        if (off != stackbuf) free(off);
+        buf_set_error("%s: batch lengths sum to %d, expected %d", what, tot, expect_total);
+        return BUF_EINVAL;
+    }
+    // pageable source: the runtime stages the bytes before hipMemcpyAsync returns
+    hipError_t e = hipMemcpyAsync(dev, off, sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, s);
+    if (off != stackbuf) {
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        free(off);
+    }
+    if (e != hipSuccess) { buf_set_error("%s: offsets upload -> %s", what, hipGetErrorString(e)); return BUF_EHIP; }
+    return BUF_OK;
+}

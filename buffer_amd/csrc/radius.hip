@@ -1,0 +1,313 @@
+// A2 -- batched radius neighbours on a uniform cell grid (replaces
+// cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-332, the nanoflann KD-tree search).
+//
+// Build (per call, all batch elements at once):
+//   k_grid_bbox    one workgroup per batch element: bounding box, cell edge >= radius coarsened
+//                  until the dense table fits `cells_per_elem`
+//   k_grid_count   one thread per support: cell id (fp64 cell coordinates), atomic histogram
+//   exclusive scan over the concatenated tables -> cell starts in the stacked order
+//   k_grid_scatter pos = atomicAdd(table[cell],1): float4 (x,y,z,bitcast index) in cell order;
+//                  the table ends up holding inclusive cell ends
+// Query:
+//   k_grid_query   one lane per query, 9 contiguous x-runs of cells (3 y * 3 z), candidates read as
+//                  float4 from the cell-ordered array (lanes of a wavefront that sit in the same
+//                  cell read the same addresses -> one transaction), accept d2 < r2, keep the KL
+//                  smallest (d2,index) keys in a lane-private LDS column, emit ascending.
+//                  Rows longer than KL are produced in further sweeps (keys > last emitted).
+#include "common.h"
+
+struct CellGrid {
+    float mn[3];
+    int   table_off;     // first table slot of this element (global, concatenated)
+    double inv_cell;
+    int   dim[3];
+    int   s_off;
+};
+
+#define BBOX_THREADS 1024
+
+__global__ void __launch_bounds__(BBOX_THREADS) k_grid_bbox(const float* __restrict__ pts, const int* __restrict__ s_off,
+                                                         CellGrid* __restrict__ grids, double radius,
+                                                         long long cells_per_elem)
+{
+    int b = blockIdx.x;
+    int lo = s_off[b], hi = s_off[b + 1];
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    for (int i = lo + threadIdx.x; i < hi; i += BBOX_THREADS) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float v = pts[3 * (size_t)i + c];
+            mn[c] = fminf(mn[c], v);
+            mx[c] = fmaxf(mx[c], v);
+        }
+    }
+    __shared__ float smn[3][BBOX_THREADS / WAVE], smx[3][BBOX_THREADS / WAVE];
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = mn[c], z = mx[c];
+        for (int d = WAVE / 2; d > 0; d >>= 1) {
+            a = fminf(a, __shfl_xor(a, d, WAVE));
+            z = fmaxf(z, __shfl_xor(z, d, WAVE));
+        }
+        if (lane == 0) { smn[c][w] = a; smx[c][w] = z; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        CellGrid g;
+        double ext[3];
+        for (int c = 0; c < 3; c++) {
+            float a = smn[c][0], z = smx[c][0];
+            for (int i = 1; i < BBOX_THREADS / WAVE; i++) { a = fminf(a, smn[c][i]); z = fmaxf(z, smx[c][i]); }
+            if (hi <= lo) { a = 0.f; z = 0.f; }
+            g.mn[c] = a;
+            ext[c] = (double)z - (double)a;
+        }
+        // cell edge strictly larger than the radius so that |dx| < r never spans two cells + 1
+        double cell = radius > 0 ? radius * 1.00001 : 1.0;
+        for (int it = 0; it < 200; it++) {
+            double tot = 1.0;
+            for (int c = 0; c < 3; c++) tot *= floor(ext[c] / cell) + 1.0;
+            if (tot <= (double)cells_per_elem) break;
+            cell *= 1.25;
+        }
+        for (int c = 0; c < 3; c++) g.dim[c] = (int)(floor(ext[c] / cell) + 1.0);
+        g.inv_cell = 1.0 / cell;
+        g.table_off = (int)((long long)b * cells_per_elem);
+        g.s_off = lo;
+        grids[b] = g;
+    }
+}
+
+__device__ __forceinline__ int cell_coord(float v, float mn, double inv_cell, int dim)
+{
+    double c = floor(((double)v - (double)mn) * inv_cell);
+    c = fmin(fmax(c, 0.0), (double)(dim - 1));
+    return (int)c;
+}
+
+__global__ void __launch_bounds__(256) k_grid_count(const float* __restrict__ pts, int ns, const int* __restrict__ s_off,
+                                                  int nb, const CellGrid* __restrict__ grids,
+                                                  int* __restrict__ table, int* __restrict__ cell_of)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    int b = find_elem(s_off, nb, i);
+    CellGrid g = grids[b];
+    int cx = cell_coord(pts[3 * (size_t)i], g.mn[0], g.inv_cell, g.dim[0]);
+    int cy = cell_coord(pts[3 * (size_t)i + 1], g.mn[1], g.inv_cell, g.dim[1]);
+    int cz = cell_coord(pts[3 * (size_t)i + 2], g.mn[2], g.inv_cell, g.dim[2]);
+    int c = g.table_off + cx + g.dim[0] * (cy + g.dim[1] * cz);
+    cell_of[i] = c;
+    atomicAdd(&table[c], 1);
+}
+
+template <int KL>
+__global__ void __launch_bounds__(WAVE) k_grid_query(const CellGrid* __restrict__ grids, const int* __restrict__ table,
+                                                   const float4* __restrict__ sorted, const float* __restrict__ queries,
+                                                   int nq, const int* __restrict__ q_off, int nb,
+                                                   const int* __restrict__ q_order, float r2, int k_out, int shadow,
+                                                   int* __restrict__ nbr_out, int* __restrict__ counts_out,
+                                                   int* __restrict__ max_count_out)
+{
+    __shared__ unsigned long long col[KL][WAVE];
+    const int lane = threadIdx.x;
+    int t = blockIdx.x * WAVE + lane;
+    bool active = t < nq;
+    int qi = active ? (q_order ? q_order[t] : t) : 0;
+    int rs[9], re[9];
+    float qx = 0, qy = 0, qz = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) { rs[j] = 0; re[j] = 0; }
+    if (active) {
+        int b = find_elem(q_off, nb, qi);
+        CellGrid g = grids[b];
+        qx = queries[3 * (size_t)qi]; qy = queries[3 * (size_t)qi + 1]; qz = queries[3 * (size_t)qi + 2];
+        double fx = floor(((double)qx - (double)g.mn[0]) * g.inv_cell);
+        double fy = floor(((double)qy - (double)g.mn[1]) * g.inv_cell);
+        double fz = floor(((double)qz - (double)g.mn[2]) * g.inv_cell);
+        // clamp far-away queries before the int conversion; they simply find no cell
+        fx = fmin(fmax(fx, -2.0), (double)g.dim[0] + 1.0);
+        fy = fmin(fmax(fy, -2.0), (double)g.dim[1] + 1.0);
+        fz = fmin(fmax(fz, -2.0), (double)g.dim[2] + 1.0);
+        int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+        int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            int y = cy + (j % 3) - 1, z = cz + (j / 3) - 1;
+            if (x0 <= x1 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+                int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
+                int g1 = g0 + (x1 - x0);
+                rs[j] = g0 == 0 ? 0 : table[g0 - 1];
+                re[j] = table[g1];
+            }
+        }
+    }
+
+    int total = 0;
+    unsigned long long lb = 0;      // keys must be > lb (exclusive) in sweeps after the first
+    bool first = true;
+    int written = 0;
+    int* row = nbr_out + (size_t)qi * k_out;
+    // sweeps are wave-uniform in count only through the ballot below
+    for (;;) {
+        int n = 0;
+        unsigned long long worst = ~0ull;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            for (int p = rs[j]; p < re[j]; p++) {
+                float4 c = sorted[p];
+                float d2 = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+                if (d2 < r2) {
+                    if (first) total++;
+                    unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) |
+                                             (unsigned int)__float_as_int(c.w);
+                    if ((first || key > lb) && (n < KL || key < worst) && k_out > 0) {
+                        int i = n < KL ? n : KL - 1;
+                        while (i > 0 && col[i - 1][lane] > key) { col[i][lane] = col[i - 1][lane]; i--; }
+                        col[i][lane] = key;
+                        if (n < KL) n++;
+                        if (n == KL) worst = col[KL - 1][lane];
+                    }
+                }
+            }
+        }
+        if (active) {
+            int lim = min(n, k_out - written);
+            for (int i = 0; i < lim; i++) row[written + i] = (int)(unsigned int)(col[i][lane] & 0xffffffffu);
+            written += lim;
+            if (n == KL) lb = col[KL - 1][lane];
+        }
+        first = false;
+        bool more = active && n == KL && written < k_out && written < total;
+        if (!__any(more)) break;
+        if (!more) {  // this lane is done: make further sweeps empty for it
+#pragma unroll
+            for (int j = 0; j < 9; j++) re[j] = rs[j];
+        }
+    }
+    if (active) {
+        for (int i = written; i < k_out; i++) row[i] = shadow;
+        if (counts_out) counts_out[qi] = total;
+    }
+    if (max_count_out) {
+        int m = active ? total : 0;
+        for (int d = WAVE / 2; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, WAVE));
+        if (lane == 0 && m > 0) atomicMax(max_count_out, m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int64_t buf_grid_default_cells(int ns, int nb)
+{
+    int64_t per = nb > 0 ? ((int64_t)ns + nb - 1) / nb : ns;
+    int64_t c = 16 * per + 65536;
+    // keep the concatenated table addressable with int32
+    int64_t cap = nb > 0 ? (int64_t)0x7fff0000 / nb : 0x7fff0000;
+    return c < cap ? c : cap;
+}
+
+static void carve_grid(buf_grid_t* g, WsCarver& w, int ns, int nb, int64_t cells)
+{
+    g->desc = w.take<CellGrid>((size_t)nb);
+    g->s_off = w.take<int>((size_t)nb + 1);
+    g->table = w.take<int>((size_t)nb * (size_t)cells);
+    g->sorted = w.take<float4>((size_t)(ns > 0 ? ns : 1));
+    g->order = w.take<int>((size_t)(ns > 0 ? ns : 1));
+    g->scan_tmp = w.take<int>(scan_tmp_ints());
+}
+
+struct GridExtra { float4* sorted_tmp; int* cell_of; int* q_off; };
+
+static GridExtra carve_extra(WsCarver& w, int ns, int nb)
+{
+    GridExtra e;
+    e.sorted_tmp = w.take<float4>((size_t)(ns > 0 ? ns : 1));
+    e.cell_of = w.take<int>((size_t)(ns > 0 ? ns : 1));
+    e.q_off = w.take<int>((size_t)nb + 1);
+    return e;
+}
+
+extern "C" size_t buf_grid_ws_bytes(int ns, int nb, int64_t cells_per_elem)
+{
+    if (cells_per_elem <= 0) cells_per_elem = buf_grid_default_cells(ns, nb);
+    buf_grid_t g;
+    WsCarver w(nullptr, 0);
+    carve_grid(&g, w, ns, nb, cells_per_elem);
+    carve_extra(w, ns, nb);
+    return w.used();
+}
+
+extern "C" int buf_grid_build(buf_grid_t* g, const float* supports, int ns, const int* s_batches_host, int nb,
+                              float radius, int64_t cells_per_elem, void* ws, size_t ws_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    BUF_REQUIRE(g && s_batches_host && ws, BUF_EINVAL, "buf_grid_build: null argument");
+    BUF_REQUIRE(ns >= 0 && nb > 0, BUF_EINVAL, "buf_grid_build: ns=%d nb=%d", ns, nb);
+    BUF_REQUIRE(ns == 0 || supports, BUF_EINVAL, "buf_grid_build: null supports");
+    BUF_REQUIRE(radius == radius, BUF_EINVAL, "buf_grid_build: radius is NaN");
+    if (cells_per_elem <= 0) cells_per_elem = buf_grid_default_cells(ns, nb);
+    BUF_REQUIRE((int64_t)nb * cells_per_elem < 0x7fffffffLL, BUF_EINVAL, "buf_grid_build: table too large");
+    memset(g, 0, sizeof(*g));
+    WsCarver w(ws, ws_bytes);
+    carve_grid(g, w, ns, nb, cells_per_elem);
+    GridExtra ex = carve_extra(w, ns, nb);
+    BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_grid_build: workspace %zu < %zu bytes", ws_bytes, w.used());
+    g->ws = ws; g->ws_bytes = ws_bytes; g->ns = ns; g->nb = nb; g->cells_per_elem = cells_per_elem; g->radius = radius;
+
+    int rc = upload_offsets(g->s_off, s_batches_host, nb, ns, "buf_grid_build", s);
+    if (rc) return rc;
+    size_t table_n = (size_t)nb * (size_t)cells_per_elem;
+    BUF_CHECK_HIP(hipMemsetAsync(g->table, 0, sizeof(int) * table_n, s));
+    k_grid_bbox<<<nb, BBOX_THREADS, 0, s>>>(supports, g->s_off, (CellGrid*)g->desc, (double)radius, (long long)cells_per_elem);
+    if (ns > 0) {
+        k_grid_count<<<cdiv(ns, 256), 256, 0, s>>>(supports, ns, g->s_off, nb, (const CellGrid*)g->desc, g->table, ex.cell_of);
+        rc = exclusive_scan_i32(g->table, (long long)table_n, (int*)g->scan_tmp, nullptr, s);
+        if (rc) return rc;
+        k_cell_scatter<<<cdiv(ns, 256), 256, 0, s>>>(supports, ns, ex.cell_of, nullptr, g->table, ex.sorted_tmp);
+        k_cell_rank<<<cdiv(ns, 256), 256, 0, s>>>(ex.cell_of, g->table, ex.sorted_tmp, ns, nullptr, (float4*)g->sorted, g->order);
+    }
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq, const int* q_batches_host,
+                              const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
+                              int* max_count_out, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    BUF_REQUIRE(g && g->ws && q_batches_host, BUF_EINVAL, "buf_grid_query: null argument");
+    BUF_REQUIRE(nq >= 0 && k_out >= 0, BUF_EINVAL, "buf_grid_query: nq=%d k_out=%d", nq, k_out);
+    BUF_REQUIRE(k_out == 0 || nbr_out, BUF_EINVAL, "buf_grid_query: null nbr_out");
+    BUF_REQUIRE(radius <= g->radius, BUF_EINVAL, "buf_grid_query: radius %g > grid radius %g", radius, g->radius);
+    if (nq == 0) return BUF_OK;
+    BUF_REQUIRE(queries, BUF_EINVAL, "buf_grid_query: null queries");
+    // q_off lives behind the grid in the same workspace
+    WsCarver w(g->ws, g->ws_bytes);
+    buf_grid_t tmp;
+    carve_grid(&tmp, w, g->ns, g->nb, g->cells_per_elem);
+    GridExtra ex = carve_extra(w, g->ns, g->nb);
+    int rc = upload_offsets(ex.q_off, q_batches_host, g->nb, nq, "buf_grid_query", s);
+    if (rc) return rc;
+    float r2 = radius * radius;     // neighbors.cpp:228
+    int blocks = cdiv(nq, WAVE);
+    if (k_out <= 32)
+        k_grid_query<32><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
+                                                ex.q_off, g->nb, q_order, r2, k_out, g->ns, nbr_out, counts_out, max_count_out);
+    else
+        k_grid_query<64><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
+                                                ex.q_off, g->nb, q_order, r2, k_out, g->ns, nbr_out, counts_out, max_count_out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+extern "C" int buf_radius_neighbors(const float* queries, int nq, const float* supports, int ns,
+                                    const int* q_batches_host, const int* s_batches_host, int nb, float radius,
+                                    int k_out, int* nbr_out, int* counts_out, int* max_count_out,
+                                    void* ws, size_t ws_bytes, void* stream)
+{
+    buf_grid_t g;
+    int rc = buf_grid_build(&g, supports, ns, s_batches_host, nb, radius, 0, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return buf_grid_query(&g, queries, nq, q_batches_host, nullptr, radius, k_out, nbr_out, counts_out, max_count_out, stream);
+}

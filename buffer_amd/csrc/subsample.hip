@@ -1,0 +1,254 @@
+// A1 -- batched grid (voxel-barycentre) subsampling
+// (replaces cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:5-106,109-211).
+//
+// The reference accumulates points into an unordered_map keyed by the voxel index and emits the
+// barycentres in hash-map order.  Here: dense voxel table per batch element, counting sort of the
+// points by voxel (ties ranked by input index, so each voxel's run is in INPUT ORDER and the fp32
+// sum is the reference's, bit for bit), one lane per voxel run, rows emitted in ascending voxel-key
+// order.
+#include "common.h"
+
+struct VoxGrid {
+    float o[3];            // originCorner (grid_subsampling.cpp:27)
+    float dl;
+    long long NX, NY, NZ;  // sampleNX, sampleNY (:30-31) and the z extent for the dense table
+    long long table_off;   // first slot of this element in the concatenated table
+    int lo, hi;            // point range
+};
+
+struct VoxStatus { int error; int total_rows; };
+
+__global__ void __launch_bounds__(1024) k_vox_bbox(const float* __restrict__ pts, const int* __restrict__ off,
+                                                 VoxGrid* __restrict__ grids, float dl)
+{
+    int b = blockIdx.x;
+    int lo = off[b], hi = off[b + 1];
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float v = pts[3 * (size_t)i + c];
+            mn[c] = v < mn[c] ? v : mn[c];
+            mx[c] = v > mx[c] ? v : mx[c];
+        }
+    }
+    __shared__ float smn[3][16], smx[3][16];
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = mn[c], z = mx[c];
+        for (int d = WAVE / 2; d > 0; d >>= 1) {
+            a = fminf(a, __shfl_xor(a, d, WAVE));
+            z = fmaxf(z, __shfl_xor(z, d, WAVE));
+        }
+        if (lane == 0) { smn[c][w] = a; smx[c][w] = z; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        VoxGrid g;
+        g.dl = dl;
+        g.lo = lo; g.hi = hi;
+        float inv = __fdiv_rn(1.0f, dl);                       // (1/sampleDl), fp32
+        long long N[3];
+        for (int c = 0; c < 3; c++) {
+            float a = smn[c][0], z = smx[c][0];
+            for (int i = 1; i < 16; i++) { a = fminf(a, smn[c][i]); z = fmaxf(z, smx[c][i]); }
+            if (hi <= lo) { a = 0.f; z = 0.f; }
+            g.o[c] = __fmul_rn(floorf(__fmul_rn(a, inv)), dl);  // floor(min * (1/dl)) * dl
+            N[c] = (long long)floorf(__fdiv_rn(__fsub_rn(z, g.o[c]), dl)) + 1;
+        }
+        g.NX = N[0]; g.NY = N[1]; g.NZ = N[2];
+        g.table_off = 0;
+        grids[b] = g;
+    }
+}
+
+__global__ void k_vox_offsets(VoxGrid* __restrict__ grids, int nb, long long max_cells, VoxStatus* __restrict__ st)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long run = 0;
+    int err = 0;
+    for (int b = 0; b < nb; b++) {
+        VoxGrid g = grids[b];
+        grids[b].table_off = run;
+        if (g.hi > g.lo) {
+            if (g.NX <= 0 || g.NY <= 0 || g.NZ <= 0) err = 1;
+            else {
+                double cells = (double)g.NX * (double)g.NY * (double)g.NZ;
+                if (cells > (double)max_cells) err = 1; else run += g.NX * g.NY * g.NZ;
+            }
+        }
+        if (run > max_cells) err = 1;
+    }
+    st->error = err;
+    st->total_rows = 0;
+}
+
+__global__ void __launch_bounds__(256) k_vox_count(const float* __restrict__ pts, int n, const int* __restrict__ off, int nb,
+                                                 const VoxGrid* __restrict__ grids, VoxStatus* __restrict__ st,
+                                                 int* __restrict__ table, int* __restrict__ cell_of)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || st->error) return;
+    int b = find_elem(off, nb, i);
+    VoxGrid g = grids[b];
+    // (size_t)floor((p - origin) / dl), fp32 (grid_subsampling.cpp:53-55)
+    long long iX = (long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i], g.o[0]), g.dl));
+    long long iY = (long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], g.o[1]), g.dl));
+    long long iZ = (long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], g.o[2]), g.dl));
+    if (iX < 0 || iY < 0 || iZ < 0 || iX >= g.NX || iY >= g.NY || iZ >= g.NZ) {
+        // The reference's size_t cast of a negative floor (origin rounding) yields a wrapped key;
+        // a dense table cannot hold it.
+        atomicExch(&st->error, 2);
+        return;
+    }
+    long long c = g.table_off + iX + g.NX * iY + g.NX * g.NY * iZ;   // mapIdx (:56) + element offset
+    cell_of[i] = (int)c;
+    atomicAdd(&table[c], 1);
+}
+
+// heads: sorted position p starts a voxel run
+__global__ void __launch_bounds__(256) k_vox_heads(const float4* __restrict__ sorted, const int* __restrict__ cell_of, int n,
+                                                 const VoxStatus* __restrict__ st, int* __restrict__ head)
+{
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    if (st->error) { head[p] = 0; return; }
+    int c = cell_of[__float_as_int(sorted[p].w)];
+    int prev = p == 0 ? -1 : cell_of[__float_as_int(sorted[p - 1].w)];
+    head[p] = c != prev ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_vox_emit(const float4* __restrict__ sorted, const int* __restrict__ cell_of,
+                                                const int* __restrict__ table, const int* __restrict__ rowidx,
+                                                int n, const VoxStatus* __restrict__ st, float* __restrict__ out)
+{
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n || st->error) return;
+    int c = cell_of[__float_as_int(sorted[p].w)];
+    int s = c == 0 ? 0 : table[c - 1];
+    if (p != s) return;                      // not a run head
+    int e = table[c];
+    float sx = 0.f, sy = 0.f, sz = 0.f;      // SampledData.point += p, in input order (grid_subsampling.h:95-100)
+    for (int t = s; t < e; t++) {
+        float4 q = sorted[t];
+        sx = __fadd_rn(sx, q.x); sy = __fadd_rn(sy, q.y); sz = __fadd_rn(sz, q.z);
+    }
+    float w = (float)(1.0 / (double)(e - s));          // point * (1.0 / count): double -> float (:87)
+    int r = rowidx[p];
+    out[3 * (size_t)r] = __fmul_rn(sx, w);
+    out[3 * (size_t)r + 1] = __fmul_rn(sy, w);
+    out[3 * (size_t)r + 2] = __fmul_rn(sz, w);
+}
+
+// per-element row counts from the exclusive head scan; counts[nb] = status word
+__global__ void k_vox_counts(const int* __restrict__ rowidx, const int* __restrict__ off, int nb, int n, int total,
+                             const int* __restrict__ total_dev, VoxStatus* __restrict__ st, int* __restrict__ counts)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    int tot = *total_dev;
+    if (b == nb) { counts[nb] = st->error; counts[nb + 1] = tot; return; }
+    int lo = off[b], hi = off[b + 1];
+    int rlo = lo < n ? rowidx[lo] : tot;
+    int rhi = hi < n ? rowidx[hi] : tot;
+    counts[b] = rhi - rlo;
+}
+
+struct VoxWs {
+    VoxGrid* grids; VoxStatus* st; int* off; int* table; int* cell_of; float4* sorted_tmp; float4* sorted;
+    int* order; int* head; int* scan_tmp; int* total; int* counts; float* out_tmp;
+};
+
+static VoxWs carve_vox(WsCarver& w, int n, int nb, int64_t max_cells)
+{
+    VoxWs v;
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    v.grids = w.take<VoxGrid>((size_t)nb);
+    v.st = w.take<VoxStatus>(1);
+    v.off = w.take<int>((size_t)nb + 1);
+    v.table = w.take<int>((size_t)max_cells);
+    v.cell_of = w.take<int>(nn);
+    v.sorted_tmp = w.take<float4>(nn);
+    v.sorted = w.take<float4>(nn);
+    v.order = w.take<int>(nn);
+    v.head = w.take<int>(nn);
+    v.scan_tmp = w.take<int>(scan_tmp_ints());
+    v.total = w.take<int>(1);
+    v.counts = w.take<int>((size_t)nb + 2);
+    v.out_tmp = w.take<float>(3 * nn);
+    return v;
+}
+
+extern "C" size_t buf_grid_subsample_ws_bytes(int n, int nb, int64_t max_cells)
+{
+    WsCarver w(nullptr, 0);
+    carve_vox(w, n, nb, max_cells);
+    return w.used();
+}
+
+extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batches_host, int nb, float dl,
+                                        int max_p, float* out_pts, int* out_batches_host, int* out_m_host,
+                                        int64_t max_cells, void* ws, size_t ws_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    BUF_REQUIRE(batches_host && out_batches_host && out_m_host && ws, BUF_EINVAL, "buf_grid_subsample_batch: null argument");
+    BUF_REQUIRE(n >= 0 && nb > 0, BUF_EINVAL, "buf_grid_subsample_batch: n=%d nb=%d", n, nb);
+    BUF_REQUIRE(dl > 0.f, BUF_EINVAL, "buf_grid_subsample_batch: sampleDl=%g must be > 0", dl);
+    BUF_REQUIRE(max_cells > 0 && max_cells < 0x7fffffffLL, BUF_EINVAL, "buf_grid_subsample_batch: max_cells=%lld", (long long)max_cells);
+    BUF_REQUIRE(n == 0 || (pts && out_pts), BUF_EINVAL, "buf_grid_subsample_batch: null points");
+    WsCarver w(ws, ws_bytes);
+    VoxWs v = carve_vox(w, n, nb, max_cells);
+    BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_grid_subsample_batch: workspace %zu < %zu bytes", ws_bytes, w.used());
+    int rc = upload_offsets(v.off, batches_host, nb, n, "buf_grid_subsample_batch", s);
+    if (rc) return rc;
+    if (n == 0) {
+        for (int b = 0; b < nb; b++) out_batches_host[b] = 0;
+        *out_m_host = 0;
+        return BUF_OK;
+    }
+    BUF_CHECK_HIP(hipMemsetAsync(v.table, 0, sizeof(int) * (size_t)max_cells, s));
+    k_vox_bbox<<<nb, 1024, 0, s>>>(pts, v.off, v.grids, dl);
+    k_vox_offsets<<<1, 1, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
+    int blocks = cdiv(n, 256);
+    k_vox_count<<<blocks, 256, 0, s>>>(pts, n, v.off, nb, v.grids, v.st, v.table, v.cell_of);
+    rc = exclusive_scan_i32(v.table, (long long)max_cells, v.scan_tmp, nullptr, s);
+    if (rc) return rc;
+    k_cell_scatter<<<blocks, 256, 0, s>>>(pts, n, v.cell_of, &v.st->error, v.table, v.sorted_tmp);
+    k_cell_rank<<<blocks, 256, 0, s>>>(v.cell_of, v.table, v.sorted_tmp, n, &v.st->error, v.sorted, v.order);
+    k_vox_heads<<<blocks, 256, 0, s>>>(v.sorted, v.cell_of, n, v.st, v.head);
+    rc = exclusive_scan_i32(v.head, n, v.scan_tmp, v.total, s);
+    if (rc) return rc;
+    float* dst = max_p > 0 ? v.out_tmp : out_pts;
+    k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.cell_of, v.table, v.head, n, v.st, dst);
+    k_vox_counts<<<cdiv(nb + 1, 64), 64, 0, s>>>(v.head, v.off, nb, n, 0, v.total, v.st, v.counts);
+    BUF_LAUNCH_CHECK();
+    int stackc[66];
+    int* hc = nb + 2 <= 66 ? stackc : (int*)malloc(sizeof(int) * ((size_t)nb + 2));
+    hipError_t e = hipMemcpyAsync(hc, v.counts, sizeof(int) * ((size_t)nb + 2), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int err = hc[nb];
+    int m = 0;
+    rc = BUF_OK;
+    if (e != hipSuccess) { buf_set_error("buf_grid_subsample_batch: %s", hipGetErrorString(e)); rc = BUF_EHIP; }
+    else if (err == 1) { buf_set_error("buf_grid_subsample_batch: dense voxel table needs more than max_cells=%lld cells", (long long)max_cells); rc = BUF_ECAPACITY; }
+    else if (err == 2) { buf_set_error("buf_grid_subsample_batch: point below the grid origin (reference wraps the voxel key here)"); rc = BUF_ECAPACITY; }
+    else {
+        int src = 0;
+        for (int b = 0; b < nb; b++) {
+            int mb = hc[b];
+            int keep = (max_p > 0 && mb > max_p) ? max_p : mb;      // grid_subsampling.cpp:186-200, in OUR row order
+            if (max_p > 0 && keep > 0) {
+                hipError_t e2 = hipMemcpyAsync(out_pts + 3 * (size_t)m, v.out_tmp + 3 * (size_t)src, sizeof(float) * 3 * (size_t)keep,
+                                               hipMemcpyDeviceToDevice, s);
+                if (e2 != hipSuccess) { buf_set_error("buf_grid_subsample_batch: %s", hipGetErrorString(e2)); rc = BUF_EHIP; break; }
+            }
+            out_batches_host[b] = keep;
+            m += keep;
+            src += mb;
+        }
+        *out_m_host = m;
+    }
+    if (hc != stackc) free(hc);
+    return rc;
+}
