@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/*.c, oracle/torch_ref.py) against the golden vectors that the
+reference itself produced (tools/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from buffer_amd import synth
+from oracle import torch_ref as T
+from util import assert_neighbors_equal_mod_ties as nbr_eq
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def W():
+    from buffer_amd.weights import load_weights
+    return {k: torch.from_numpy(v) for k, v in load_weights("3dmatch").items()}
+
+
+def _sample(g):
+    return {k[3:]: g[k] for k in g.files if k.startswith('in_')}
+
+
+def _canon_rows(a):
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.mark.parametrize("name", ["pyramid_tiny.npz", "pyramid_5k.npz"])
+def test_pyramid_ops_match_reference(name, oracle):
+    """A1/A2 per operator on the reference's own arrays: every neighbour table index-exact, every
+    subsampled layer the same multiset of rows bit for bit (the reference emits rows in libstdc++
+    unordered_map order, we emit ascending voxel key)."""
+    g = load(name)
+    lim = g['limits']
+    r = 0.035 * 2.0
+    for l in range(3):
+        pts, lens = g[f'points_{l}'], g[f'lengths_{l}']
+        conv = oracle.radius_neighbors(pts, pts, lens, lens, r)[:, :lim[l]]
+        nbr_eq(conv, g[f'neighbors_{l}'], pts, pts)
+        if l < 2:
+            nxt, nlens = g[f'points_{l + 1}'], g[f'lengths_{l + 1}']
+            sub, sl = oracle.grid_subsample_batch(pts, lens, r)          # dl = 2 * r / conv_radius = r
+            assert np.array_equal(sl, nlens)
+            o = 0
+            for n in sl:
+                assert np.array_equal(_canon_rows(sub[o:o + n]).view(np.uint32),
+                                      _canon_rows(nxt[o:o + n]).view(np.uint32))
+                o += n
+            pool = oracle.radius_neighbors(nxt, pts, nlens, lens, r)[:, :lim[l]]
+            nbr_eq(pool, g[f'pools_{l}'], nxt, pts)
+            up = oracle.radius_neighbors(pts, nxt, lens, nlens, 2 * r)[:, :lim[l]]
+            nbr_eq(up, g[f'upsamples_{l}'], pts, nxt)
+        r *= 2
+
+
+@pytest.mark.parametrize("name", ["pyramid_tiny.npz", "pyramid_5k.npz"])
+def test_pyramid_composed_matches_reference(name, oracle):
+    """A0/A3 composed: limits equal; layer 1 is the reference's multiset bit for bit and its tables map
+    onto the reference's through the row permutation; layer 2 (barycentres of layer-1 rows summed in
+    OUR row order) agrees to fp32 round-off."""
+    g = load(name)
+    sample = _sample(g)
+    limits = T.calibrate_limits([sample])
+    assert np.array_equal(limits, g['limits'])
+    b = T.collate(sample, limits)
+    ours1, ref1 = b['points'][1].numpy(), g['points_1']
+    assert np.array_equal(b['stack_lengths'][1].numpy(), g['lengths_1'])
+    lo, lr = np.lexsort(ours1.T[::-1]), np.lexsort(ref1.T[::-1])
+    assert np.array_equal(ours1[lo].view(np.uint32), ref1[lr].view(np.uint32))
+    perm1 = np.empty(len(ours1), np.int64)
+    perm1[lo] = lr                                   # perm1[our row] = reference row
+    n0 = len(g['points_0'])
+    nbr_eq(b['neighbors'][0].numpy(), g['neighbors_0'], g['points_0'], g['points_0'])
+    lut1 = np.concatenate([perm1, [len(perm1)]])
+    up0 = lut1[b['upsamples'][0].numpy()]
+    nbr_eq(up0, g['upsamples_0'], g['points_0'], ref1)
+    pool0 = np.empty_like(g['pools_0'])
+    pool0[perm1] = b['pools'][0].numpy()
+    nbr_eq(pool0, g['pools_0'], ref1, g['points_0'])
+    conv1 = np.empty_like(g['neighbors_1'])
+    conv1[perm1] = lut1[b['neighbors'][1].numpy()]
+    nbr_eq(conv1, g['neighbors_1'], ref1, ref1)
+    assert np.array_equal(b['stack_lengths'][2].numpy(), g['lengths_2'])
+    ours2, ref2 = b['points'][2].numpy(), g['points_2']
+    np.testing.assert_allclose(_canon_rows(ours2), _canon_rows(ref2), rtol=0, atol=1e-6)
+    assert n0 == len(b['points'][0])
+
+
+def _ref_batch(g):
+    return dict(points=[torch.from_numpy(g[f'points_{l}']) for l in range(3)],
+                neighbors=[torch.from_numpy(g[f'neighbors_{l}']).long() for l in range(3)],
+                pools=[torch.from_numpy(g[f'pools_{l}']).long() for l in range(3)],
+                upsamples=[torch.from_numpy(g[f'upsamples_{l}']).long() for l in range(3)])
+
+
+def test_point_learner_matches_reference(W):
+    """A4/A5 on the reference's own pyramid tables."""
+    g, f = load("pyramid_tiny.npz"), load("point_learner_tiny.npz")
+    batch = _ref_batch(g)
+    batch['features'] = torch.from_numpy(f['features'])
+    with torch.no_grad():
+        axis, eps, bottle, skips, blocks = T.efcnn_forward(batch, W, return_blocks=True)
+        score = T.detnet_forward(batch, bottle, skips, W)
+    for i in range(5):
+        np.testing.assert_allclose(blocks[i].numpy(), f[f'block{i}'], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(axis.numpy(), f['axis'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(eps.numpy(), f['eps'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(score.numpy(), f['score'], rtol=1e-3, atol=1e-4)
+
+
+def test_desc_matches_reference(W):
+    """A8-A11 with the reference's permutation of the support cloud."""
+    f = load("desc_tiny.npz")
+    with torch.no_grad():
+        out = T.desc_forward(torch.from_numpy(f['raw']), torch.from_numpy(f['kpts']), torch.from_numpy(f['kaxis']),
+                             torch.from_numpy(f['perm']), W)
+        inv = T.spt(out['patches'])
+    np.testing.assert_allclose(out['patches'].numpy(), f['patches'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out['R'].numpy(), f['R'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out['rand_axis'].numpy(), f['rand_axis'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(inv[:8].numpy(), f['spt_first8'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(inv.sum((2, 3)).numpy(), f['spt_sum'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out['desc'].numpy(), f['desc'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out['equi'].numpy(), f['equi'], rtol=1e-4, atol=1e-5)
+
+
+def test_matching_and_pose_match_reference(W):
+    """A12-A14, A16."""
+    f = load("match_tiny.npz")
+    sd, td = torch.from_numpy(f['src_desc']), torch.from_numpy(f['tgt_desc'])
+    s_mids, t_mids = T.mutual_matching(sd, td)
+    assert np.array_equal(s_mids, f['s_mids']) and np.array_equal(t_mids, f['t_mids'])
+    se, te = torch.from_numpy(f['src_equi'])[s_mids], torch.from_numpy(f['tgt_equi'])[t_mids]
+    with torch.no_grad():
+        ind = T.cost_volume(se[:, :, 1:6], te[:, :, 1:6], W)
+    np.testing.assert_allclose(ind.numpy(), f['ind'], rtol=1e-4, atol=1e-4)
+    ss, tt = torch.from_numpy(f['src_kpts'])[s_mids], torch.from_numpy(f['tgt_kpts'])[t_mids]
+    R, t = T.hypotheses(torch.from_numpy(f['ind']), ss, tt, torch.from_numpy(f['src_R'])[s_mids],
+                        torch.from_numpy(f['tgt_R'])[t_mids])
+    np.testing.assert_allclose(R.numpy(), f['R_hyp'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(t.numpy(), f['t_hyp'], rtol=0, atol=1e-5)
+    num, best, inl = T.score_hypotheses(torch.from_numpy(f['R_hyp']), torch.from_numpy(f['t_hyp']), ss, tt)
+    assert np.array_equal(num.numpy(), f['inlier_num']) and best == int(f['best'])
+    assert np.array_equal(inl.numpy(), f['inlier_ind'])
+    refined = T.post_refinement(torch.from_numpy(f['init_pose']), ss[None], tt[None])
+    np.testing.assert_allclose(refined.numpy(), f['refined_pose'], rtol=0, atol=1e-5)
