@@ -42,6 +42,25 @@ _SIGNATURES = {
     "buf_radius_neighbors": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "buf_grid_subsample_ws_bytes": (_sz, [_i, _i, _i64]),
     "buf_grid_subsample_batch": (_i, [_vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "buf_fps_ws_bytes": (_sz, [_i, _i]),
+    "buf_fps": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "buf_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "buf_group": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "buf_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "buf_three_nn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "buf_select_patches": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp]),
+    "buf_knn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "buf_svd3x3_batched": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "buf_vn_gather_block": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "buf_vn_pointwise": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "buf_gather_max": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "buf_vn_std": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "buf_patch_voxelize": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp]),
+    "buf_hypotheses_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_ransac_ws_bytes": (_sz, [_i]),
+    "buf_ransac_kabsch": (_i, [_vp, _vp, _vp, _i, _i, C.c_uint64, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "buf_post_refine": (_i, [_vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
 }
 
 

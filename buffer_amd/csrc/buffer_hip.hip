@@ -4,3 +4,7 @@
 #include "core.hip"
 #include "radius.hip"
 #include "subsample.hip"
+#include "pointops.hip"
+#include "vn.hip"
+#include "voxelize.hip"
+#include "registration.hip"

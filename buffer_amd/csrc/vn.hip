@@ -1,0 +1,267 @@
+// A4/A5 -- Vector-Neuron blocks of the point-wise learner (models/point_learner.py, models/vn_layers.py).
+//
+// Feature rows are f32[N, 3C], channel-major / xyz-minor (point_learner.py:196,261,407).
+// One lane per (point, output channel): the lanes of one point read the same gathered rows (one
+// transaction), weights sit in LDS.  Nothing of size [N,K,C] is ever materialised: the reference
+// moves ~0.5 GB per block through [1,C,3,N,K] temporaries, here the traffic is the index table,
+// the gathered rows and the [N,3Cout] result.
+#include "common.h"
+
+#define VN_EPS 1e-6f     // models/vn_layers.py:10
+
+struct VnParams {
+    const float* wf;        // [Cout, Cin']  map_to_feat
+    const float* wd;        // [Cout, Cin']  map_to_dir   (null: linear only)
+    const float* bn_scale;  // [Cout] w / sqrt(var + 1e-5) (null: no VN batch-norm, i.e. Cout == 1)
+    const float* bn_shift;  // [Cout] b - mean * scale
+    float slope;            // negative_slope
+};
+
+// VNBatchNorm (vn_layers.py:108-130) + VN leaky ReLU (:69-75) on one output channel
+__device__ __forceinline__ void vn_epilogue(float& px, float& py, float& pz, float dx, float dy, float dz,
+                                            bool has_bn, float bsc, float bsh, float slope)
+{
+    if (has_bn) {
+        float norm = sqrtf(px * px + py * py + pz * pz) + VN_EPS;
+        float nbn = norm * bsc + bsh;
+        px = px / norm * nbn; py = py / norm * nbn; pz = pz / norm * nbn;
+    }
+    float dot = px * dx + py * dy + pz * dz;
+    if (!(dot >= 0.f)) {
+        float dsq = dx * dx + dy * dy + dz * dz;
+        float f = dot / (dsq + VN_EPS);
+        float rx = px - f * dx, ry = py - f * dy, rz = pz - f * dz;
+        px = slope * px + (1.f - slope) * rx;
+        py = slope * py + (1.f - slope) * ry;
+        pz = slope * pz + (1.f - slope) * rz;
+    } else {
+        px = slope * px + (1.f - slope) * px;
+        py = slope * py + (1.f - slope) * py;
+        pz = slope * pz + (1.f - slope) * pz;
+    }
+}
+
+// VNNBlock / the conv half of VNNResnetBlock (point_learner.py:315-416, 467-552):
+// gather neighbours -> [f, delta] (mode '1') or [f, delta, f x delta, mean_K(delta)] (mode '6', Cin == 1)
+// -> VN-linear -> VN-BN -> VN-leaky -> mean over ALL K slots (shadows included).
+__global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                 const float* __restrict__ feats, const int* __restrict__ idx,
+                                                 int nq, int ns, int K, int cin, int cout, int mode6, float scale,
+                                                 VnParams P, float* __restrict__ out)
+{
+    extern __shared__ float lds[];
+    const int cinp = cin + (mode6 ? 3 : 1);
+    float* wf = lds;
+    float* wd = lds + cout * cinp;
+    for (int t = threadIdx.x; t < cout * cinp; t += 256) { wf[t] = P.wf[t]; wd[t] = P.wd[t]; }
+    __syncthreads();
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)nq * cout) return;
+    int i = (int)(t / cout), o = (int)(t % cout);
+    const float* wfo = wf + o * cinp;
+    const float* wdo = wd + o * cinp;
+    bool has_bn = P.bn_scale != nullptr;
+    float bsc = has_bn ? P.bn_scale[o] : 0.f, bsh = has_bn ? P.bn_shift[o] : 0.f;
+    float qx = q_pts[3 * (size_t)i], qy = q_pts[3 * (size_t)i + 1], qz = q_pts[3 * (size_t)i + 2];
+    const int* row = idx + (size_t)i * K;
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    if (mode6) {                                            // mean over K of delta (point_learner.py:392)
+        for (int k = 0; k < K; k++) {
+            int j = row[k];
+            if (j < ns) {
+                mx += (s_pts[3 * (size_t)j] - qx) / scale;
+                my += (s_pts[3 * (size_t)j + 1] - qy) / scale;
+                mz += (s_pts[3 * (size_t)j + 2] - qz) / scale;
+            }
+        }
+        mx /= (float)K; my /= (float)K; mz /= (float)K;
+    }
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < K; k++) {
+        int j = row[k];
+        bool real = j < ns;                                  // shadow: delta = 0, features = 0 (:329-349)
+        float ex = 0.f, ey = 0.f, ez = 0.f;
+        if (real) {
+            ex = (s_pts[3 * (size_t)j] - qx) / scale;
+            ey = (s_pts[3 * (size_t)j + 1] - qy) / scale;
+            ez = (s_pts[3 * (size_t)j + 2] - qz) / scale;
+        }
+        float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+        if (mode6) {
+            float fx = 0.f, fy = 0.f, fz = 0.f;
+            if (real) { fx = feats[3 * (size_t)j]; fy = feats[3 * (size_t)j + 1]; fz = feats[3 * (size_t)j + 2]; }
+            float cx = fy * ez - fz * ey, cy = fz * ex - fx * ez, cz = fx * ey - fy * ex;
+            px = wfo[0] * fx + wfo[1] * ex + wfo[2] * cx + wfo[3] * mx;
+            py = wfo[0] * fy + wfo[1] * ey + wfo[2] * cy + wfo[3] * my;
+            pz = wfo[0] * fz + wfo[1] * ez + wfo[2] * cz + wfo[3] * mz;
+            dx = wdo[0] * fx + wdo[1] * ex + wdo[2] * cx + wdo[3] * mx;
+            dy = wdo[0] * fy + wdo[1] * ey + wdo[2] * cy + wdo[3] * my;
+            dz = wdo[0] * fz + wdo[1] * ez + wdo[2] * cz + wdo[3] * mz;
+        } else {
+            if (real) {
+                const float* f = feats + (size_t)j * 3 * cin;
+                for (int c = 0; c < cin; c++) {
+                    float a = wfo[c], b = wdo[c];
+                    float fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
+                    px = fmaf(a, fx, px); py = fmaf(a, fy, py); pz = fmaf(a, fz, pz);
+                    dx = fmaf(b, fx, dx); dy = fmaf(b, fy, dy); dz = fmaf(b, fz, dz);
+                }
+                float a = wfo[cin], b = wdo[cin];
+                px = fmaf(a, ex, px); py = fmaf(a, ey, py); pz = fmaf(a, ez, pz);
+                dx = fmaf(b, ex, dx); dy = fmaf(b, ey, dy); dz = fmaf(b, ez, dz);
+            }
+        }
+        vn_epilogue(px, py, pz, dx, dy, dz, has_bn, bsc, bsh, P.slope);
+        ax += px; ay += py; az += pz;
+    }
+    float* dst = out + (size_t)i * 3 * cout + 3 * o;
+    dst[0] = ax / (float)K; dst[1] = ay / (float)K; dst[2] = az / (float)K;      // mean_pool, vn_layers.py:165-166
+}
+
+// Point-wise VN layer (VNLinearLeakyReLU with dim=4; VNBlock, unary, shortcut, fc_layer, VNStdFeature):
+//   in_i = concat( A[ia(i)] (ca channels; row through ind_a[i*ind_stride], >= na -> zeros) , B[i] (cb channels) )
+//   out_i = VN(in_i) (+ residual_i)
+// ind_a implements closest_pool (models/KPConv/blocks.py:88-101), B the skip concat (point_learner.py:189-191),
+// residual the resnet sum (:577).  wd == null: plain VNLinear (VNStdFeature.vn_lin).
+__global__ void __launch_bounds__(256) k_vn_pointwise(const float* __restrict__ A, const int* __restrict__ ind_a, int ind_stride,
+                                                    int na, int ca, const float* __restrict__ B, int cb, int n, int cout,
+                                                    VnParams P, const float* __restrict__ residual, float* __restrict__ out)
+{
+    extern __shared__ float lds[];
+    const int cin = ca + cb;
+    float* wf = lds;
+    float* wd = lds + cout * cin;
+    bool has_dir = P.wd != nullptr;
+    for (int t = threadIdx.x; t < cout * cin; t += 256) { wf[t] = P.wf[t]; if (has_dir) wd[t] = P.wd[t]; }
+    __syncthreads();
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * cout) return;
+    int i = (int)(t / cout), o = (int)(t % cout);
+    const float* wfo = wf + o * cin;
+    const float* wdo = wd + o * cin;
+    float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    int ia = ind_a ? ind_a[(size_t)i * ind_stride] : i;
+    if (ca > 0 && ia < na) {
+        const float* f = A + (size_t)ia * 3 * ca;
+        for (int c = 0; c < ca; c++) {
+            float a = wfo[c], b = has_dir ? wdo[c] : 0.f;
+            float fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
+            px = fmaf(a, fx, px); py = fmaf(a, fy, py); pz = fmaf(a, fz, pz);
+            dx = fmaf(b, fx, dx); dy = fmaf(b, fy, dy); dz = fmaf(b, fz, dz);
+        }
+    }
+    if (cb > 0) {
+        const float* f = B + (size_t)i * 3 * cb;
+        for (int c = 0; c < cb; c++) {
+            float a = wfo[ca + c], b = has_dir ? wdo[ca + c] : 0.f;
+            float fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
+            px = fmaf(a, fx, px); py = fmaf(a, fy, py); pz = fmaf(a, fz, pz);
+            dx = fmaf(b, fx, dx); dy = fmaf(b, fy, dy); dz = fmaf(b, fz, dz);
+        }
+    }
+    if (has_dir) {
+        bool has_bn = P.bn_scale != nullptr;
+        vn_epilogue(px, py, pz, dx, dy, dz, has_bn, has_bn ? P.bn_scale[o] : 0.f, has_bn ? P.bn_shift[o] : 0.f, P.slope);
+    }
+    size_t off = (size_t)i * 3 * cout + 3 * o;
+    if (residual) { px += residual[off]; py += residual[off + 1]; pz += residual[off + 2]; }
+    out[off] = px; out[off + 1] = py; out[off + 2] = pz;
+}
+
+// max_pool (models/KPConv/blocks.py:104-121): element-wise max over the gathered rows, zero shadow row.
+__global__ void __launch_bounds__(256) k_gather_max(const float* __restrict__ feats, const int* __restrict__ idx, int nq, int ns,
+                                                  int K, int width, float* __restrict__ out)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)nq * width) return;
+    int i = (int)(t / width), f = (int)(t % width);
+    const int* row = idx + (size_t)i * K;
+    float m = -3.4e38f;
+    for (int k = 0; k < K; k++) {
+        int j = row[k];
+        float v = j < ns ? feats[(size_t)j * width + f] : 0.f;
+        m = fmaxf(m, v);
+    }
+    out[t] = m;
+}
+
+// VNStdFeature tail (vn_layers.py:213-219): x_std[i, c*3+k] = sum_j x[i,c,j] * z[i,k,j]
+__global__ void __launch_bounds__(256) k_vn_std(const float* __restrict__ x, const float* __restrict__ z, int n, int c,
+                                              float* __restrict__ out)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * c * 3) return;
+    int i = (int)(t / (c * 3)), r = (int)(t % (c * 3));
+    int ch = r / 3, k = r % 3;
+    const float* xv = x + (size_t)i * 3 * c + 3 * ch;
+    const float* zv = z + (size_t)i * 9 + 3 * k;
+    out[t] = xv[0] * zv[0] + xv[1] * zv[1] + xv[2] * zv[2];
+}
+
+// ------------------------------------------------------------------------------------------
+static VnParams make_params(const float* wf, const float* wd, const float* bn_scale, const float* bn_shift, float slope)
+{
+    VnParams p;
+    p.wf = wf; p.wd = wd; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.slope = slope;
+    return p;
+}
+
+extern "C" int buf_vn_gather_block(const float* q_pts, const float* s_pts, const float* feats, const int* idx,
+                                   int nq, int ns, int k, int cin, int cout, int mode, float scale,
+                                   const float* wf, const float* wd, const float* bn_scale, const float* bn_shift,
+                                   float slope, float* out, void* stream)
+{
+    BUF_REQUIRE(nq >= 0 && ns >= 0 && k > 0 && cin > 0 && cout > 0, BUF_EINVAL, "buf_vn_gather_block: bad sizes");
+    BUF_REQUIRE(mode == 1 || mode == 6, BUF_EINVAL, "buf_vn_gather_block: mode %d (only '1' and '6' are reachable)", mode);
+    BUF_REQUIRE(mode != 6 || cin == 1, BUF_EINVAL, "buf_vn_gather_block: mode '6' needs one input vector channel");
+    BUF_REQUIRE(scale != 0.f, BUF_EINVAL, "buf_vn_gather_block: scale == 0");
+    if (nq == 0) return BUF_OK;
+    BUF_REQUIRE(q_pts && s_pts && feats && idx && wf && wd && out, BUF_EINVAL, "buf_vn_gather_block: null argument");
+    int cinp = cin + (mode == 6 ? 3 : 1);
+    size_t lds = sizeof(float) * 2 * (size_t)cout * cinp;
+    long long total = (long long)nq * cout;
+    k_vn_gather<<<cdiv(total, 256), 256, lds, (hipStream_t)stream>>>(q_pts, s_pts, feats, idx, nq, ns, k, cin, cout,
+                                                                   mode == 6 ? 1 : 0, scale,
+                                                                   make_params(wf, wd, bn_scale, bn_shift, slope), out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+extern "C" int buf_vn_pointwise(const float* a, const int* ind_a, int ind_stride, int na, int ca, const float* b, int cb,
+                                int n, int cout, const float* wf, const float* wd, const float* bn_scale,
+                                const float* bn_shift, float slope, const float* residual, float* out, void* stream)
+{
+    BUF_REQUIRE(n >= 0 && ca >= 0 && cb >= 0 && ca + cb > 0 && cout > 0, BUF_EINVAL, "buf_vn_pointwise: bad sizes");
+    if (n == 0) return BUF_OK;
+    BUF_REQUIRE(wf && out && (ca == 0 || a) && (cb == 0 || b), BUF_EINVAL, "buf_vn_pointwise: null argument");
+    size_t lds = sizeof(float) * 2 * (size_t)cout * (ca + cb);
+    BUF_REQUIRE(lds <= 64 * 1024, BUF_EINVAL, "buf_vn_pointwise: weights exceed 64 KiB of LDS");
+    long long total = (long long)n * cout;
+    k_vn_pointwise<<<cdiv(total, 256), 256, lds, (hipStream_t)stream>>>(a, ind_a, ind_stride, na, ca, b, cb, n, cout,
+                                                                      make_params(wf, wd, bn_scale, bn_shift, slope),
+                                                                      residual, out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+extern "C" int buf_gather_max(const float* feats, const int* idx, int nq, int ns, int k, int width, float* out, void* stream)
+{
+    BUF_REQUIRE(nq >= 0 && ns >= 0 && k > 0 && width > 0, BUF_EINVAL, "buf_gather_max: bad sizes");
+    if (nq == 0) return BUF_OK;
+    BUF_REQUIRE(feats && idx && out, BUF_EINVAL, "buf_gather_max: null argument");
+    long long total = (long long)nq * width;
+    k_gather_max<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(feats, idx, nq, ns, k, width, out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+extern "C" int buf_vn_std(const float* x, const float* z, int n, int c, float* out, void* stream)
+{
+    BUF_REQUIRE(n >= 0 && c > 0, BUF_EINVAL, "buf_vn_std: bad sizes");
+    if (n == 0) return BUF_OK;
+    BUF_REQUIRE(x && z && out, BUF_EINVAL, "buf_vn_std: null argument");
+    long long total = (long long)n * c * 3;
+    k_vn_std<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(x, z, n, c, out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

@@ -115,3 +115,225 @@ def grid_subsample_batch(points, lengths, dl, max_p=0, max_cells=0):
                                      _hptr(out_b), C.byref(m), max_cells, _ptr(ws), nbytes, _stream()),
           "buf_grid_subsample_batch")
     return out[:m.value], out_b
+
+
+# ----------------------------------------------------------------------------- pointnet2 / knn / svd
+def furthest_point_sample(xyz, npoint):
+    """xyz f32[B,N,3] -> int32[B,npoint]."""
+    L = _lib.lib()
+    xyz = _dev(xyz, torch.float32, "furthest_point_sample")
+    b, n, _ = xyz.shape
+    out = torch.empty((b, npoint), dtype=torch.int32, device=xyz.device)
+    nbytes = L.buf_fps_ws_bytes(b, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+    check(L.buf_fps(_ptr(xyz), b, n, int(npoint), _ptr(out), _ptr(ws), nbytes, _stream()), "buf_fps")
+    return out
+
+
+def gather_operation(feat, idx):
+    """feat f32[B,C,N], idx int32[B,M] -> f32[B,C,M]."""
+    L = _lib.lib()
+    feat, idx = _dev(feat, torch.float32, "gather_operation"), _dev(idx, torch.int32, "gather_operation")
+    b, c, n = feat.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=feat.device)
+    check(L.buf_gather(_ptr(feat), _ptr(idx), b, c, n, m, _ptr(out), _stream()), "buf_gather")
+    return out
+
+
+def grouping_operation(feat, idx):
+    """feat f32[B,C,N], idx int32[B,M,S] -> f32[B,C,M,S]."""
+    L = _lib.lib()
+    feat, idx = _dev(feat, torch.float32, "grouping_operation"), _dev(idx, torch.int32, "grouping_operation")
+    b, c, n = feat.shape
+    _, m, s = idx.shape
+    out = torch.empty((b, c, m, s), dtype=torch.float32, device=feat.device)
+    check(L.buf_group(_ptr(feat), _ptr(idx), b, c, n, m, s, _ptr(out), _stream()), "buf_group")
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """xyz f32[B,N,3], new_xyz f32[B,M,3] -> int32[B,M,nsample]."""
+    L = _lib.lib()
+    xyz, new_xyz = _dev(xyz, torch.float32, "ball_query"), _dev(new_xyz, torch.float32, "ball_query")
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    out = torch.zeros((b, m, nsample), dtype=torch.int32, device=xyz.device)
+    check(L.buf_ball_query(_ptr(xyz), _ptr(new_xyz), b, n, m, float(radius), int(nsample), _ptr(out), _stream()),
+          "buf_ball_query")
+    return out
+
+
+def three_nn(unknown, known):
+    L = _lib.lib()
+    unknown, known = _dev(unknown, torch.float32, "three_nn"), _dev(known, torch.float32, "three_nn")
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknown.device)
+    check(L.buf_three_nn(_ptr(unknown), _ptr(known), b, n, m, _ptr(dist), _ptr(idx), _stream()), "buf_three_nn")
+    return dist, idx
+
+
+def select_patches(pts, kpts, radius, nsample):
+    """pts f32[N,3] (already permuted), kpts f32[P,3] -> f32[P,nsample,3]."""
+    L = _lib.lib()
+    pts, kpts = _dev(pts, torch.float32, "select_patches"), _dev(kpts, torch.float32, "select_patches")
+    out = torch.empty((kpts.shape[0], nsample, 3), dtype=torch.float32, device=pts.device)
+    check(L.buf_select_patches(_ptr(pts), _ptr(kpts), pts.shape[0], kpts.shape[0], float(radius), int(nsample),
+                               _ptr(out), _stream()), "buf_select_patches")
+    return out
+
+
+def knn(ref, query, k):
+    """ref f32[B,N,D], query f32[B,Q,D] -> (dist f32[B,Q,k], idx int64[B,Q,k])."""
+    L = _lib.lib()
+    ref, query = _dev(ref, torch.float32, "knn"), _dev(query, torch.float32, "knn")
+    b, n, d = ref.shape
+    q = query.shape[1]
+    dist = torch.empty((b, q, k), dtype=torch.float32, device=ref.device)
+    idx = torch.empty((b, q, k), dtype=torch.int64, device=ref.device)
+    check(L.buf_knn(_ptr(ref), _ptr(query), b, n, q, d, int(k), _ptr(dist), _ptr(idx), _stream()), "buf_knn")
+    return dist, idx
+
+
+def svd3x3(a):
+    """a f32[B,3,3] -> (U, S, V), a = U diag(S) V^T."""
+    L = _lib.lib()
+    a = _dev(a, torch.float32, "svd3x3")
+    n = a.shape[0]
+    u, v = torch.empty_like(a), torch.empty_like(a)
+    s = torch.empty((n, 3), dtype=torch.float32, device=a.device)
+    check(L.buf_svd3x3_batched(_ptr(a), n, _ptr(u), _ptr(s), _ptr(v), _stream()), "buf_svd3x3_batched")
+    return u, s, v
+
+
+# ----------------------------------------------------------------------------- VN blocks
+class VnLayer:
+    """Device copy of one VNLinearLeakyReLU (map_to_feat / map_to_dir / VN batch-norm folded)."""
+
+    def __init__(self, W, prefix, device, slope=0.2, linear_only=False):
+        if linear_only:
+            self.wf = torch.as_tensor(W[prefix + '.weight'], dtype=torch.float32, device=device).contiguous()
+            self.wd = self.bsc = self.bsh = None
+        else:
+            self.wf = torch.as_tensor(W[prefix + '.map_to_feat.weight'], dtype=torch.float32, device=device).contiguous()
+            self.wd = torch.as_tensor(W[prefix + '.map_to_dir.weight'], dtype=torch.float32, device=device).contiguous()
+            self.bsc = self.bsh = None
+            if self.wf.shape[0] != 1:                                  # vn_layers.py:123
+                g = np.asarray(W[prefix + '.batchnorm.bn.weight'], np.float64)
+                b = np.asarray(W[prefix + '.batchnorm.bn.bias'], np.float64)
+                m = np.asarray(W[prefix + '.batchnorm.bn.running_mean'], np.float64)
+                v = np.asarray(W[prefix + '.batchnorm.bn.running_var'], np.float64)
+                sc = g / np.sqrt(v + 1e-5)
+                self.bsc = torch.tensor(sc, dtype=torch.float32, device=device)
+                self.bsh = torch.tensor(b - m * sc, dtype=torch.float32, device=device)
+        self.cout, self.cin = int(self.wf.shape[0]), int(self.wf.shape[1])
+        self.slope = float(slope)
+
+
+def vn_gather_block(layer, q_pts, s_pts, feats, idx, mode, scale=1.0):
+    """VNNBlock / conv half of VNNResnetBlock -> f32[nq, 3*cout]."""
+    L = _lib.lib()
+    nq, k = idx.shape
+    ns = s_pts.shape[0]
+    cin = feats.shape[1] // 3
+    out = torch.empty((nq, 3 * layer.cout), dtype=torch.float32, device=feats.device)
+    check(L.buf_vn_gather_block(_ptr(q_pts), _ptr(s_pts), _ptr(feats), _ptr(idx), nq, ns, k, cin, layer.cout, int(mode),
+                                float(scale), _ptr(layer.wf), _ptr(layer.wd), _ptr(layer.bsc), _ptr(layer.bsh),
+                                layer.slope, _ptr(out), _stream()), "buf_vn_gather_block")
+    return out
+
+
+def vn_pointwise(layer, b, a=None, ind_a=None, residual=None):
+    """VN layer on concat(a[ind_a[:,0]], b) (+ residual) -> f32[n, 3*cout]."""
+    L = _lib.lib()
+    n = b.shape[0] if b is not None else (ind_a.shape[0] if ind_a is not None else a.shape[0])
+    ca = a.shape[1] // 3 if a is not None else 0
+    cb = b.shape[1] // 3 if b is not None else 0
+    dev = (b if b is not None else a).device
+    out = torch.empty((n, 3 * layer.cout), dtype=torch.float32, device=dev)
+    stride = ind_a.shape[1] if ind_a is not None else 0
+    check(L.buf_vn_pointwise(_ptr(a), _ptr(ind_a), stride, a.shape[0] if a is not None else 0, ca, _ptr(b), cb, n,
+                             layer.cout, _ptr(layer.wf), _ptr(layer.wd), _ptr(layer.bsc), _ptr(layer.bsh), layer.slope,
+                             _ptr(residual), _ptr(out), _stream()), "buf_vn_pointwise")
+    return out
+
+
+def gather_max(feats, idx):
+    L = _lib.lib()
+    nq, k = idx.shape
+    out = torch.empty((nq, feats.shape[1]), dtype=torch.float32, device=feats.device)
+    check(L.buf_gather_max(_ptr(feats), _ptr(idx), nq, feats.shape[0], k, feats.shape[1], _ptr(out), _stream()),
+          "buf_gather_max")
+    return out
+
+
+def vn_std(x, z):
+    L = _lib.lib()
+    n, c = x.shape[0], x.shape[1] // 3
+    out = torch.empty((n, 3 * c), dtype=torch.float32, device=x.device)
+    check(L.buf_vn_std(_ptr(x), _ptr(z), n, c, _ptr(out), _stream()), "buf_vn_std")
+    return out
+
+
+# ----------------------------------------------------------------------------- patch voxelisation
+def patch_voxelize(patches, axis, des_r, centres, azi_cs, voxel_r, nsample, mlp_w, mlp_b, bn_scale, bn_shift,
+                   azi_n=20, want_patches=False):
+    """patches f32[P,S,3] -> (x f32[P,16,ncentres], R f32[P,3,3], rand_axis f32[P,3], patches_norm|None)."""
+    L = _lib.lib()
+    P, S, _ = patches.shape
+    nc = centres.shape[0]
+    dev = patches.device
+    x = torch.empty((P, 16, nc), dtype=torch.float32, device=dev)
+    R = torch.empty((P, 3, 3), dtype=torch.float32, device=dev)
+    ra = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    pn = torch.empty((P, S, 3), dtype=torch.float32, device=dev) if want_patches else None
+    hw = [np.ascontiguousarray(a, dtype=np.float32) for a in (mlp_w, mlp_b, bn_scale, bn_shift)]
+    check(L.buf_patch_voxelize(_ptr(patches), _ptr(axis), P, S, float(des_r), _ptr(centres), nc, int(azi_n),
+                               _ptr(azi_cs), float(voxel_r), int(nsample), _hptr(hw[0]), _hptr(hw[1]), _hptr(hw[2]),
+                               _hptr(hw[3]), _ptr(x), _ptr(R), _ptr(ra), _ptr(pn), _stream()), "buf_patch_voxelize")
+    return x, R, ra, pn
+
+
+# ----------------------------------------------------------------------------- pose recovery
+def hypotheses_score(ind, ss_kpts, tt_kpts, ss_R, tt_R, azi_n=20, inlier_th=1 / 3):
+    L = _lib.lib()
+    m = ind.shape[0]
+    dev = ind.device
+    R = torch.empty((m, 3, 3), dtype=torch.float32, device=dev)
+    t = torch.empty((m, 3), dtype=torch.float32, device=dev)
+    num = torch.empty((m,), dtype=torch.int32, device=dev)
+    best = torch.zeros((1,), dtype=torch.int32, device=dev)
+    mask = torch.zeros((m,), dtype=torch.uint8, device=dev)
+    check(L.buf_hypotheses_score(_ptr(ind.contiguous()), _ptr(ss_kpts.contiguous()), _ptr(tt_kpts.contiguous()),
+                                 _ptr(ss_R.contiguous()), _ptr(tt_R.contiguous()), m, int(azi_n), float(inlier_th),
+                                 _ptr(R), _ptr(t), _ptr(num), _ptr(best), _ptr(mask), _stream()),
+          "buf_hypotheses_score")
+    return R, t, num, best, mask
+
+
+def ransac_kabsch(src, tgt, corr, nhyp=4096, seed=0, max_dist=0.10, edge_similarity=0.8):
+    """-> (T f32[4,4], info int32[2])."""
+    L = _lib.lib()
+    dev = src.device
+    corr = _dev(corr, torch.int32, "ransac_kabsch")
+    T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+    info = torch.zeros((2,), dtype=torch.int32, device=dev)
+    nbytes = L.buf_ransac_ws_bytes(int(nhyp))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(L.buf_ransac_kabsch(_ptr(src.contiguous()), _ptr(tgt.contiguous()), _ptr(corr), corr.shape[0], int(nhyp),
+                              int(seed), float(max_dist), float(edge_similarity), _ptr(T), _ptr(info), _ptr(ws), nbytes,
+                              _stream()), "buf_ransac_kabsch")
+    return T, info
+
+
+def post_refine(T_init, src, tgt, thr=0.10, iters=20):
+    L = _lib.lib()
+    dev = src.device
+    T_init = _dev(T_init, torch.float32, "post_refine").reshape(4, 4)
+    T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+    info = torch.zeros((2,), dtype=torch.int32, device=dev)
+    check(L.buf_post_refine(_ptr(T_init), _ptr(src.contiguous()), _ptr(tgt.contiguous()), src.shape[0], float(thr),
+                            int(iters), _ptr(T), _ptr(info), _stream()), "buf_post_refine")
+    return T, info

@@ -1,0 +1,107 @@
+"""A8-A11 -- patch-wise embedder (MiniSpinNet, models/patch_embedder.py) on device.
+
+select_patches and the fused align/voxelise/point-MLP run as hand-written kernels (csrc/pointops.hip,
+csrc/voxelize.hip); the dense Cylindrical_Net stack (models/patchnet.py:15-85) currently goes through
+torch's convolution (MIOpen) with the reference's circular-azimuth / zero-elevation padding -- the
+hand-written MFMA implicit GEMM is SURVEY 8(f) N2.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def voxel_centres(rad_n, azi_n, ele_n, radius=1.0):
+    """get_voxel_coordinate (utils/common.py:248-262,422-428): f32[rad_n*ele_n*azi_n,3], rad->ele->azi."""
+    beta = np.linspace(0, np.pi, ele_n, endpoint=False) + np.pi / ele_n / 2
+    alpha = np.linspace(0, 2 * np.pi, azi_n, endpoint=False) + np.pi / azi_n
+    B, A = np.meshgrid(beta, alpha, indexing='ij')
+    B, A = B.flatten(), A.flatten()
+    s2 = np.stack([radius * np.sin(B) * np.cos(A), radius * np.sin(B) * np.sin(A), radius * np.cos(B)], 1)
+    scale = (np.arange(rad_n) / rad_n + 1 / (2 * rad_n)).reshape(rad_n, 1, 1)
+    return (scale * s2[None]).reshape(-1, 3).astype(np.float32)
+
+
+def _fold_bn(w, b, mean, var, gamma=None, beta=None):
+    """conv + BatchNorm(eval) -> one conv (fp64 fold, fp32 storage)."""
+    w, b, mean, var = (np.asarray(a, np.float64) for a in (w, b, mean, var))
+    s = 1.0 / np.sqrt(var + 1e-5)
+    if gamma is not None:
+        s = s * np.asarray(gamma, np.float64)
+    w2 = w * s.reshape((-1,) + (1,) * (w.ndim - 1))
+    b2 = (b - mean) * s
+    if beta is not None:
+        b2 = b2 + np.asarray(beta, np.float64)
+    return w2.astype(np.float32), b2.astype(np.float32)
+
+
+class PatchEmbedder:
+    def __init__(self, W, device, cfg):
+        self.cfg, self.device = cfg, device
+        self.centres = torch.from_numpy(voxel_centres(cfg.rad_n, cfg.azi_n, cfg.ele_n)).to(device)
+        ang = -np.arange(cfg.azi_n) * (2 * np.pi / cfg.azi_n)         # var_to_invar, utils/common.py:485-491
+        self.azi_cs = torch.from_numpy(np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)).to(device)
+        g = np.asarray(W['Desc.pnt_layer.1.weight'], np.float64)
+        s = g / np.sqrt(np.asarray(W['Desc.pnt_layer.1.running_var'], np.float64) + 1e-5)
+        self.mlp_w = np.asarray(W['Desc.pnt_layer.0.weight'], np.float32).reshape(16, 3)
+        self.mlp_b = np.asarray(W['Desc.pnt_layer.0.bias'], np.float32)
+        self.mlp_s = s.astype(np.float32)
+        self.mlp_t = (np.asarray(W['Desc.pnt_layer.1.bias'], np.float64)
+                      - np.asarray(W['Desc.pnt_layer.1.running_mean'], np.float64) * s).astype(np.float32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        p = 'Desc.conv_net.ops'
+        self.convs = []
+        for i, bn in ((0, 1), (3, 4), (6, 7), (9, 10), (12, 13), (15, 16), (18, 19)):
+            w, b = _fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var'])
+            self.convs.append((t(w), t(b)))
+        self.last = (t(np.asarray(W[f'{p}.21.weight'], np.float32)), t(np.asarray(W[f'{p}.21.bias'], np.float32)))
+        q = 'Desc.pool_layer'
+        w0, b0 = _fold_bn(W[f'{q}.0.weight'], W[f'{q}.0.bias'], W[f'{q}.1.running_mean'], W[f'{q}.1.running_var'],
+                          W[f'{q}.1.weight'], W[f'{q}.1.bias'])
+        w3, b3 = _fold_bn(W[f'{q}.3.weight'], W[f'{q}.3.bias'], W[f'{q}.4.running_mean'], W[f'{q}.4.running_var'],
+                          W[f'{q}.4.weight'], W[f'{q}.4.bias'])
+        self.pool = [(t(w0), t(b0)), (t(w3), t(b3))]
+
+    @staticmethod
+    def _pad(x):
+        """pad_image / pad_image_3d (utils/common.py:265-310): circular azimuth (last dim), zeros in elevation."""
+        x = torch.cat([x[..., -1:], x, x[..., :1]], -1)
+        return F.pad(x, (0, 0, 1, 1))
+
+    def conv_net(self, x):
+        """Cylindrical_Net: x f32[P,16,3,7,20] -> f32[P,32,7,20]."""
+        w, b = self.convs[0]
+        x = F.relu(F.conv3d(self._pad(x), w, b)).squeeze(2)
+        for w, b in self.convs[1:]:
+            x = F.relu(F.conv2d(self._pad(x), w, b))
+        return F.conv2d(self._pad(x), *self.last)
+
+    def head(self, x):
+        """attention pooling + normalisation (patch_embedder.py:81-84)."""
+        w = F.relu(F.conv2d(x, *self.pool[0]))
+        w = F.relu(F.conv2d(w, *self.pool[1]))
+        f = (x * w).mean((2, 3))
+        return F.normalize(f, p=2, dim=1), F.normalize(x, p=2, dim=1)
+
+    def __call__(self, pts, kpts, axis, perm=None, chunk=1024, want_patches=False):
+        """pts f32[N,3] (2 cm cloud), kpts f32[P,3], axis f32[P,3] -> dict(desc, equi, R, rand_axis[, patches])."""
+        cfg = self.cfg
+        if perm is None:
+            perm = torch.randperm(pts.shape[0], device=pts.device)        # patch_embedder.py:97-98
+        sup = pts[perm].contiguous()
+        patches = ops.select_patches(sup, kpts.contiguous(), cfg.des_r, cfg.num_points_per_patch)
+        ax = axis.contiguous() if cfg.dataset in ('3DMatch', '3DLoMatch') else None
+        x, R, rand_axis, pn = ops.patch_voxelize(patches, ax, cfg.des_r, self.centres, self.azi_cs,
+                                                 cfg.delta / cfg.rad_n, cfg.voxel_sample, self.mlp_w, self.mlp_b,
+                                                 self.mlp_s, self.mlp_t, cfg.azi_n, want_patches)
+        descs, equis = [], []
+        for s in range(0, x.shape[0], chunk):
+            y = self.conv_net(x[s:s + chunk].view(-1, 16, cfg.rad_n, cfg.ele_n, cfg.azi_n))
+            f, e = self.head(y)
+            descs.append(f); equis.append(e)
+        out = dict(desc=torch.cat(descs), equi=torch.cat(equis), R=R, rand_axis=rand_axis, x=x)
+        if want_patches:
+            out['patches'] = pn
+            out['init_patches'] = patches
+        return out

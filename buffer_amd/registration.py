@@ -1,0 +1,60 @@
+"""A12-A16 -- matching and pose recovery on device (models/BUFFER.py:283-333,335-359,382-464)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .patch_embedder import _fold_bn
+
+
+def mutual_matching(src_des, tgt_des):
+    """buffer.mutual_matching (BUFFER.py:335-359): 1-NN both ways (csrc/pointops.hip k_knn), mutual check.
+    -> (s_mids, t_mids) int64 device tensors (ascending s_mids, as np.where yields them)."""
+    _, s_idx = ops.knn(tgt_des[None], src_des[None], 1)
+    _, t_idx = ops.knn(src_des[None], tgt_des[None], 1)
+    s_nn, t_nn = s_idx[0, :, 0], t_idx[0, :, 0]
+    ar = torch.arange(s_nn.shape[0], device=s_nn.device)
+    s_mids = torch.nonzero(t_nn[s_nn] == ar).flatten()
+    return s_mids, s_nn[s_mids]
+
+
+class CostVolume:
+    """CostVolume + CostNet (BUFFER.py:37-66, models/patchnet.py:88-147): dense, through torch/MIOpen for now."""
+
+    def __init__(self, W, device, azi_n=20):
+        self.azi_n = azi_n
+        p = 'Inlier.conv.ops'
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.convs = []
+        for i, bn in ((0, 1), (3, 4), (6, 7), (9, 10), (12, 13), (15, 16), (18, 19), (21, 22), (24, 25)):
+            w, b = _fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var'])
+            self.convs.append((t(w), t(b)))
+        self.last = (t(np.asarray(W[f'{p}.27.weight'], np.float32)), t(np.asarray(W[f'{p}.27.bias'], np.float32)))
+        cols = np.stack([np.roll(np.arange(azi_n), i) for i in range(azi_n)])     # BUFFER.py:41-46
+        self.cols = torch.from_numpy(cols.reshape(-1)).to(device)
+        self.bins = torch.arange(0, azi_n, dtype=torch.float32, device=device)
+
+    def __call__(self, d1, d2, chunk=256):
+        """d1,d2 f32[M,32,5,20] -> expected azimuth shift f32[M]."""
+        outs = []
+        n = self.azi_n
+        for s in range(0, d1.shape[0], chunk):
+            a, b = d1[s:s + chunk], d2[s:s + chunk]
+            x = a[:, :, :, self.cols].reshape(a.shape[0], a.shape[1], a.shape[2], n, n).permute(0, 1, 3, 2, 4)
+            x = x - b.unsqueeze(2)
+            for w, bb in self.convs:
+                x = F.relu(F.conv3d(x, w, bb))
+            x = F.conv3d(x, *self.last).reshape(x.shape[0], -1)
+            outs.append(torch.sum(F.softmax(x, dim=-1) * self.bins[None], dim=-1))
+        return torch.cat(outs) if outs else torch.zeros(0, device=d1.device)
+
+
+def recover_pose(ind, ss_kpts, tt_kpts, ss_R, tt_R, cfg, seed=0):
+    """BUFFER.py:295-333: hypotheses, all-vs-all scoring, RANSAC on the winner's inliers, refinement.
+    -> (pose f32[4,4] device, dict of diagnostics)."""
+    R, t, num, best, mask = ops.hypotheses_score(ind, ss_kpts, tt_kpts, ss_R, tt_R, cfg.azi_n, cfg.inlier_th)
+    inlier_ind = torch.nonzero(mask).flatten().int()
+    T, info = ops.ransac_kabsch(ss_kpts, tt_kpts, inlier_ind, cfg.ransac_hypotheses, seed, cfg.dist_th, cfg.similar_th)
+    if cfg.pose_refine:
+        T, rinfo = ops.post_refine(T, ss_kpts, tt_kpts, cfg.refine_threshold, 20)
+    return T, dict(inlier_num=num, best=best, inlier_ind=inlier_ind, ransac_info=info, R_hyp=R, t_hyp=t)

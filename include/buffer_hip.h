@@ -102,6 +102,92 @@ int     buf_grid_subsample_batch(const float* pts, int n, const int* batches_hos
                                  int max_p, float* out_pts, int* out_batches_host, int* out_m_host,
                                  int64_t max_cells, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * pointnet2_ops.pointnet2_utils surface (external CUDA package, README.md:31; call sites
+ * models/BUFFER.py:266-271, models/patch_embedder.py:100-104, utils/common.py:442-455).
+ * All tensors contiguous fp32 / int32 in device memory.
+ */
+/* furthest_point_sample: xyz f32[b,n,3] -> idx int32[b,m]; starts at index 0, skips points with
+ * |p|^2 <= 1e-3, arg-max tie rule of the upstream 512-thread kernel.  ws only for n > 32768. */
+size_t  buf_fps_ws_bytes(int b, int n);
+int     buf_fps(const float* xyz, int b, int n, int m, int* idx_out, void* ws, size_t ws_bytes, void* stream);
+/* gather_operation: feat f32[b,c,n], idx int32[b,m] -> f32[b,c,m] */
+int     buf_gather(const float* feat, const int* idx, int b, int c, int n, int m, float* out, void* stream);
+/* grouping_operation: feat f32[b,c,n], idx int32[b,m,nsample] -> f32[b,c,m,nsample] */
+int     buf_group(const float* feat, const int* idx, int b, int c, int n, int m, int nsample, float* out, void* stream);
+/* ball_query: first nsample points (index order) with d2 < radius^2; unused slots = first hit; rows
+ * without any hit are all zero.  idx int32[b,m,nsample]. */
+int     buf_ball_query(const float* xyz, const float* new_xyz, int b, int n, int m, float radius, int nsample,
+                       int* idx, void* stream);
+/* three_nn: unknown f32[b,n,3], known f32[b,m,3] -> dist f32[b,n,3] (sqrt of the 3 smallest d2), idx int32[b,n,3] */
+int     buf_three_nn(const float* unknown, const float* known, int b, int n, int m, float* dist, int* idx, void* stream);
+/* MiniSpinNet.select_patches fused (models/patch_embedder.py:93-121): pts f32[n,3] (already permuted),
+ * kpts f32[m,3] -> patches f32[m,nsample,3] with the keypoint in every unused slot and in the last slot. */
+int     buf_select_patches(const float* pts, const float* kpts, int n, int m, float radius, int nsample,
+                           float* patches, void* stream);
+
+/* knn_cuda.KNN(k, transpose_mode=True) (README.md:32; models/BUFFER.py:347,352):
+ * ref f32[b,n,d], query f32[b,q,d] -> dist f32[b,q,k] (Euclidean, ascending), idx int64[b,q,k]. d,k <= 64. */
+int     buf_knn(const float* ref, const float* query, int b, int n, int q, int d, int k, float* dist,
+                long long* idx, void* stream);
+
+/* torch_batch_svd.svd (README.md:35; utils/common.py:715): a f32[n,3,3] -> u,s,v with a = u diag(s) v^T, s descending. */
+int     buf_svd3x3_batched(const float* a, int n, float* u, float* s, float* v, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A4/A5  Vector-Neuron blocks (models/point_learner.py:315-416,467-582,246-265; models/vn_layers.py:46-75,108-130).
+ * Feature rows f32[N,3C] channel-major/xyz-minor.  bn_scale = w/sqrt(var+1e-5), bn_shift = b - mean*bn_scale
+ * (both null when Cout == 1: the reference skips VN batch-norm there).
+ */
+/* gather + VN-linear + VN-BN + VN-leaky + mean over all k slots.  mode 1: [f,delta]; mode 6: [f,delta,f x delta,mean(delta)].
+ * idx int32[nq,k] with shadow index >= ns.  wf,wd f32[cout, cin+1 | cin+3]. */
+int     buf_vn_gather_block(const float* q_pts, const float* s_pts, const float* feats, const int* idx,
+                            int nq, int ns, int k, int cin, int cout, int mode, float scale,
+                            const float* wf, const float* wd, const float* bn_scale, const float* bn_shift,
+                            float slope, float* out, void* stream);
+/* point-wise VN layer on concat(a[ind_a[i*ind_stride]] , b[i]) (+ residual); ind_a null = identity;
+ * rows with index >= na read as zeros (closest_pool shadow); wd null = plain VN linear. */
+int     buf_vn_pointwise(const float* a, const int* ind_a, int ind_stride, int na, int ca, const float* b, int cb,
+                         int n, int cout, const float* wf, const float* wd, const float* bn_scale,
+                         const float* bn_shift, float slope, const float* residual, float* out, void* stream);
+/* max_pool (models/KPConv/blocks.py:104-121): out[i,f] = max_k feats_pad[idx[i,k], f], zero shadow row. */
+int     buf_gather_max(const float* feats, const int* idx, int nq, int ns, int k, int width, float* out, void* stream);
+/* VNStdFeature tail (vn_layers.py:213-219): x f32[n,3c], z f32[n,9] -> f32[n,3c] invariant scalars. */
+int     buf_vn_std(const float* x, const float* z, int n, int c, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A9+A10 (+ point MLP of A11) fused: axis alignment, normalisation, cylindrical voxelisation
+ * (420 ball queries of `nsample` per patch), azimuth de-rotation, Conv1x1(3->16)+BN+ReLU, max.
+ * (models/patch_embedder.py:123-171,74-79; utils/common.py:431-498,501-525)
+ * patches f32[np,npts,3] (keypoint in the last slot); axis f32[np,3] or null (KITTI/ETH: R = I);
+ * centres f32[ncentres,3]; azi_cs f32[azi_n,2] = cos,sin of -i*2pi/azi_n; mlp_* are HOST arrays
+ * (w[16,3], b[16], bn_scale[16], bn_shift[16]).  out_x f32[np,16,ncentres]; out_R f32[np,3,3];
+ * out_rand f32[np,3]; out_patches (nullable) f32[np,npts,3].
+ */
+int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, int npts, float des_r,
+                           const float* centres, int ncentres, int azi_n, const float* azi_cs, float voxel_r,
+                           int nsample, const float* mlp_w_host, const float* mlp_b_host, const float* bn_scale_host,
+                           const float* bn_shift_host, float* out_x, float* out_R, float* out_rand, float* out_patches,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A14  hypotheses + all-vs-all scoring (models/BUFFER.py:295-311): ind f32[m] -> R f32[m,3,3], t f32[m,3],
+ * inlier_num int32[m], best_out int32[1] (first arg-max), best_mask uint8[m]. */
+int     buf_hypotheses_score(const float* ind, const float* ss_kpts, const float* tt_kpts, const float* ss_R,
+                             const float* tt_R, int m, int azi_n, float inlier_th, float* R_out, float* t_out,
+                             int* inlier_num, int* best_out, unsigned char* best_mask, void* stream);
+/* A15  deterministic 3-point RANSAC over `corr` (int32[ncorr] indices into src/tgt, both f32[*,3]);
+ * replaces open3d registration_ransac_based_on_correspondence (models/BUFFER.py:314-326).
+ * T_out f32[4,4]; info_out (nullable) int32[2] = {inliers of the winner, winner id or -1}. */
+size_t  buf_ransac_ws_bytes(int nhyp);
+int     buf_ransac_kabsch(const float* src, const float* tgt, const int* corr, int ncorr, int nhyp,
+                          unsigned long long seed, float max_dist, float edge_similarity, float* T_out,
+                          int* info_out, void* ws, size_t ws_bytes, void* stream);
+/* A16  post_refinement (models/BUFFER.py:382-418,424-464): <= iters rounds of weighted Kabsch in one launch.
+ * T_init,T_out f32[4,4]; src,tgt f32[m,3]; info_out (nullable) int32[2] = {last inlier count, rounds run}. */
+int     buf_post_refine(const float* T_init, const float* src, const float* tgt, int m, float inlier_threshold,
+                        int iters, float* T_out, int* info_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

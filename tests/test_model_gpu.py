@@ -1,0 +1,127 @@
+"""A4-A16 on the GPU: HIP stages vs the golden vectors produced by the reference and vs the torch
+fp32 oracle.  Tolerances: 1e-4 relative on descriptors / poses (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def W():
+    from buffer_amd.weights import load_weights
+    return load_weights("3dmatch")
+
+
+def _pyr_from_golden(g, dev):
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    return dict(points=[t(g[f'points_{l}'], torch.float32) for l in range(3)],
+                neighbors=[t(g[f'neighbors_{l}'], torch.int32) for l in range(3)],
+                pools=[t(g[f'pools_{l}'], torch.int32) for l in range(2)],
+                upsamples=[t(g[f'upsamples_{l}'], torch.int32) for l in range(2)])
+
+
+def test_point_learner_vs_reference(W, dev):
+    """EFCNN + DetNet on the reference's own pyramid tables (fixture F1) -> fixture F3."""
+    from buffer_amd.point_learner import PointLearner
+    g, f = load("pyramid_tiny.npz"), load("point_learner_tiny.npz")
+    pyr = _pyr_from_golden(g, dev)
+    pl = PointLearner(W, dev)
+    axis, eps, bottle, skips, blocks = pl.efcnn(pyr, torch.from_numpy(f['features']).to(dev))
+    score = pl.detnet(pyr, bottle, skips)
+    for i in range(5):
+        np.testing.assert_allclose(blocks[i].cpu().numpy(), f[f'block{i}'], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(bottle.cpu().numpy(), f['bottle'], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(axis.cpu().numpy(), f['axis'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(eps.cpu().numpy(), f['eps'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(score.cpu().numpy(), f['score'], rtol=1e-3, atol=2e-4)
+    # the keypoint decision (score > 0.1) must agree wherever the score is not on the threshold
+    s_ref, s_got = f['score'][:, 0], score.cpu().numpy()[:, 0]
+    clear = np.abs(s_ref - 0.1) > 1e-3
+    assert np.array_equal((s_got > 0.1)[clear], (s_ref > 0.1)[clear])
+
+
+def test_patch_embedder_vs_reference(W, dev):
+    """select_patches + fused voxelise + Cylindrical_Net -> fixture F4."""
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    f = load("desc_tiny.npz")
+    pe = PatchEmbedder(W, dev, THREEDMATCH)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = pe(t(f['raw']), t(f['kpts']), t(f['kaxis']), t(f['perm']), want_patches=True)
+    np.testing.assert_allclose(out['patches'].cpu().numpy(), f['patches'], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(out['R'].cpu().numpy(), f['R'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out['rand_axis'].cpu().numpy(), f['rand_axis'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out['desc'].cpu().numpy(), f['desc'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out['equi'].cpu().numpy(), f['equi'], rtol=1e-4, atol=2e-5)
+
+
+def test_voxelize_vs_oracle_spt(W, dev):
+    """fused A9+A10+point-MLP == oracle SPT [P,420,10,3] -> conv1x1+BN+ReLU -> max (incl. the zero-slot quirks)."""
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    from oracle import torch_ref as T
+    f = load("desc_tiny.npz")
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    pe = PatchEmbedder(W, dev, THREEDMATCH)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = pe(t(f['raw']), t(f['kpts']), t(f['kaxis']), t(f['perm']), want_patches=True)
+    with torch.no_grad():
+        inv = T.spt(torch.from_numpy(f['patches']))
+        np.testing.assert_allclose(inv[:8].numpy(), f['spt_first8'], rtol=0, atol=2e-6)
+        want = T.point_mlp_max(inv, Wt).numpy()
+    np.testing.assert_allclose(out['x'].cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
+def test_matching_and_pose_vs_reference(W, dev):
+    """mutual 1-NN, cost volume, hypotheses, scoring, refinement -> fixture F5."""
+    from buffer_amd import ops, registration
+    f = load("match_tiny.npz")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    s_mids, t_mids = registration.mutual_matching(t(f['src_desc']), t(f['tgt_desc']))
+    assert np.array_equal(s_mids.cpu().numpy(), f['s_mids']) and np.array_equal(t_mids.cpu().numpy(), f['t_mids'])
+    cv = registration.CostVolume(W, dev)
+    se, te = t(f['src_equi'])[s_mids][:, :, 1:6].contiguous(), t(f['tgt_equi'])[t_mids][:, :, 1:6].contiguous()
+    ind = cv(se, te)
+    np.testing.assert_allclose(ind.cpu().numpy(), f['ind'], rtol=1e-4, atol=2e-4)
+    ss, tt = t(f['src_kpts'])[s_mids].contiguous(), t(f['tgt_kpts'])[t_mids].contiguous()
+    R, tr, num, best, mask = ops.hypotheses_score(t(f['ind']), ss, tt, t(f['src_R'])[s_mids].contiguous(),
+                                                  t(f['tgt_R'])[t_mids].contiguous())
+    np.testing.assert_allclose(R.cpu().numpy(), f['R_hyp'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(tr.cpu().numpy(), f['t_hyp'], rtol=0, atol=1e-5)
+    assert np.abs(num.cpu().numpy() - f['inlier_num']).max() <= 1      # borderline residuals may flip
+    assert int(best.item()) == int(f['best'])
+    assert np.array_equal(np.nonzero(mask.cpu().numpy())[0], f['inlier_ind'])
+    T, info = ops.post_refine(t(f['init_pose']), ss, tt, 0.10, 20)
+    np.testing.assert_allclose(T.cpu().numpy(), f['refined_pose'][0], rtol=0, atol=2e-5)
+
+
+def test_ransac_recovers_planted_pose(dev):
+    """A15: deterministic GPU RANSAC finds a planted rigid motion among 40 % outliers and is reproducible."""
+    from buffer_amd import ops, synth
+    rng = np.random.default_rng(4)
+    n = 400
+    src = rng.normal(size=(n, 3)).astype(np.float32)
+    R = synth.random_rotation(rng)
+    tvec = rng.normal(size=3)
+    tgt = (src @ R.T + tvec + rng.normal(scale=0.01, size=(n, 3))).astype(np.float32)
+    out = rng.permutation(n)[:160]
+    tgt[out] = rng.normal(size=(160, 3)).astype(np.float32) * 2
+    t = lambda a: torch.from_numpy(a).to(dev)
+    corr = torch.arange(n, dtype=torch.int32, device=dev)
+    T1, info1 = ops.ransac_kabsch(t(src), t(tgt), corr, nhyp=4096, seed=1, max_dist=0.1, edge_similarity=0.8)
+    T2, _ = ops.ransac_kabsch(t(src), t(tgt), corr, nhyp=4096, seed=1, max_dist=0.1, edge_similarity=0.8)
+    assert torch.equal(T1, T2)
+    T1 = T1.cpu().numpy()
+    assert int(info1[0]) >= 200
+    assert np.abs(T1[:3, :3] - R).max() < 0.05 and np.abs(T1[:3, 3] - tvec).max() < 0.05
+    Tr, _ = ops.post_refine(t(T1), t(src), t(tgt), 0.1, 20)
+    Tr = Tr.cpu().numpy()
+    assert np.abs(Tr[:3, :3] - R).max() < 5e-3 and np.abs(Tr[:3, 3] - tvec).max() < 5e-3

@@ -1,0 +1,115 @@
+"""pointnet2_ops / knn_cuda / torch_batch_svd surface: HIP kernels (C ABI) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from buffer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(seed, n):
+    rng = np.random.default_rng(seed)
+    d = synth.make_pair(seed, n_raw=60_000, size=(1.0, 1.0, 0.9), n_boxes=3)
+    p = d['src_sds_pts'][:, :3].astype(np.float32)
+    while len(p) < n:
+        p = np.concatenate([p, p + rng.normal(scale=0.01, size=p.shape).astype(np.float32)])
+    return p[rng.permutation(len(p))[:n]]
+
+
+@pytest.mark.parametrize("n,m", [(1000, 64), (5000, 1500), (9000, 1500), (20000, 300), (40000, 64)])
+def test_fps_index_exact(n, m, oracle, dev):
+    from buffer_amd import ops
+    xyz = np.stack([_cloud(1, n), _cloud(2, n)])
+    xyz[1, :7] = 0.0                                   # points the upstream kernel skips (|p|^2 <= 1e-3)
+    want = oracle.fps(xyz, m)
+    got = ops.furthest_point_sample(torch.from_numpy(xyz).to(dev), m).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_fps_duplicates_and_small(oracle, dev):
+    from buffer_amd import ops
+    rng = np.random.default_rng(0)
+    base = rng.random((50, 3)).astype(np.float32) + 1
+    xyz = np.concatenate([base, base, base])[None]     # exact distance ties everywhere
+    want = oracle.fps(xyz, 120)
+    got = ops.furthest_point_sample(torch.from_numpy(xyz).to(dev), 120).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("radius,nsample", [(0.3, 512), (0.1, 16), (0.05, 10)])
+def test_ball_query_and_group(radius, nsample, oracle, dev):
+    from buffer_amd import ops
+    xyz = np.stack([_cloud(3, 6000), _cloud(4, 6000)])
+    new = xyz[:, :200].copy()
+    new[0, :5] += 10.0                                  # queries with an empty ball -> all-zero rows
+    want = oracle.ball_query(radius, nsample, xyz, new)
+    t_xyz, t_new = torch.from_numpy(xyz).to(dev), torch.from_numpy(new).to(dev)
+    got = ops.ball_query(radius, nsample, t_xyz, t_new)
+    assert np.array_equal(got.cpu().numpy(), want)
+    feat = np.ascontiguousarray(xyz.transpose(0, 2, 1))
+    g = ops.grouping_operation(torch.from_numpy(feat).to(dev), got)
+    assert np.array_equal(g.cpu().numpy(), oracle.grouping_operation(feat, want))
+    idx = want[:, :, 0].copy()
+    ga = ops.gather_operation(torch.from_numpy(feat).to(dev), torch.from_numpy(idx).to(dev))
+    assert np.array_equal(ga.cpu().numpy(), oracle.gather_operation(feat, idx))
+
+
+def test_select_patches_matches_reference_composition(oracle, dev):
+    """fused kernel == ball_query + grouping + the mask arithmetic of patch_embedder.py:100-112"""
+    from buffer_amd import ops
+    from oracle import torch_ref as T
+    pts = _cloud(5, 8000)
+    kpts = pts[:300].copy()
+    kpts[:4] += 10.0
+    perm = torch.arange(len(pts))
+    want = T.select_patches(torch.from_numpy(pts), torch.from_numpy(kpts), perm, 0.3, 512).numpy()
+    got = ops.select_patches(torch.from_numpy(pts).to(dev), torch.from_numpy(kpts).to(dev), 0.3, 512)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("k,d", [(1, 32), (5, 32), (16, 3), (40, 7)])
+def test_knn(k, d, oracle, dev):
+    from buffer_amd import ops
+    rng = np.random.default_rng(k)
+    ref = rng.normal(size=(2, 700, d)).astype(np.float32)
+    qry = rng.normal(size=(2, 333, d)).astype(np.float32)
+    ref[0, 10] = ref[0, 3]                              # an exact tie
+    wd, wi = oracle.knn(ref, qry, k)
+    gd, gi = ops.knn(torch.from_numpy(ref).to(dev), torch.from_numpy(qry).to(dev), k)
+    assert np.array_equal(gi.cpu().numpy(), wi)
+    np.testing.assert_allclose(gd.cpu().numpy(), wd, rtol=1e-6, atol=0)
+
+
+def test_three_nn(oracle, dev):
+    from buffer_amd import ops
+    rng = np.random.default_rng(1)
+    u = rng.random((2, 500, 3)).astype(np.float32)
+    kn = rng.random((2, 77, 3)).astype(np.float32)
+    wd, wi = oracle.three_nn(u, kn)
+    gd, gi = ops.three_nn(torch.from_numpy(u).to(dev), torch.from_numpy(kn).to(dev))
+    assert np.array_equal(gi.cpu().numpy(), wi)
+    np.testing.assert_allclose(gd.cpu().numpy(), wd, rtol=1e-6, atol=0)
+
+
+def test_svd3x3(dev):
+    """A = U diag(S) V^T, orthonormal factors, S descending and equal to LAPACK's; rank-deficient inputs."""
+    from buffer_amd import ops
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(4096, 3, 3)).astype(np.float32)
+    a[0] = 0
+    a[1] = np.outer([1, 2, 3], [4, 5, 6])
+    a[2] = np.diag([3, 0, 0])
+    a[3] = np.eye(3)
+    pts = rng.normal(size=(100, 40, 3)).astype(np.float32)
+    a[4:104] = np.einsum('bni,bnj->bij', pts, pts)      # covariance-like (cal_Z_axis, utils/common.py:709-716)
+    u, s, v = (t.cpu().numpy().astype(np.float64) for t in ops.svd3x3(torch.from_numpy(a).to(dev)))
+    rec = np.einsum('bik,bk,bjk->bij', u, s, v)
+    scale = np.abs(a).max((1, 2)) + 1e-12
+    assert (np.abs(rec - a).max((1, 2)) / scale).max() < 2e-5
+    eye = np.eye(3)[None]
+    assert np.abs(np.einsum('bki,bkj->bij', u, u) - eye).max() < 2e-5
+    assert np.abs(np.einsum('bki,bkj->bij', v, v) - eye).max() < 2e-5
+    assert (s[:, 0] >= s[:, 1]).all() and (s[:, 1] >= s[:, 2]).all()
+    np.testing.assert_allclose(s, np.linalg.svd(a.astype(np.float64), compute_uv=False), rtol=1e-4,
+                               atol=1e-5 * scale.max())

@@ -1,0 +1,62 @@
+"""End-to-end: device pyramid vs oracle collate, full registration of synthetic pairs."""
+import numpy as np
+import pytest
+import torch
+
+from buffer_amd import synth
+from util import assert_neighbors_equal_mod_ties as nbr_eq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return synth.make_pair(11, n_raw=40_000, size=(1.0, 1.0, 0.9), n_boxes=3)
+
+
+def test_device_pyramid_equals_oracle_collate(tiny, oracle, dev):
+    """A0-A3 composed on device == oracle collate (same row order: both ascending voxel key)."""
+    from buffer_amd import pyramid
+    from buffer_amd.config import THREEDMATCH as cfg
+    from oracle import torch_ref as T
+    limits = T.calibrate_limits([tiny])
+    got_limits = pyramid.calibrate_limits([tiny], cfg, dev)
+    assert np.array_equal(limits, got_limits)
+    want = T.collate(tiny, limits)
+    pts, lens, *_ = pyramid.stack_sample(tiny, dev)
+    got = pyramid.build_pyramid(pts, lens, limits, cfg)
+    for l in range(3):
+        assert np.array_equal(got['lengths'][l], want['stack_lengths'][l].numpy())
+        assert np.array_equal(got['points'][l].cpu().numpy().view(np.uint32), want['points'][l].numpy().view(np.uint32))
+        assert np.array_equal(got['neighbors'][l].cpu().numpy(), want['neighbors'][l].numpy())
+        if l < 2:
+            assert np.array_equal(got['pools'][l].cpu().numpy(), want['pools'][l].numpy())
+            assert np.array_equal(got['upsamples'][l].cpu().numpy(), want['upsamples'][l].numpy())
+
+
+def test_register_tiny_pair(tiny, dev):
+    from buffer_amd.pipeline import BufferPipeline
+    pipe = BufferPipeline(device=dev)
+    pipe.calibrate([tiny])
+    inp = pipe.upload(tiny)
+    pose, d = pipe.register(inp, seed=0, detail=True)
+    pose2 = pipe.register(inp, seed=0)
+    assert torch.equal(pose, pose2), "registration must be deterministic for a fixed seed"
+    gt = tiny['relt_pose']
+    T = pose.cpu().numpy().astype(np.float64)
+    rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
+    rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+    assert rte < 0.05 and rre < 2.0, (rte, rre)
+
+
+def test_register_3dmatch_shape_pair(dev):
+    from buffer_amd.pipeline import BufferPipeline
+    s = synth.make_pair(1)
+    pipe = BufferPipeline(device=dev)
+    pipe.calibrate([s])
+    pose = pipe.register(pipe.upload(s), seed=0)
+    gt = s['relt_pose']
+    T = pose.cpu().numpy().astype(np.float64)
+    rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
+    rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+    assert rte < 0.3 and rre < 15.0, (rte, rre)       # the DGR success criterion of ThreeDMatch/test.py:264-270
