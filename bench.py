@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Registration throughput of the MI355X-native BUFFER inference path (BASELINE.json metric:
+registration pairs/sec; workload = configs[1], one 3DMatch-shape fragment pair, full inference, fp32).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step registers `--pairs-per-step` device-resident synthetic pairs on every rank (pair-sharded, no
+data-path collective; one all_gather of the poses at the end of the timed region).  Rank 0 prints
+one JSON line (contract in the task description): whole-job pairs/s, the roofline of the dominant
+hand-written kernel (k_grid_query, timed with HIP events on its launch stream inside the library)
+and, at N=1, the CPU baseline (reference cpp_wrappers cores when oracle/_ref is built, else the
+plain-C port, + the torch-CPU restatement of the model stages) timed on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from dataclasses import replace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--keypts', type=int, default=5000, help='keypoints per fragment (BASELINE: ~5k)')
+    ap.add_argument('--pairs-per-step', type=int, default=1)
+    ap.add_argument('--distinct-pairs', type=int, default=2, help='synthetic pairs generated per rank (cycled)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-keypts', type=int, default=256, help='keypoint sample of the CPU baseline leg')
+    return ap.parse_args()
+
+
+def cpu_baseline(sample, cfg, limits, keypts_full, keypts_sample):
+    """One pair through the CPU path on this box's host cores.  The descriptor/matching stages run on
+    a `keypts_sample`-keypoint sample and are scaled linearly to `keypts_full` (they are linear in the
+    number of patches / matches); pyramid, point learner and FPS run in full."""
+    from oracle import cpu, pipeline_ref
+    from buffer_amd.weights import load_weights
+    cpu.build(ref=True)
+    use_ref = cpu.have_ref()
+    W = {k: torch.from_numpy(v) for k, v in load_weights(cfg.weights).items()}
+    rng = np.random.default_rng(0)
+    perms = [rng.permutation(len(sample['src_fds_pts'])), rng.permutation(len(sample['tgt_fds_pts']))]
+    tm = {}
+    t0 = time.perf_counter()
+    pipeline_ref.register_pair(sample, W, limits, cfg, 0, perms, num_keypts=keypts_sample, use_ref=use_ref, timings=tm)
+    wall = time.perf_counter() - t0
+    scale = keypts_full / keypts_sample
+    # FPS is run for keypts_sample rounds only: scale it too (rounds are identical work)
+    est = tm['pyramid'] + tm['point_learner'] + (tm['keypoints'] + tm['descriptors'] + tm['matching']) * scale + tm['pose']
+    return dict(value=1.0 / est, unit='pairs/s', cores=torch.get_num_threads(),
+                kind='reference' if use_ref else 'port',
+                sample=f'1 pair: pyramid (cpp_wrappers cores, 1 thread) + point learner in full; FPS/descriptor/matching '
+                       f'stages on {keypts_sample} of {keypts_full} keypoints per fragment, scaled x{scale:.1f}; '
+                       f'torch-CPU {torch.get_num_threads()} threads; measured {wall:.1f} s',
+                stages_s={k: round(v, 3) for k, v in tm.items()})
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from buffer_amd import _lib, synth
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.pipeline import BufferPipeline
+    cfg = replace(THREEDMATCH, num_keypts=a.keypts)
+    pipe = BufferPipeline(cfg, dev)
+    calib = synth.make_pair(1000)                     # same calibration pair on every rank -> identical limits
+    limits = pipe.calibrate([calib])
+    samples = [synth.make_pair(2000 + rank * 97 + i) for i in range(a.distinct_pairs)]
+    inputs = [pipe.upload(s) for s in samples]
+    torch.cuda.synchronize()
+    L = _lib.lib()
+
+    def step(i):
+        poses = []
+        for j in range(a.pairs_per_step):
+            k = (i * a.pairs_per_step + j) % len(inputs)
+            poses.append(pipe.register(inputs[k], seed=k))
+        return poses
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    L.buf_timing_enable(1)
+    t0 = time.perf_counter()
+    all_poses = []
+    for i in range(a.steps):
+        all_poses += step(i)
+    mine = torch.stack(all_poses)
+    if dist:                                           # the path's one exchange: poses of every shard
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.buf_timing_enable(0)
+    ms, by = C.c_double(0), C.c_double(0)
+    launches = L.buf_timing_collect(C.byref(ms), C.byref(by))
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # registration quality on this rank's pairs (DGR criterion of ThreeDMatch/test.py:264-270)
+    ok = 0
+    for n, pose in enumerate(all_poses):
+        gt = samples[n % len(samples)]['relt_pose']
+        T = pose.cpu().numpy().astype(np.float64)
+        rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
+        rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+        ok += int(rte < 0.3 and rre < 15)
+
+    if rank == 0:
+        pairs = world * a.steps * a.pairs_per_step
+        achieved = (by.value / launches) / (ms.value / launches * 1e-3) / 1e9 if launches else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('k_grid_query_hbm_bytes_per_launch')
+        out = {
+            'metric': 'registration pairs/sec', 'value': pairs / elapsed, 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'one 3DMatch-shape fragment pair, full BUFFER inference (BASELINE configs[1])',
+                       'pairs_per_step_per_gpu': a.pairs_per_step, 'keypoints_per_fragment': a.keypts,
+                       'fds_points': [int(s['src_fds_pts'].shape[0]) for s in samples[:1]]
+                       + [int(s['tgt_fds_pts'].shape[0]) for s in samples[:1]],
+                       'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,
+                       'weights': '3DMatch 06132318 (released)', 'parallelism': f'pair-sharded x{world}',
+                       'registered_ok': f'{ok}/{len(all_poses)} (rank 0, RTE<0.3 m & RRE<15 deg)'},
+            'roofline': {'kernel': 'k_grid_query (A2 radius neighbours)', 'bound': 'hbm', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'launches': int(launches), 'avg_us': (ms.value / launches * 1e3) if launches else None,
+                         'avg_algorithmic_bytes': (by.value / launches) if launches else None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits, a.keypts, a.cpu_keypts)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

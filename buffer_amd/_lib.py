@@ -35,10 +35,12 @@ _SIGNATURES = {
     "buf_last_error": (C.c_char_p, []),
     "buf_version": (_i, []),
     "buf_device_count": (_i, []),
+    "buf_timing_enable": (None, [_i]),
+    "buf_timing_collect": (C.c_longlong, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "buf_grid_default_cells": (_i64, [_i, _i]),
     "buf_grid_ws_bytes": (_sz, [_i, _i, _i64]),
     "buf_grid_build": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _i, _f, _i64, _vp, _sz, _vp]),
-    "buf_grid_query": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
+    "buf_grid_query": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "buf_radius_neighbors": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "buf_grid_subsample_ws_bytes": (_sz, [_i, _i, _i64]),
     "buf_grid_subsample_batch": (_i, [_vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
@@ -49,7 +51,9 @@ _SIGNATURES = {
     "buf_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "buf_three_nn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "buf_select_patches": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp]),
-    "buf_knn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "buf_knn_ws_bytes": (_sz, [_i, _i, _i]),
+    "buf_knn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "buf_fps_ragged": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "buf_svd3x3_batched": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "buf_vn_gather_block": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "buf_vn_pointwise": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
@@ -76,6 +80,10 @@ def lib():
             raise BufferHipError(
                 f"{LIB_PATH} is missing: build it with `python -m buffer_amd.build` "
                 "(hipcc --offload-arch=gfx950). buffer_amd has no CPU fallback.")
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  Loading it first makes
+        # our library bind to that same runtime instead of pulling a second one from /opt/rocm, so
+        # torch's allocator/streams and our kernels share one context.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)

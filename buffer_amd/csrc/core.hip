@@ -15,6 +15,51 @@ void buf_set_error(const char* fmt, ...)
 extern "C" const char* buf_last_error(void) { return g_err; }
 extern "C" int buf_version(void) { return 100; }
 
+// ------------------------------------------------------------------------------------------
+// Optional per-kernel timing for bench.py's roofline line: HIP events recorded on the launch
+// stream directly around the dominant kernel (k_grid_query).  Off by default; profiling state only.
+#include <mutex>
+#include <vector>
+struct TimedSpan { hipEvent_t a, b; double bytes; };
+static std::mutex g_time_mu;
+static std::vector<TimedSpan> g_spans;
+static int g_timing_on = 0;
+
+extern "C" void buf_timing_enable(int on) { std::lock_guard<std::mutex> l(g_time_mu); g_timing_on = on; }
+
+static bool timing_begin(hipStream_t s, TimedSpan* sp, double bytes)
+{
+    if (!g_timing_on) return false;
+    if (hipEventCreate(&sp->a) != hipSuccess || hipEventCreate(&sp->b) != hipSuccess) return false;
+    sp->bytes = bytes;
+    (void)hipEventRecord(sp->a, s);
+    return true;
+}
+
+static void timing_end(hipStream_t s, TimedSpan* sp)
+{
+    (void)hipEventRecord(sp->b, s);
+    std::lock_guard<std::mutex> l(g_time_mu);
+    g_spans.push_back(*sp);
+}
+
+// Synchronises on the recorded events; returns the number of launches collected and resets.
+extern "C" long long buf_timing_collect(double* total_ms, double* total_bytes)
+{
+    std::lock_guard<std::mutex> l(g_time_mu);
+    double ms = 0, by = 0;
+    long long n = 0;
+    for (auto& sp : g_spans) {
+        float t = 0.f;
+        if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) { ms += t; by += sp.bytes; n++; }
+        (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
+    }
+    g_spans.clear();
+    if (total_ms) *total_ms = ms;
+    if (total_bytes) *total_bytes = by;
+    return n;
+}
+
 extern "C" int buf_device_count(void)
 {
     int n = 0;

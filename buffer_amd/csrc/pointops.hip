@@ -12,8 +12,116 @@
 // distance, the smaller (k mod T) and then the smaller k, T = min(512, 2^floor(log2 n)) being the
 // upstream block size (per-thread strict '>' over k = t, t+T, ...; pairwise tree keeps the lower
 // thread).  Keys are packed as (d2 bits << 32) | ~((k mod T) << 22 | k) and max-reduced.
-#define FPS_THREADS 1024
+#define FPS_THREADS 512
+#define FPS_WAVES (FPS_THREADS / WAVE)
+#define FPS_MAXB 64
 
+struct FpsBatch { int off[FPS_MAXB]; int n[FPS_MAXB]; };   // per-cloud row offset and length (ragged batch)
+
+// wave64 max-reduction of a non-negative-or-(-1) float through DPP row shifts/broadcasts (no LDS traffic)
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#define DPP_MAX(ctrl, rmask, bmask) \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, bmask, false)))
+    DPP_MAX(0x111, 0xf, 0xf);   // row_shr:1
+    DPP_MAX(0x112, 0xf, 0xf);   // row_shr:2
+    DPP_MAX(0x114, 0xf, 0xe);   // row_shr:4
+    DPP_MAX(0x118, 0xf, 0xc);   // row_shr:8
+    DPP_MAX(0x142, 0xa, 0xf);   // row_bcast:15
+    DPP_MAX(0x143, 0xc, 0xf);   // row_bcast:31
+#undef DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Per lane the candidates k = tid + j*FPS_THREADS share (k mod T) because T divides FPS_THREADS, so
+// inside a lane the upstream tie rule reduces to "first j wins" = strict '>' in ascending j.
+// Points the upstream kernel skips carry temp = -1, which never beats the initial best of -1.
+template <int PPT>
+__global__ void __launch_bounds__(FPS_THREADS) k_fps(const float* __restrict__ xyz, FpsBatch B, int m, int* __restrict__ idx_out)
+{
+    const int n = B.n[blockIdx.x];
+    const float* P = xyz + (size_t)B.off[blockIdx.x] * 3;
+    int* out = idx_out + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    int T = 1;
+    while (T * 2 <= n && T * 2 <= 512) T *= 2;
+    float px[PPT], py[PPT], pz[PPT], temp[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; j++) {
+        int k = tid + j * FPS_THREADS;
+        bool ok = k < n;
+        px[j] = ok ? P[3 * (size_t)k] : 0.f;
+        py[j] = ok ? P[3 * (size_t)k + 1] : 0.f;
+        pz[j] = ok ? P[3 * (size_t)k + 2] : 0.f;
+        float mag = __fadd_rn(__fadd_rn(__fmul_rn(px[j], px[j]), __fmul_rn(py[j], py[j])), __fmul_rn(pz[j], pz[j]));
+        ok = ok && !((double)mag <= 1e-3);
+        temp[j] = ok ? 1e10f : -1.0f;
+    }
+    __shared__ float sbest[2][FPS_WAVES];
+    __shared__ unsigned int stie[2][FPS_WAVES];
+    __shared__ float sxyz[2][FPS_WAVES][3];
+    float x1 = n > 0 ? P[0] : 0.f, y1 = n > 0 ? P[1] : 0.f, z1 = n > 0 ? P[2] : 0.f;
+    if (tid == 0 && m > 0) out[0] = 0;
+    const unsigned int tmod = (unsigned int)(tid % T) << 22;
+    for (int r = 1; r < m; r++) {
+        float best = -1.0f;
+        int bj = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            float d = sqdist3(px[j], py[j], pz[j], x1, y1, z1);
+            float d2 = fminf(d, temp[j]);
+            temp[j] = d2;
+            bool gt = d2 > best;
+            best = gt ? d2 : best;
+            bj = gt ? j : bj;
+        }
+        float wmax = wave_max_f32(best);
+        const int buf = r & 1;
+        if (wmax >= 0.f) {
+            // smaller tie key wins among equal distances: (k mod T) << 22 | k
+            unsigned int tk = tmod | (unsigned int)(tid + bj * FPS_THREADS);
+            unsigned long long cand = __ballot(best == wmax);
+            int win;
+            if (__popcll(cand) == 1) win = __ffsll((long long)cand) - 1;
+            else {
+                unsigned int v = best == wmax ? tk : 0xffffffffu;
+                for (int d = WAVE / 2; d > 0; d >>= 1) v = min(v, (unsigned int)__shfl_xor((int)v, d, WAVE));
+                win = __ffsll((long long)__ballot(best == wmax && tk == v)) - 1;
+            }
+            if (lane == win) {
+                float bx = px[0], by = py[0], bz = pz[0];
+#pragma unroll
+                for (int j = 1; j < PPT; j++) { bool s = bj == j; bx = s ? px[j] : bx; by = s ? py[j] : by; bz = s ? pz[j] : bz; }
+                sbest[buf][w] = wmax; stie[buf][w] = tk;
+                sxyz[buf][w][0] = bx; sxyz[buf][w][1] = by; sxyz[buf][w][2] = bz;
+            }
+        } else if (lane == 0) {
+            sbest[buf][w] = -1.0f; stie[buf][w] = 0xffffffffu;
+        }
+        __syncthreads();
+        float g = -1.0f;
+        unsigned int gt = 0xffffffffu;
+        int gw = 0;
+#pragma unroll
+        for (int i = 0; i < FPS_WAVES; i++) {
+            float v = sbest[buf][i];
+            unsigned int t = stie[buf][i];
+            bool better = v > g || (v == g && t < gt);
+            g = better ? v : g; gt = better ? t : gt; gw = better ? i : gw;
+        }
+        int old;
+        if (g < 0.f) {            // nobody competes: upstream returns index 0
+            old = 0;
+            x1 = P[0]; y1 = P[1]; z1 = P[2];
+        } else {
+            old = (int)(gt & 0x3fffffu);
+            x1 = sxyz[buf][gw][0]; y1 = sxyz[buf][gw][1]; z1 = sxyz[buf][gw][2];
+        }
+        if (tid == 0) out[r] = old;
+    }
+}
+
+// generic fallback for clouds that do not fit the register-resident kernel (temp in global memory)
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
 #pragma unroll
@@ -26,83 +134,20 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-template <int PPT>
-__global__ void __launch_bounds__(FPS_THREADS) k_fps(const float* __restrict__ xyz, int n, int m, int T,
-                                                    int* __restrict__ idx_out)
-{
-    const float* P = xyz + (size_t)blockIdx.x * n * 3;
-    int* out = idx_out + (size_t)blockIdx.x * m;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
-    float px[PPT], py[PPT], pz[PPT], temp[PPT];
-    unsigned int tie[PPT];      // ~((k mod T) << 22 | k), 0 marks "never competes"
-#pragma unroll
-    for (int j = 0; j < PPT; j++) {
-        int k = tid + j * FPS_THREADS;
-        bool ok = k < n;
-        px[j] = ok ? P[3 * (size_t)k] : 0.f;
-        py[j] = ok ? P[3 * (size_t)k + 1] : 0.f;
-        pz[j] = ok ? P[3 * (size_t)k + 2] : 0.f;
-        temp[j] = 1e10f;
-        float mag = __fadd_rn(__fadd_rn(__fmul_rn(px[j], px[j]), __fmul_rn(py[j], py[j])), __fmul_rn(pz[j], pz[j]));
-        ok = ok && !((double)mag <= 1e-3);
-        tie[j] = ok ? ~((((unsigned int)(k % T)) << 22) | (unsigned int)k) : 0u;
-    }
-    __shared__ unsigned long long skey[2][FPS_THREADS / WAVE];
-    __shared__ float sxyz[2][FPS_THREADS / WAVE][3];
-    float x1 = P[0], y1 = P[1], z1 = P[2];
-    if (tid == 0) out[0] = 0;
-    for (int r = 1; r < m; r++) {
-        unsigned long long best = 0;
-        float bx = 0.f, by = 0.f, bz = 0.f;
-#pragma unroll
-        for (int j = 0; j < PPT; j++) {
-            float d = sqdist3(px[j], py[j], pz[j], x1, y1, z1);
-            float d2 = fminf(d, temp[j]);
-            if (tie[j]) {
-                temp[j] = d2;
-                unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie[j];
-                if (key > best) { best = key; bx = px[j]; by = py[j]; bz = pz[j]; }
-            }
-        }
-        unsigned long long wbest = wave_max_u64(best);
-        int buf = r & 1;
-        // exactly one lane holds the wave maximum (keys are unique per point) unless it is 0
-        if (best == wbest && (wbest != 0 || lane == 0)) {
-            skey[buf][w] = wbest;
-            sxyz[buf][w][0] = bx; sxyz[buf][w][1] = by; sxyz[buf][w][2] = bz;
-        }
-        __syncthreads();
-        unsigned long long g = 0;
-        int gw = 0;
-#pragma unroll
-        for (int i = 0; i < FPS_THREADS / WAVE; i++) {
-            unsigned long long v = skey[buf][i];
-            if (v > g) { g = v; gw = i; }
-        }
-        int old;
-        if (g == 0) {             // nobody competes: upstream returns index 0
-            old = 0;
-            x1 = P[0]; y1 = P[1]; z1 = P[2];
-        } else {
-            old = (int)((~(unsigned int)g) & 0x3fffffu);
-            x1 = sxyz[buf][gw][0]; y1 = sxyz[buf][gw][1]; z1 = sxyz[buf][gw][2];
-        }
-        if (tid == 0) out[r] = old;
-    }
-}
-
-// generic fallback for clouds that do not fit the register-resident kernel
-__global__ void __launch_bounds__(FPS_THREADS) k_fps_global(const float* __restrict__ xyz, int n, int m, int T,
+__global__ void __launch_bounds__(FPS_THREADS) k_fps_global(const float* __restrict__ xyz, FpsBatch B, int m,
                                                            float* __restrict__ temp_all, int* __restrict__ idx_out)
 {
-    const float* P = xyz + (size_t)blockIdx.x * n * 3;
-    float* temp = temp_all + (size_t)blockIdx.x * n;
+    const int n = B.n[blockIdx.x];
+    const float* P = xyz + (size_t)B.off[blockIdx.x] * 3;
+    float* temp = temp_all + (size_t)B.off[blockIdx.x];
     int* out = idx_out + (size_t)blockIdx.x * m;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    int T = 1;
+    while (T * 2 <= n && T * 2 <= 512) T *= 2;
     for (int k = tid; k < n; k += FPS_THREADS) temp[k] = 1e10f;
-    __shared__ unsigned long long skey[2][FPS_THREADS / WAVE];
+    __shared__ unsigned long long skey[2][FPS_WAVES];
     int old = 0;
-    if (tid == 0) out[0] = 0;
+    if (tid == 0 && m > 0) out[0] = 0;
     for (int r = 1; r < m; r++) {
         float x1 = P[3 * (size_t)old], y1 = P[3 * (size_t)old + 1], z1 = P[3 * (size_t)old + 2];
         unsigned long long best = 0;
@@ -122,39 +167,59 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps_global(const float* __restr
         __syncthreads();
         unsigned long long g = 0;
 #pragma unroll
-        for (int i = 0; i < FPS_THREADS / WAVE; i++) g = skey[buf][i] > g ? skey[buf][i] : g;
+        for (int i = 0; i < FPS_WAVES; i++) g = skey[buf][i] > g ? skey[buf][i] : g;
         old = g == 0 ? 0 : (int)((~(unsigned int)g) & 0x3fffffu);
         if (tid == 0) out[r] = old;
     }
 }
 
-static int fps_upstream_threads(int n)
-{
-    int p = 1;
-    while (p * 2 <= n && p * 2 <= 512) p *= 2;
-    return p;
-}
+#define FPS_MAX_RESIDENT (32 * FPS_THREADS)
 
-extern "C" size_t buf_fps_ws_bytes(int b, int n) { return n > 32 * FPS_THREADS ? sizeof(float) * (size_t)b * n : 256; }
+extern "C" size_t buf_fps_ws_bytes(int b, int n) { return n > FPS_MAX_RESIDENT ? sizeof(float) * (size_t)b * n : 256; }
 
-extern "C" int buf_fps(const float* xyz, int b, int n, int m, int* idx_out, void* ws, size_t ws_bytes, void* stream)
+// Ragged batch: clouds stacked in xyz f32[sum(n),3], lengths_host int[b] -> idx int32[b,m] (indices local to a cloud).
+extern "C" int buf_fps_ragged(const float* xyz, const int* lengths_host, int b, int m, int* idx_out, void* ws, size_t ws_bytes,
+                              void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    BUF_REQUIRE(b >= 0 && n > 0 && m >= 0, BUF_EINVAL, "buf_fps: b=%d n=%d m=%d", b, n, m);
-    BUF_REQUIRE(n < (1 << 22), BUF_EINVAL, "buf_fps: n=%d exceeds 2^22 points per cloud", n);
+    BUF_REQUIRE(b >= 0 && m >= 0, BUF_EINVAL, "buf_fps: b=%d m=%d", b, m);
     if (b == 0 || m == 0) return BUF_OK;
-    BUF_REQUIRE(xyz && idx_out, BUF_EINVAL, "buf_fps: null argument");
-    int T = fps_upstream_threads(n);
-    if (n <= 4 * FPS_THREADS) k_fps<4><<<b, FPS_THREADS, 0, s>>>(xyz, n, m, T, idx_out);
-    else if (n <= 8 * FPS_THREADS) k_fps<8><<<b, FPS_THREADS, 0, s>>>(xyz, n, m, T, idx_out);
-    else if (n <= 16 * FPS_THREADS) k_fps<16><<<b, FPS_THREADS, 0, s>>>(xyz, n, m, T, idx_out);
-    else if (n <= 32 * FPS_THREADS) k_fps<32><<<b, FPS_THREADS, 0, s>>>(xyz, n, m, T, idx_out);
-    else {
-        BUF_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)b * n, BUF_EWORKSPACE, "buf_fps: workspace too small");
-        k_fps_global<<<b, FPS_THREADS, 0, s>>>(xyz, n, m, T, (float*)ws, idx_out);
+    BUF_REQUIRE(xyz && idx_out && lengths_host, BUF_EINVAL, "buf_fps: null argument");
+    for (int c0 = 0, row0 = 0; c0 < b; c0 += FPS_MAXB) {
+        FpsBatch B;
+        int nb = b - c0 < FPS_MAXB ? b - c0 : FPS_MAXB, nmax = 0, row = row0;
+        for (int i = 0; i < nb; i++) {
+            int n = lengths_host[c0 + i];
+            BUF_REQUIRE(n > 0 && n < (1 << 22), BUF_EINVAL, "buf_fps: cloud %d has %d points (need 1..2^22-1)", c0 + i, n);
+            B.off[i] = row; B.n[i] = n; row += n;
+            nmax = n > nmax ? n : nmax;
+        }
+        int* out = idx_out + (size_t)c0 * m;
+        if (nmax <= 4 * FPS_THREADS) k_fps<4><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
+        else if (nmax <= 8 * FPS_THREADS) k_fps<8><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
+        else if (nmax <= 16 * FPS_THREADS) k_fps<16><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
+        else if (nmax <= 24 * FPS_THREADS) k_fps<24><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
+        else if (nmax <= 32 * FPS_THREADS) k_fps<32><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
+        else {
+            BUF_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)row, BUF_EWORKSPACE, "buf_fps: workspace too small");
+            k_fps_global<<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, (float*)ws, out);
+        }
+        row0 = row;
     }
     BUF_LAUNCH_CHECK();
     return BUF_OK;
+}
+
+extern "C" int buf_fps(const float* xyz, int b, int n, int m, int* idx_out, void* ws, size_t ws_bytes, void* stream)
+{
+    BUF_REQUIRE(b >= 0 && n > 0 && m >= 0, BUF_EINVAL, "buf_fps: b=%d n=%d m=%d", b, n, m);
+    if (b == 0) return BUF_OK;
+    int stackl[64];
+    int* lens = b <= 64 ? stackl : (int*)malloc(sizeof(int) * (size_t)b);
+    for (int i = 0; i < b; i++) lens[i] = n;
+    int rc = buf_fps_ragged(xyz, lens, b, m, idx_out, ws, ws_bytes, stream);
+    if (lens != stackl) free(lens);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------ A7
@@ -399,14 +464,85 @@ __global__ void __launch_bounds__(WAVE) k_knn(const float* __restrict__ ref, con
     }
 }
 
+// k = 1 fast path (the mutual-matching call sites, models/BUFFER.py:347,352): grid = query tiles x reference
+// splits; 4 wavefronts of a workgroup share 64 queries (lane = query, vector in registers) and each scans a
+// quarter of the split's LDS-staged reference rows (float4 broadcast reads).  ssd is accumulated over the
+// feature dims in order without contraction, exactly like the generic kernel; the per-query winner
+// (ssd bits << 32 | index) is min-reduced through LDS and one 64-bit atomicMin per query and split.
+#define NN1_SPLIT 256
+
+template <int D>
+__global__ void __launch_bounds__(256) k_nn1(const float* __restrict__ ref, const float* __restrict__ query, int n, int nq,
+                                           unsigned long long* __restrict__ best)
+{
+    __shared__ float4 tile[NN1_SPLIT * (D / 4)];
+    __shared__ unsigned long long red[4][WAVE];
+    const int b = blockIdx.z, lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int q = blockIdx.x * WAVE + lane;
+    const int base = blockIdx.y * NN1_SPLIT;
+    const int cnt = min(NN1_SPLIT, n - base);
+    const float4* R4 = reinterpret_cast<const float4*>(ref + ((size_t)b * n + base) * D);
+    for (int t = threadIdx.x; t < cnt * (D / 4); t += 256) tile[t] = R4[t];
+    float qv[D];
+    const float* Q = query + ((size_t)b * nq + (q < nq ? q : 0)) * D;
+#pragma unroll
+    for (int c = 0; c < D; c++) qv[c] = Q[c];
+    __syncthreads();
+    unsigned long long mine = ~0ull;
+    for (int i = w; i < cnt; i += 4) {
+        float ssd = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < D / 4; c4++) {
+            float4 r = tile[i * (D / 4) + c4];
+            float t0 = __fsub_rn(r.x, qv[4 * c4]);     ssd = __fadd_rn(ssd, __fmul_rn(t0, t0));
+            float t1 = __fsub_rn(r.y, qv[4 * c4 + 1]); ssd = __fadd_rn(ssd, __fmul_rn(t1, t1));
+            float t2 = __fsub_rn(r.z, qv[4 * c4 + 2]); ssd = __fadd_rn(ssd, __fmul_rn(t2, t2));
+            float t3 = __fsub_rn(r.w, qv[4 * c4 + 3]); ssd = __fadd_rn(ssd, __fmul_rn(t3, t3));
+        }
+        unsigned long long key = ((unsigned long long)__float_as_uint(ssd) << 32) | (unsigned int)(base + i);
+        mine = key < mine ? key : mine;
+    }
+    red[w][lane] = mine;
+    __syncthreads();
+    if (w == 0 && q < nq) {
+        unsigned long long m = red[0][lane];
+        for (int i = 1; i < 4; i++) m = red[i][lane] < m ? red[i][lane] : m;
+        atomicMin(&best[(size_t)b * nq + q], m);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_nn1_finish(const unsigned long long* __restrict__ best, long long total,
+                                                  float* __restrict__ dist, long long* __restrict__ idx)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    unsigned long long key = best[t];
+    if (key == ~0ull) { dist[t] = __uint_as_float(0x7f800000u); idx[t] = 0; return; }
+    dist[t] = sqrtf(__uint_as_float((unsigned int)(key >> 32)));
+    idx[t] = (long long)(key & 0xffffffffu);
+}
+
+extern "C" size_t buf_knn_ws_bytes(int b, int q, int k) { return k == 1 ? sizeof(unsigned long long) * (size_t)b * q + 256 : 256; }
+
 extern "C" int buf_knn(const float* ref, const float* query, int b, int n, int nq, int d, int k, float* dist,
-                       long long* idx, void* stream)
+                       long long* idx, void* ws, size_t ws_bytes, void* stream)
 {
     BUF_REQUIRE(b >= 0 && n >= 0 && nq >= 0 && d > 0 && k > 0, BUF_EINVAL, "buf_knn: b=%d n=%d q=%d d=%d k=%d", b, n, nq, d, k);
     BUF_REQUIRE(d <= KNN_MAXD, BUF_EINVAL, "buf_knn: feature dim %d > %d", d, KNN_MAXD);
     BUF_REQUIRE(k <= 64, BUF_EINVAL, "buf_knn: k=%d > 64", k);
     if ((long long)b * nq == 0) return BUF_OK;
     BUF_REQUIRE(query && dist && idx && (n == 0 || ref), BUF_EINVAL, "buf_knn: null argument");
+    if (k == 1 && d == 32 && n > 0 && ws && ws_bytes >= sizeof(unsigned long long) * (size_t)b * nq) {
+        hipStream_t s = (hipStream_t)stream;
+        unsigned long long* best = (unsigned long long*)ws;
+        BUF_CHECK_HIP(hipMemsetAsync(best, 0xff, sizeof(unsigned long long) * (size_t)b * nq, s));
+        dim3 g1(cdiv(nq, WAVE), cdiv(n, NN1_SPLIT), b);
+        k_nn1<32><<<g1, 256, 0, s>>>(ref, query, n, nq, best);
+        long long total = (long long)b * nq;
+        k_nn1_finish<<<cdiv(total, 256), 256, 0, s>>>(best, total, dist, idx);
+        BUF_LAUNCH_CHECK();
+        return BUF_OK;
+    }
     dim3 grid(cdiv(nq, WAVE), b);
     if (k <= 8) k_knn<8><<<grid, WAVE, 0, (hipStream_t)stream>>>(ref, query, n, nq, d, k, dist, idx);
     else k_knn<64><<<grid, WAVE, 0, (hipStream_t)stream>>>(ref, query, n, nq, d, k, dist, idx);

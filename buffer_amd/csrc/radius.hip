@@ -108,11 +108,15 @@ __global__ void __launch_bounds__(WAVE) k_grid_query(const CellGrid* __restrict_
                                                    int nq, const int* __restrict__ q_off, int nb,
                                                    const int* __restrict__ q_order, float r2, int k_out, int shadow,
                                                    int* __restrict__ nbr_out, int* __restrict__ counts_out,
-                                                   int* __restrict__ max_count_out)
+                                                   int* __restrict__ max_count_out, const int* __restrict__ nq_dyn)
 {
     __shared__ unsigned long long col[KL][WAVE];
     const int lane = threadIdx.x;
     int t = blockIdx.x * WAVE + lane;
+    if (nq_dyn) {                       // fallback pass: the list length lives in device memory
+        nq = min(nq, *nq_dyn);
+        if (blockIdx.x * WAVE >= nq) return;
+    }
     bool active = t < nq;
     int qi = active ? (q_order ? q_order[t] : t) : 0;
     int rs[9], re[9];
@@ -197,6 +201,102 @@ __global__ void __launch_bounds__(WAVE) k_grid_query(const CellGrid* __restrict_
     }
 }
 
+// Fast path: one WAVEFRONT per query.  The 9 cell runs are flattened and scanned 64 candidates at a
+// time (coalesced float4 loads), accepted (d2,index) keys are compacted into a per-wave LDS buffer
+// through ballot + popcount prefix, and every key ranks itself against the others (LDS broadcast
+// reads) -- an exact sort by (d2, index) for rows of up to QW_CAP neighbours.  Longer rows are pushed
+// on a todo list and redone by k_grid_query (lane-per-query, unbounded rows) in the same stream.
+#define QW_WAVES 4
+#define QW_CAP 256
+
+__global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellGrid* __restrict__ grids, const int* __restrict__ table,
+                                                                  const float4* __restrict__ sorted, const float* __restrict__ queries,
+                                                                  int nq, const int* __restrict__ q_off, int nb,
+                                                                  const int* __restrict__ q_order, float r2, int k_out, int shadow,
+                                                                  int* __restrict__ nbr_out, int* __restrict__ counts_out,
+                                                                  int* __restrict__ max_count_out, int* __restrict__ todo,
+                                                                  int* __restrict__ todo_n)
+{
+    __shared__ unsigned long long keys[QW_WAVES][QW_CAP];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    int t = blockIdx.x * QW_WAVES + w;
+    if (t >= nq) return;
+    int qi = __builtin_amdgcn_readfirstlane(q_order ? q_order[t] : t);
+    int b = find_elem(q_off, nb, qi);
+    const CellGrid g = grids[b];
+    const float qx = queries[3 * (size_t)qi], qy = queries[3 * (size_t)qi + 1], qz = queries[3 * (size_t)qi + 2];
+    double fx = floor(((double)qx - (double)g.mn[0]) * g.inv_cell);
+    double fy = floor(((double)qy - (double)g.mn[1]) * g.inv_cell);
+    double fz = floor(((double)qz - (double)g.mn[2]) * g.inv_cell);
+    fx = fmin(fmax(fx, -2.0), (double)g.dim[0] + 1.0);
+    fy = fmin(fmax(fy, -2.0), (double)g.dim[1] + 1.0);
+    fz = fmin(fmax(fz, -2.0), (double)g.dim[2] + 1.0);
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+    // lane j < 9 owns run j; exclusive prefix of the run lengths through a 16-lane scan
+    int rs = 0, len = 0;
+    if (lane < 9) {
+        int y = cy + (lane % 3) - 1, z = cz + (lane / 3) - 1;
+        if (x0 <= x1 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+            int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
+            rs = g0 == 0 ? 0 : table[g0 - 1];
+            len = table[g0 + (x1 - x0)] - rs;
+        }
+    }
+    int inc = len;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        int v = __shfl_up(inc, d, WAVE);
+        if (lane >= d) inc += v;
+    }
+    const int total = __shfl(inc, 8, WAVE);
+    int pre[9], st[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        pre[j] = __shfl(inc - len, j, WAVE);       // exclusive prefix of run j
+        st[j] = __shfl(rs, j, WAVE);
+    }
+    unsigned long long* K = keys[w];
+    int m = 0;
+    for (int c0 = 0; c0 < total; c0 += WAVE) {
+        int c = c0 + lane;
+        bool hit = false;
+        unsigned long long key = 0;
+        if (c < total) {
+            int p = st[0] + c;
+#pragma unroll
+            for (int j = 1; j < 9; j++) p = c >= pre[j] ? st[j] + (c - pre[j]) : p;
+            float4 s = sorted[p];
+            float d2 = sqdist3(qx, qy, qz, s.x, s.y, s.z);
+            hit = d2 < r2;
+            key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(s.w);
+        }
+        unsigned long long mask = __ballot(hit);
+        int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit && pos < QW_CAP) K[pos] = key;
+        m += __popcll(mask);
+    }
+    if (lane == 0) {
+        if (counts_out) counts_out[qi] = m;
+        if (max_count_out && m > 0) atomicMax(max_count_out, m);
+    }
+    if (k_out == 0) return;
+    if (m > QW_CAP) {                    // rare: row longer than the LDS buffer -> lane-per-query fallback
+        if (lane == 0) todo[atomicAdd(todo_n, 1)] = qi;
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int* row = nbr_out + (size_t)qi * k_out;
+    for (int s0 = 0; s0 < m; s0 += WAVE) {
+        int i = s0 + lane;
+        unsigned long long mine = i < m ? K[i] : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < m; j++) rank += K[j] < mine ? 1 : 0;
+        if (i < m && rank < k_out) row[rank] = (int)(unsigned int)(mine & 0xffffffffu);
+    }
+    for (int i = m + lane; i < k_out; i += WAVE) row[i] = shadow;
+}
+
 // ------------------------------------------------------------------------------------------
 extern "C" int64_t buf_grid_default_cells(int ns, int nb)
 {
@@ -217,7 +317,7 @@ static void carve_grid(buf_grid_t* g, WsCarver& w, int ns, int nb, int64_t cells
     g->scan_tmp = w.take<int>(scan_tmp_ints());
 }
 
-struct GridExtra { float4* sorted_tmp; int* cell_of; int* q_off; };
+struct GridExtra { float4* sorted_tmp; int* cell_of; int* q_off; int* todo_n; };
 
 static GridExtra carve_extra(WsCarver& w, int ns, int nb)
 {
@@ -225,6 +325,7 @@ static GridExtra carve_extra(WsCarver& w, int ns, int nb)
     e.sorted_tmp = w.take<float4>((size_t)(ns > 0 ? ns : 1));
     e.cell_of = w.take<int>((size_t)(ns > 0 ? ns : 1));
     e.q_off = w.take<int>((size_t)nb + 1);
+    e.todo_n = w.take<int>(64);
     return e;
 }
 
@@ -273,7 +374,7 @@ extern "C" int buf_grid_build(buf_grid_t* g, const float* supports, int ns, cons
 
 extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq, const int* q_batches_host,
                               const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
-                              int* max_count_out, void* stream)
+                              int* max_count_out, void* todo_ws, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     BUF_REQUIRE(g && g->ws && q_batches_host, BUF_EINVAL, "buf_grid_query: null argument");
@@ -291,12 +392,27 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
     if (rc) return rc;
     float r2 = radius * radius;     // neighbors.cpp:228
     int blocks = cdiv(nq, WAVE);
-    if (k_out <= 32)
-        k_grid_query<32><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
-                                                ex.q_off, g->nb, q_order, r2, k_out, g->ns, nbr_out, counts_out, max_count_out);
-    else
-        k_grid_query<64><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
-                                                ex.q_off, g->nb, q_order, r2, k_out, g->ns, nbr_out, counts_out, max_count_out);
+    BUF_REQUIRE(todo_ws || k_out == 0, BUF_EINVAL, "buf_grid_query: todo workspace missing");
+    int* todo = (int*)todo_ws;
+    BUF_CHECK_HIP(hipMemsetAsync(ex.todo_n, 0, sizeof(int), s));
+    // algorithmic bytes of this launch: queries + supports + the index table
+    TimedSpan span;
+    bool timed = timing_begin(s, &span, 12.0 * nq + 12.0 * g->ns + 4.0 * (double)nq * k_out);
+    // todo list (query ids of rows longer than QW_CAP) is carved behind the caller's output: it needs at
+    // most nq ints; the first k_out==0 launch never produces one.
+    k_grid_query_wave<<<cdiv(nq, QW_WAVES), QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
+                                                                   queries, nq, ex.q_off, g->nb, q_order, r2, k_out, g->ns, nbr_out,
+                                                                   counts_out, max_count_out, todo, ex.todo_n);
+    if (timed) timing_end(s, &span);
+    if (k_out > 0) {
+        // fallback pass over the (normally empty) todo list; exits at once when the device-side count is 0
+        if (k_out <= 32)
+            k_grid_query<32><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
+                                                    ex.q_off, g->nb, todo, r2, k_out, g->ns, nbr_out, nullptr, nullptr, ex.todo_n);
+        else
+            k_grid_query<64><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
+                                                    ex.q_off, g->nb, todo, r2, k_out, g->ns, nbr_out, nullptr, nullptr, ex.todo_n);
+    }
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
@@ -309,5 +425,10 @@ extern "C" int buf_radius_neighbors(const float* queries, int nq, const float* s
     buf_grid_t g;
     int rc = buf_grid_build(&g, supports, ns, s_batches_host, nb, radius, 0, ws, ws_bytes, stream);
     if (rc) return rc;
-    return buf_grid_query(&g, queries, nq, q_batches_host, nullptr, radius, k_out, nbr_out, counts_out, max_count_out, stream);
+    // the todo list of the query pass goes behind the grid in the same workspace
+    size_t need = buf_grid_ws_bytes(ns, nb, 0);
+    BUF_REQUIRE(ws_bytes >= need + sizeof(int) * (size_t)nq, BUF_EWORKSPACE, "buf_radius_neighbors: workspace %zu < %zu",
+                ws_bytes, need + sizeof(int) * (size_t)nq);
+    return buf_grid_query(&g, queries, nq, q_batches_host, nullptr, radius, k_out, nbr_out, counts_out, max_count_out,
+                          (char*)ws + need, stream);
 }

@@ -80,8 +80,9 @@ class CellGrid:
         if q_order is not None:
             q_order = _dev(q_order, torch.int32, "q_order")
         r = self.radius if radius is None else float(radius)
+        todo = torch.empty((max(nq, 1),), dtype=torch.int32, device=queries.device) if k > 0 else None
         check(L.buf_grid_query(C.byref(self.g), _ptr(queries), nq, _hptr(q_lengths), _ptr(q_order), r, int(k),
-                               _ptr(out), _ptr(cnt), _ptr(max_count), _stream()), "buf_grid_query")
+                               _ptr(out), _ptr(cnt), _ptr(max_count), _ptr(todo), _stream()), "buf_grid_query")
         return (out, cnt) if counts else out
 
 
@@ -127,6 +128,21 @@ def furthest_point_sample(xyz, npoint):
     nbytes = L.buf_fps_ws_bytes(b, n)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
     check(L.buf_fps(_ptr(xyz), b, n, int(npoint), _ptr(out), _ptr(ws), nbytes, _stream()), "buf_fps")
+    return out
+
+
+def furthest_point_sample_ragged(xyz, lengths, npoint):
+    """clouds of different size stacked in xyz f32[sum(n),3] -> int32[b,npoint] (indices local to each cloud);
+    all clouds are sampled concurrently, one workgroup each."""
+    L = _lib.lib()
+    xyz = _dev(xyz, torch.float32, "furthest_point_sample_ragged")
+    lengths = _host_i32(lengths)
+    b = int(lengths.shape[0])
+    out = torch.empty((b, npoint), dtype=torch.int32, device=xyz.device)
+    nbytes = L.buf_fps_ws_bytes(1, int(xyz.shape[0]))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+    check(L.buf_fps_ragged(_ptr(xyz), _hptr(lengths), b, int(npoint), _ptr(out), _ptr(ws), nbytes, _stream()),
+          "buf_fps_ragged")
     return out
 
 
@@ -193,7 +209,10 @@ def knn(ref, query, k):
     q = query.shape[1]
     dist = torch.empty((b, q, k), dtype=torch.float32, device=ref.device)
     idx = torch.empty((b, q, k), dtype=torch.int64, device=ref.device)
-    check(L.buf_knn(_ptr(ref), _ptr(query), b, n, q, d, int(k), _ptr(dist), _ptr(idx), _stream()), "buf_knn")
+    nbytes = L.buf_knn_ws_bytes(b, q, int(k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
+    check(L.buf_knn(_ptr(ref), _ptr(query), b, n, q, d, int(k), _ptr(dist), _ptr(idx), _ptr(ws), nbytes, _stream()),
+          "buf_knn")
     return dist, idx
 
 

@@ -43,16 +43,18 @@ class BufferPipeline:
         score = self.point.detnet(pyr, bottle, skips)
         pts0 = pyr['points'][0]
         out = {}
-        kp, ka = [], []
+        cand_p, cand_a = [], []
         for lo, hi in ((0, n_src), (n_src, pts0.shape[0])):
             p = pts0[lo:hi]
             a = orient_axes(axis[lo:hi], p)
             keep = torch.nonzero(score[lo:hi, 0] > cfg.keypts_th).flatten()         # BUFFER.py:255-259
-            p, a = p[keep].contiguous(), a[keep].contiguous()
-            if p.shape[0] == 0:
+            if keep.shape[0] == 0:
                 return self._identity(out, detail)
-            idx = ops.furthest_point_sample(p[None], cfg.num_keypts)[0].long()       # :266-271
-            kp.append(p[idx].contiguous()); ka.append(a[idx].contiguous())
+            cand_p.append(p[keep]); cand_a.append(a[keep])
+        # both fragments sampled in one launch, one workgroup per cloud (BUFFER.py:266-271)
+        fps = ops.furthest_point_sample_ragged(torch.cat(cand_p), [c.shape[0] for c in cand_p], cfg.num_keypts).long()
+        kp = [cand_p[i][fps[i]].contiguous() for i in range(2)]
+        ka = [cand_a[i][fps[i]].contiguous() for i in range(2)]
         g = torch.Generator(device=self.device)
         g.manual_seed(seed)
         res = []

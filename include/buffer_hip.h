@@ -41,6 +41,11 @@ const char* buf_last_error(void);
 int         buf_version(void);
 /* Number of visible HIP devices (<0 on error); does not create a context. */
 int         buf_device_count(void);
+/* Measurement aid (off by default): when enabled, buf_grid_query brackets its kernel with HIP events on
+ * the launch stream; buf_timing_collect synchronises on them, returns the number of launches and
+ * their summed duration / algorithmic bytes, and resets. */
+void        buf_timing_enable(int on);
+long long   buf_timing_collect(double* total_ms, double* total_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * A2  radius neighbours -- cpp_neighbors.batch_query (neighbors.cpp:211-332).
@@ -80,8 +85,10 @@ int     buf_grid_build(buf_grid_t* g, const float* supports, int ns, const int* 
  * as long as it is <= the grid's cell edge. */
 int     buf_grid_query(const buf_grid_t* g, const float* queries, int nq, const int* q_batches_host,
                        const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
-                       int* max_count_out, void* stream);
-/* Build + query in one call (what batch_query does). */
+                       int* max_count_out, void* todo_ws, void* stream);
+/* todo_ws: int32[nq] scratch (rows longer than 256 neighbours are redone by a second, unbounded pass);
+ * may be null when k_out == 0.
+ * Build + query in one call (what batch_query does); ws >= buf_grid_ws_bytes(ns,nb,0) + 4*nq bytes. */
 int     buf_radius_neighbors(const float* queries, int nq, const float* supports, int ns,
                              const int* q_batches_host, const int* s_batches_host, int nb, float radius,
                              int k_out, int* nbr_out, int* counts_out, int* max_count_out,
@@ -111,6 +118,10 @@ int     buf_grid_subsample_batch(const float* pts, int n, const int* batches_hos
  * |p|^2 <= 1e-3, arg-max tie rule of the upstream 512-thread kernel.  ws only for n > 32768. */
 size_t  buf_fps_ws_bytes(int b, int n);
 int     buf_fps(const float* xyz, int b, int n, int m, int* idx_out, void* ws, size_t ws_bytes, void* stream);
+/* ragged batch (clouds of different size sampled concurrently, one workgroup each): xyz f32[sum(n),3] stacked,
+ * lengths_host int[b] -> idx int32[b,m], indices local to each cloud.  ws sized for (1, sum(n)). */
+int     buf_fps_ragged(const float* xyz, const int* lengths_host, int b, int m, int* idx_out, void* ws, size_t ws_bytes,
+                       void* stream);
 /* gather_operation: feat f32[b,c,n], idx int32[b,m] -> f32[b,c,m] */
 int     buf_gather(const float* feat, const int* idx, int b, int c, int n, int m, float* out, void* stream);
 /* grouping_operation: feat f32[b,c,n], idx int32[b,m,nsample] -> f32[b,c,m,nsample] */
@@ -128,8 +139,9 @@ int     buf_select_patches(const float* pts, const float* kpts, int n, int m, fl
 
 /* knn_cuda.KNN(k, transpose_mode=True) (README.md:32; models/BUFFER.py:347,352):
  * ref f32[b,n,d], query f32[b,q,d] -> dist f32[b,q,k] (Euclidean, ascending), idx int64[b,q,k]. d,k <= 64. */
+size_t  buf_knn_ws_bytes(int b, int q, int k);
 int     buf_knn(const float* ref, const float* query, int b, int n, int q, int d, int k, float* dist,
-                long long* idx, void* stream);
+                long long* idx, void* ws, size_t ws_bytes, void* stream);
 
 /* torch_batch_svd.svd (README.md:35; utils/common.py:715): a f32[n,3,3] -> u,s,v with a = u diag(s) v^T, s descending. */
 int     buf_svd3x3_batched(const float* a, int n, float* u, float* s, float* v, void* stream);
