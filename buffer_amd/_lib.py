@@ -42,8 +42,8 @@ _SIGNATURES = {
     "buf_grid_build": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _i, _f, _i64, _vp, _sz, _vp]),
     "buf_grid_query": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "buf_radius_neighbors": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "buf_grid_subsample_ws_bytes": (_sz, [_i, _i, _i64]),
-    "buf_grid_subsample_batch": (_i, [_vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "buf_grid_subsample_ws_bytes": (_sz, [_i, _i, _i64, _i]),
+    "buf_grid_subsample_batch": (_i, [_vp, _i, _vp, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "buf_fps_ws_bytes": (_sz, [_i, _i]),
     "buf_fps": (_i, [_vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "buf_gather": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

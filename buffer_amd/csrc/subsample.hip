@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(256) k_vox_heads(const float4* __restrict__ so
 
 __global__ void __launch_bounds__(256) k_vox_emit(const float4* __restrict__ sorted, const int* __restrict__ cell_of,
                                                 const int* __restrict__ table, const int* __restrict__ rowidx,
-                                                int n, const VoxStatus* __restrict__ st, float* __restrict__ out)
+                                                int n, const VoxStatus* __restrict__ st, float* __restrict__ out,
+                                                const float* __restrict__ feats, int fdim, float* __restrict__ out_feats)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n || st->error) return;
@@ -139,6 +140,14 @@ __global__ void __launch_bounds__(256) k_vox_emit(const float4* __restrict__ sor
     out[3 * (size_t)r] = __fmul_rn(sx, w);
     out[3 * (size_t)r + 1] = __fmul_rn(sy, w);
     out[3 * (size_t)r + 2] = __fmul_rn(sz, w);
+    if (feats) {                             // features summed in input order, then f / (float)count (:90-96)
+        float cf = (float)(e - s);
+        for (int d = 0; d < fdim; d++) {
+            float acc = 0.f;
+            for (int t = s; t < e; t++) acc = __fadd_rn(acc, feats[(size_t)__float_as_int(sorted[t].w) * fdim + d]);
+            out_feats[(size_t)r * fdim + d] = __fdiv_rn(acc, cf);
+        }
+    }
 }
 
 // per-element row counts from the exclusive head scan; counts[nb] = status word
@@ -157,10 +166,10 @@ __global__ void k_vox_counts(const int* __restrict__ rowidx, const int* __restri
 
 struct VoxWs {
     VoxGrid* grids; VoxStatus* st; int* off; int* table; int* cell_of; float4* sorted_tmp; float4* sorted;
-    int* order; int* head; int* scan_tmp; int* total; int* counts; float* out_tmp;
+    int* order; int* head; int* scan_tmp; int* total; int* counts; float* out_tmp; float* feat_tmp;
 };
 
-static VoxWs carve_vox(WsCarver& w, int n, int nb, int64_t max_cells)
+static VoxWs carve_vox(WsCarver& w, int n, int nb, int64_t max_cells, int fdim)
 {
     VoxWs v;
     size_t nn = (size_t)(n > 0 ? n : 1);
@@ -177,18 +186,20 @@ static VoxWs carve_vox(WsCarver& w, int n, int nb, int64_t max_cells)
     v.total = w.take<int>(1);
     v.counts = w.take<int>((size_t)nb + 2);
     v.out_tmp = w.take<float>(3 * nn);
+    v.feat_tmp = w.take<float>((size_t)(fdim > 0 ? fdim : 0) * nn + 1);
     return v;
 }
 
-extern "C" size_t buf_grid_subsample_ws_bytes(int n, int nb, int64_t max_cells)
+extern "C" size_t buf_grid_subsample_ws_bytes(int n, int nb, int64_t max_cells, int fdim)
 {
     WsCarver w(nullptr, 0);
-    carve_vox(w, n, nb, max_cells);
+    carve_vox(w, n, nb, max_cells, fdim);
     return w.used();
 }
 
 extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batches_host, int nb, float dl,
-                                        int max_p, float* out_pts, int* out_batches_host, int* out_m_host,
+                                        int max_p, const float* feats, int fdim, float* out_pts, float* out_feats,
+                                        int* out_batches_host, int* out_m_host,
                                         int64_t max_cells, void* ws, size_t ws_bytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -198,7 +209,9 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     BUF_REQUIRE(max_cells > 0 && max_cells < 0x7fffffffLL, BUF_EINVAL, "buf_grid_subsample_batch: max_cells=%lld", (long long)max_cells);
     BUF_REQUIRE(n == 0 || (pts && out_pts), BUF_EINVAL, "buf_grid_subsample_batch: null points");
     WsCarver w(ws, ws_bytes);
-    VoxWs v = carve_vox(w, n, nb, max_cells);
+    BUF_REQUIRE(fdim >= 0 && (fdim == 0 || (feats && out_feats)), BUF_EINVAL, "buf_grid_subsample_batch: features");
+    if (!feats) fdim = 0;
+    VoxWs v = carve_vox(w, n, nb, max_cells, fdim);
     BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_grid_subsample_batch: workspace %zu < %zu bytes", ws_bytes, w.used());
     int rc = upload_offsets(v.off, batches_host, nb, n, "buf_grid_subsample_batch", s);
     if (rc) return rc;
@@ -220,7 +233,8 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     rc = exclusive_scan_i32(v.head, n, v.scan_tmp, v.total, s);
     if (rc) return rc;
     float* dst = max_p > 0 ? v.out_tmp : out_pts;
-    k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.cell_of, v.table, v.head, n, v.st, dst);
+    float* fdst = max_p > 0 ? v.feat_tmp : out_feats;
+    k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.cell_of, v.table, v.head, n, v.st, dst, fdim > 0 ? feats : nullptr, fdim, fdst);
     k_vox_counts<<<cdiv(nb + 1, 64), 64, 0, s>>>(v.head, v.off, nb, n, 0, v.total, v.st, v.counts);
     BUF_LAUNCH_CHECK();
     int stackc[66];
@@ -241,6 +255,9 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
             if (max_p > 0 && keep > 0) {
                 hipError_t e2 = hipMemcpyAsync(out_pts + 3 * (size_t)m, v.out_tmp + 3 * (size_t)src, sizeof(float) * 3 * (size_t)keep,
                                                hipMemcpyDeviceToDevice, s);
+                if (e2 == hipSuccess && fdim > 0)
+                    e2 = hipMemcpyAsync(out_feats + (size_t)fdim * m, v.feat_tmp + (size_t)fdim * src, sizeof(float) * (size_t)fdim * keep,
+                                        hipMemcpyDeviceToDevice, s);
                 if (e2 != hipSuccess) { buf_set_error("buf_grid_subsample_batch: %s", hipGetErrorString(e2)); rc = BUF_EHIP; break; }
             }
             out_batches_host[b] = keep;

@@ -1,0 +1,44 @@
+"""(e) Multi-GPU: fragment pairs are independent, so the evaluation shards pair indices over the ranks
+(one process per GPU, interleaved i -> rank i mod W to balance scenes of unequal size) with no
+data-path collective; the only exchange is ONE all_gather of the per-pair poses (+ pair ids) at the
+end -- RCCL over xGMI on the GPU box (backend 'nccl'), gloo in the CPU tests."""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_pairs, rank, world):
+    """pair i is processed by rank i mod world."""
+    return list(range(rank, n_pairs, world))
+
+
+def gather_poses(local_ids, local_poses, n_pairs, device=None):
+    """all ranks call; local_poses f32[k,4,4] for pair ids local_ids (k may differ by one between ranks).
+    -> f32[n_pairs,4,4] on every rank, row i = pose of pair i (identity where nothing was reported)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    device = device or (local_poses.device if isinstance(local_poses, torch.Tensor) else 'cpu')
+    cap = (n_pairs + world - 1) // world
+    buf = torch.zeros((cap, 17), dtype=torch.float32, device=device)
+    buf[:, 0] = -1
+    k = len(local_ids)
+    if k:
+        buf[:k, 0] = torch.as_tensor(local_ids, dtype=torch.float32, device=device)
+        buf[:k, 1:] = torch.as_tensor(local_poses, dtype=torch.float32, device=device).reshape(k, 16)
+    if world > 1:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        allbuf = torch.cat(parts)
+    else:
+        allbuf = buf
+    out = torch.eye(4, dtype=torch.float32, device=device).repeat(n_pairs, 1, 1)
+    valid = allbuf[:, 0] >= 0
+    ids = allbuf[valid, 0].long()
+    out[ids] = allbuf[valid, 1:].reshape(-1, 4, 4)
+    return out
+
+
+def broadcast_limits(limits, device='cpu'):
+    """neighbourhood limits are calibrated once (rank 0) and shared, so every rank truncates identically."""
+    t = torch.as_tensor(list(limits), dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=0)
+    return [int(x) for x in t.cpu()]

@@ -96,8 +96,8 @@ def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, k=None):
     return grid.query(queries, q_lengths, k)
 
 
-def grid_subsample_batch(points, lengths, dl, max_p=0, max_cells=0):
-    """subsample_batch on device -> (f32[M,3] device tensor, int32[nb] numpy lengths).
+def grid_subsample_batch(points, lengths, dl, max_p=0, max_cells=0, features=None):
+    """subsample_batch on device -> (f32[M,3] device tensor, int32[nb] numpy lengths[, f32[M,fd] feature means]).
     Rows per element in ascending voxel-key order."""
     L = _lib.lib()
     points = _dev(points, torch.float32, "grid_subsample_batch.points")
@@ -107,14 +107,22 @@ def grid_subsample_batch(points, lengths, dl, max_p=0, max_cells=0):
     n, nb = int(points.shape[0]), int(lengths.shape[0])
     if max_cells <= 0:
         max_cells = max(1 << 22, 64 * n)
-    nbytes = L.buf_grid_subsample_ws_bytes(n, nb, max_cells)
+    fd = 0
+    out_f = None
+    if features is not None:
+        features = _dev(features, torch.float32, "grid_subsample_batch.features")
+        fd = int(features.shape[1])
+        out_f = torch.empty((max(n, 1), fd), dtype=torch.float32, device=points.device)
+    nbytes = L.buf_grid_subsample_ws_bytes(n, nb, max_cells, fd)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
     out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=points.device)
     out_b = np.zeros(nb, np.int32)
     m = C.c_int(0)
-    check(L.buf_grid_subsample_batch(_ptr(points), n, _hptr(lengths), nb, float(dl), int(max_p), _ptr(out),
-                                     _hptr(out_b), C.byref(m), max_cells, _ptr(ws), nbytes, _stream()),
-          "buf_grid_subsample_batch")
+    check(L.buf_grid_subsample_batch(_ptr(points), n, _hptr(lengths), nb, float(dl), int(max_p), _ptr(features), fd,
+                                     _ptr(out), _ptr(out_f), _hptr(out_b), C.byref(m), max_cells, _ptr(ws), nbytes,
+                                     _stream()), "buf_grid_subsample_batch")
+    if features is not None:
+        return out[:m.value], out_b, out_f[:m.value]
     return out[:m.value], out_b
 
 

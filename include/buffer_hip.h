@@ -104,9 +104,11 @@ int     buf_radius_neighbors(const float* queries, int nq, const float* supports
  * `max_cells` bounds the dense voxel table (sum over elements); BUF_ECAPACITY if exceeded.
  * Synchronises `stream` (the row count has to reach the host).
  */
-size_t  buf_grid_subsample_ws_bytes(int n, int nb, int64_t max_cells);
+size_t  buf_grid_subsample_ws_bytes(int n, int nb, int64_t max_cells, int fdim);
+/* feats (nullable) f32[n,fdim] -> out_feats f32[M,fdim]: per-voxel feature means, summed in input order. */
 int     buf_grid_subsample_batch(const float* pts, int n, const int* batches_host, int nb, float dl,
-                                 int max_p, float* out_pts, int* out_batches_host, int* out_m_host,
+                                 int max_p, const float* feats, int fdim, float* out_pts, float* out_feats,
+                                 int* out_batches_host, int* out_m_host,
                                  int64_t max_cells, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
