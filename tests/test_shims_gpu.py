@@ -63,4 +63,4 @@ def test_pointnet2_knn_svd_shims(oracle, dev):
     np.testing.assert_allclose(dis.cpu().numpy(), wd, rtol=1e-6)
     a = torch.from_numpy(rng.normal(size=(50, 3, 3)).astype(np.float32)).to(dev)
     u, s, v = svd(a)
-    np.testing.assert_allclose((u * s[:, None]) @ v.transpose(1, 2), a, atol=2e-5)
+    np.testing.assert_allclose(((u * s[:, None]) @ v.transpose(1, 2)).cpu().numpy(), a.cpu().numpy(), atol=2e-5)
