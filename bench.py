@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--keypts', type=int, default=5000, help='keypoints per fragment (BASELINE: ~5k)')
-    ap.add_argument('--pairs-per-step', type=int, default=1)
+    ap.add_argument('--pairs-per-step', type=int, default=3, help='pairs registered concurrently per GPU and step (one stream each)')
     ap.add_argument('--distinct-pairs', type=int, default=2, help='synthetic pairs generated per rank (cycled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-keypts', type=int, default=256, help='keypoint sample of the CPU baseline leg')
@@ -97,12 +97,31 @@ def main():
     torch.cuda.synchronize()
     L = _lib.lib()
 
+    # pairs of one step run concurrently, one host thread + one HIP stream each: the latency-bound stages of
+    # one pair (FPS occupies 2 CUs for milliseconds) overlap the chip-filling stages of another
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    nconc = max(1, a.pairs_per_step)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nconc)]
+    tls = threading.local()
+    slot_lock = threading.Lock()
+    free_slots = list(range(nconc))
+
+    def one_pair(k):
+        if not hasattr(tls, 'slot'):
+            with slot_lock:
+                tls.slot = free_slots.pop()
+            torch.cuda.set_device(local)
+        with torch.cuda.stream(streams[tls.slot]):
+            return pipe.register(inputs[k], seed=k)
+
+    pool = ThreadPoolExecutor(max_workers=nconc) if nconc > 1 else None
+
     def step(i):
-        poses = []
-        for j in range(a.pairs_per_step):
-            k = (i * a.pairs_per_step + j) % len(inputs)
-            poses.append(pipe.register(inputs[k], seed=k))
-        return poses
+        ks = [(i * a.pairs_per_step + j) % len(inputs) for j in range(a.pairs_per_step)]
+        if pool is None:
+            return [pipe.register(inputs[k], seed=k) for k in ks]
+        return list(pool.map(one_pair, ks))
 
     for i in range(a.warmup):
         step(i)

@@ -8,3 +8,4 @@
 #include "vn.hip"
 #include "voxelize.hip"
 #include "registration.hip"
+#include "convnet.hip"

@@ -1,0 +1,183 @@
+// A11 dense part -- Cylindrical_Net (models/patchnet.py:15-85) as ONE fused fp32-MFMA kernel.
+//
+// Reference: Conv3d(16->64, 3x3x3, radial depth 3 -> 1) + 7 x Conv2d 3x3 (64,128,128,64,64,32,32), each
+// preceded by torch.cat padding (circular in azimuth, zeros in elevation, utils/common.py:265-310) and
+// followed by BatchNorm(affine=False)+ReLU (except the last) -- 8 library convolutions, 16 concatenations
+// and 14 element-wise passes over [P,C,7,20] tensors per call.
+//
+// Here one workgroup owns one patch for the whole stack.  A layer is an implicit GEMM
+//     out[n][m] = relu( sum_k A[m][k] * Wt[k][n] + b[n] ),  m = ele*20 + azi (140 positions, 9 tiles of 16),
+//     k = s*Cin + c with s = ky*3 + kx,  A[m][k] = in[c][ele+ky-1][(azi+kx-1) mod 20]  (0 outside 0 <= ele < 7)
+// on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain).  Activations never leave LDS
+// (two 128x140 fp32 buffers, 140 KB); A fragments are gathered from LDS with the padding folded into
+// the address (one ds_read_b32 + one select per fragment), B fragments (BN-folded weights, [K][Cout]
+// row-major, 1.7 MB for the whole net, L2-resident) stream from global memory through a register ring.
+// HBM traffic per patch: 26.9 KB in, 17.9 KB out.
+#include "common.h"
+
+#define CN_POS 140            // 7 elevation x 20 azimuth
+#define CN_MT 9               // ceil(140 / 16)
+#define CN_MAXC 128
+#define CN_LAYERS 8
+#define CN_THREADS 256
+#define CN_PF 4               // k-steps per software-pipeline group
+#define CN_BUF (CN_MAXC * CN_POS)                 // one activation buffer
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct CylNetParams {
+    const float* wt[CN_LAYERS];     // [9*Cin][Cout] row-major, BN folded
+    const float* bias[CN_LAYERS];   // [Cout]
+    int cin[CN_LAYERS], cout[CN_LAYERS], relu[CN_LAYERS];
+};
+
+// One layer for the calling wavefront: M-tiles [mt0, mt0+MT) x N-tiles [nt0, nt0+NT) of 16x16.
+// The k loop is software-pipelined in groups of CN_PF k-steps: while the MFMAs of group g run, the A
+// fragments (LDS) and B fragments (global/L2) of group g+1 are already in flight.  All loads are
+// unconditional: a prefetch past the end of a tap is clamped to the tap's last group.
+template <int MT, int NT>
+__device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* __restrict__ out_lds, float* __restrict__ out_glb,
+                                          const float* __restrict__ wt, const float* __restrict__ bias, int cin, int cout,
+                                          int relu, int mt0, int mt_cnt, int nt0)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int li = lane & 15, lk = lane >> 4;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[t][u] = (f32x4){ 0.f, 0.f, 0.f, 0.f };
+    int ey[MT], ax[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        int m = (mt0 + t) * 16 + li;
+        ey[t] = m / 20; ax[t] = m % 20;
+    }
+    const int groups = cin >> 4;                     // groups of CN_PF (=4) k-steps per kernel tap
+    const float* wrow = wt + (size_t)lk * cout + nt0 * 16 + li;
+    for (int s = 0; s < 9; s++) {
+        const int ky = s / 3 - 1, kx = s % 3 - 1;
+        const float* ia[MT];
+        bool ok[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            int y = ey[t] + ky, x = ax[t] + kx;
+            x = x < 0 ? x + 20 : (x >= 20 ? x - 20 : x);
+            ok[t] = y >= 0 && y < 7 && t < mt_cnt;
+            ia[t] = in + lk * CN_POS + (ok[t] ? y * 20 + x : 0);
+        }
+        const float* ws = wrow + (size_t)s * cin * cout;
+        // ping-pong register sets; sched_barriers pin "issue loads of the next group" in front of
+        // "MFMAs of the current group" (the compiler otherwise rotates the loop and exposes the latency)
+        float a0[CN_PF][MT], b0[CN_PF][NT], a1[CN_PF][MT], b1[CN_PF][NT];
+#define CYL_LOAD(A, B, G)                                                                              \
+    {                                                                                                  \
+        const int g_ = (G) < groups ? (G) : groups - 1;   /* prefetch past the tap re-reads its last group */ \
+        const float* wn_ = ws + (size_t)g_ * CN_PF * 4 * cout;                                         \
+        _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
+            _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = wn_[(size_t)p * 4 * cout + u * 16]; \
+        }                                                                                              \
+        _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) A[p][t] = ia[t][(g_ * CN_PF + p) * 4 * CN_POS]; \
+        }                                                                                              \
+    }
+#define CYL_MMA(A, B)                                                                                  \
+    _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                                \
+        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                               \
+            const float av_ = ok[t] ? A[p][t] : 0.f;                                                   \
+            _Pragma("unroll") for (int u = 0; u < NT; u++)                                             \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, B[p][u], acc[t][u], 0, 0, 0);    \
+        }                                                                                              \
+    }
+        CYL_LOAD(a0, b0, 0)
+#pragma unroll 1
+        for (int g = 0; g < groups; g += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            CYL_LOAD(a1, b1, g + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            CYL_MMA(a0, b0)
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < groups) {
+                CYL_LOAD(a0, b0, g + 2)
+                __builtin_amdgcn_sched_barrier(0);
+                CYL_MMA(a1, b1)
+            }
+        }
+#undef CYL_LOAD
+#undef CYL_MMA
+    }
+    // epilogue: bias (+ReLU); C/D layout: col = lane & 15 (n), rows (lane >> 4)*4 + r (m)
+#pragma unroll
+    for (int u = 0; u < NT; u++) {
+        const int n = (nt0 + u) * 16 + li;
+        const float bv = bias[n];
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const int m = (mt0 + t) * 16 + lk * 4;
+            if (t < mt_cnt && m < CN_POS) {
+                f32x4 v = acc[t][u];
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                float* dst = out_glb ? out_glb + (size_t)n * CN_POS + m : out_lds + n * CN_POS + m;
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(CN_THREADS) k_cyl_net(const float* __restrict__ x, CylNetParams P, float* __restrict__ y)
+{
+    extern __shared__ float lds[];                   // 2 x [128][140] fp32
+    float* buf0 = lds;
+    float* buf1 = lds + CN_BUF;
+    const int patch = blockIdx.x;
+    const int w = threadIdx.x / WAVE;
+    {   // input: [16,3,7,20] = 48 folded channels x 140 positions, contiguous
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)patch * P.cin[0] * CN_POS);
+        f32x4* dst = reinterpret_cast<f32x4*>(buf0);
+        for (int i = threadIdx.x; i < P.cin[0] * CN_POS / 4; i += CN_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    float* in = buf0;
+    float* out = buf1;
+#pragma unroll 1
+    for (int l = 0; l < CN_LAYERS; l++) {
+        const int cin = P.cin[l], cout = P.cout[l];
+        float* glb = l == CN_LAYERS - 1 ? y + (size_t)patch * cout * CN_POS : nullptr;
+        if (cout == 128)      cyl_layer<CN_MT, 2>(in, out, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], 0, CN_MT, 2 * w);
+        else if (cout == 64)  cyl_layer<CN_MT, 1>(in, out, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], 0, CN_MT, w);
+        else {                // cout == 32: two wavefronts share an N-tile and split the M-tiles 5 / 4
+            const int half = w & 1;
+            cyl_layer<5, 1>(in, out, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], half * 5, half ? 4 : 5, w >> 1);
+        }
+        __syncthreads();
+        float* tmp = in; in = out; out = tmp;
+    }
+}
+
+// x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140].  wt/bias: DEVICE pointers per layer, passed in host arrays.
+extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
+                                   const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream)
+{
+    BUF_REQUIRE(npatch >= 0, BUF_EINVAL, "buf_cylindrical_net: npatch=%d", npatch);
+    if (npatch == 0) return BUF_OK;
+    BUF_REQUIRE(x && y && wt_host && bias_host && cin_host && cout_host && relu_host, BUF_EINVAL, "buf_cylindrical_net: null argument");
+    CylNetParams P;
+    for (int l = 0; l < CN_LAYERS; l++) {
+        P.wt[l] = wt_host[l]; P.bias[l] = bias_host[l];
+        P.cin[l] = cin_host[l]; P.cout[l] = cout_host[l]; P.relu[l] = relu_host[l];
+        BUF_REQUIRE(P.wt[l] && P.bias[l], BUF_EINVAL, "buf_cylindrical_net: null weights for layer %d", l);
+        BUF_REQUIRE(P.cin[l] % 16 == 0 && P.cin[l] <= CN_MAXC && (P.cout[l] == 32 || P.cout[l] == 64 || P.cout[l] == 128),
+                    BUF_EINVAL, "buf_cylindrical_net: layer %d has unsupported widths %d -> %d", l, P.cin[l], P.cout[l]);
+        BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net: layer %d width mismatch", l);
+    }
+    size_t lds = sizeof(float) * 2 * CN_BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+        BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cyl_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    k_cyl_net<<<npatch, CN_THREADS, lds, (hipStream_t)stream>>>(x, P, y);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

@@ -12,8 +12,9 @@
 // distance, the smaller (k mod T) and then the smaller k, T = min(512, 2^floor(log2 n)) being the
 // upstream block size (per-thread strict '>' over k = t, t+T, ...; pairwise tree keeps the lower
 // thread).  Keys are packed as (d2 bits << 32) | ~((k mod T) << 22 | k) and max-reduced.
-#define FPS_THREADS 512
+#define FPS_THREADS 512           // fallback kernel + the >16k-point register-resident variants
 #define FPS_WAVES (FPS_THREADS / WAVE)
+#define FPS_LDS_POINTS 12800      // clouds up to this size keep an xyz copy in LDS for the winner lookup
 #define FPS_MAXB 64
 
 struct FpsBatch { int off[FPS_MAXB]; int n[FPS_MAXB]; };   // per-cloud row offset and length (ragged batch)
@@ -36,9 +37,11 @@ __device__ __forceinline__ float wave_max_f32(float v)
 // Per lane the candidates k = tid + j*FPS_THREADS share (k mod T) because T divides FPS_THREADS, so
 // inside a lane the upstream tie rule reduces to "first j wins" = strict '>' in ascending j.
 // Points the upstream kernel skips carry temp = -1, which never beats the initial best of -1.
-template <int PPT>
-__global__ void __launch_bounds__(FPS_THREADS) k_fps(const float* __restrict__ xyz, FpsBatch B, int m, int* __restrict__ idx_out)
+template <int THREADS, int PPT, bool LDSPTS>
+__global__ void __launch_bounds__(THREADS) k_fps(const float* __restrict__ xyz, FpsBatch B, int m, int* __restrict__ idx_out)
 {
+    constexpr int NW = THREADS / WAVE;
+    extern __shared__ float spts[];                  // LDSPTS: xyz copy of the cloud (3*n floats)
     const int n = B.n[blockIdx.x];
     const float* P = xyz + (size_t)B.off[blockIdx.x] * 3;
     int* out = idx_out + (size_t)blockIdx.x * m;
@@ -48,7 +51,7 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps(const float* __restrict__ x
     float px[PPT], py[PPT], pz[PPT], temp[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
-        int k = tid + j * FPS_THREADS;
+        int k = tid + j * THREADS;
         bool ok = k < n;
         px[j] = ok ? P[3 * (size_t)k] : 0.f;
         py[j] = ok ? P[3 * (size_t)k + 1] : 0.f;
@@ -57,29 +60,39 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps(const float* __restrict__ x
         ok = ok && !((double)mag <= 1e-3);
         temp[j] = ok ? 1e10f : -1.0f;
     }
-    __shared__ float sbest[2][FPS_WAVES];
-    __shared__ unsigned int stie[2][FPS_WAVES];
-    __shared__ float sxyz[2][FPS_WAVES][3];
+    if (LDSPTS) {
+        for (int i = tid; i < 3 * n; i += THREADS) spts[i] = P[i];
+    }
+    __shared__ float sbest[2][NW];
+    __shared__ unsigned int stie[2][NW];
     float x1 = n > 0 ? P[0] : 0.f, y1 = n > 0 ? P[1] : 0.f, z1 = n > 0 ? P[2] : 0.f;
     if (tid == 0 && m > 0) out[0] = 0;
     const unsigned int tmod = (unsigned int)(tid % T) << 22;
     for (int r = 1; r < m; r++) {
-        float best = -1.0f;
-        int bj = 0;
+        // distances of all PPT points are independent; the arg-max is a balanced tree (max, then the
+        // first j that attains it), so no serial compare/select chain sits on the critical path
+        float d2[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
-            float d = sqdist3(px[j], py[j], pz[j], x1, y1, z1);
-            float d2 = fminf(d, temp[j]);
-            temp[j] = d2;
-            bool gt = d2 > best;
-            best = gt ? d2 : best;
-            bj = gt ? j : bj;
+            d2[j] = fminf(sqdist3(px[j], py[j], pz[j], x1, y1, z1), temp[j]);
+            temp[j] = d2[j];
         }
+        float tr[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) tr[j] = d2[j];
+#pragma unroll
+        for (int w2 = 1; w2 < PPT; w2 <<= 1)
+#pragma unroll
+            for (int j = 0; j + w2 < PPT; j += 2 * w2) tr[j] = fmaxf(tr[j], tr[j + w2]);
+        const float best = tr[0];
+        int bj = PPT;
+#pragma unroll
+        for (int j = PPT - 1; j >= 0; j--) bj = d2[j] == best ? j : bj;   // independent compares, short select chain
         float wmax = wave_max_f32(best);
         const int buf = r & 1;
         if (wmax >= 0.f) {
             // smaller tie key wins among equal distances: (k mod T) << 22 | k
-            unsigned int tk = tmod | (unsigned int)(tid + bj * FPS_THREADS);
+            unsigned int tk = tmod | (unsigned int)(tid + bj * THREADS);
             unsigned long long cand = __ballot(best == wmax);
             int win;
             if (__popcll(cand) == 1) win = __ffsll((long long)cand) - 1;
@@ -88,13 +101,7 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps(const float* __restrict__ x
                 for (int d = WAVE / 2; d > 0; d >>= 1) v = min(v, (unsigned int)__shfl_xor((int)v, d, WAVE));
                 win = __ffsll((long long)__ballot(best == wmax && tk == v)) - 1;
             }
-            if (lane == win) {
-                float bx = px[0], by = py[0], bz = pz[0];
-#pragma unroll
-                for (int j = 1; j < PPT; j++) { bool s = bj == j; bx = s ? px[j] : bx; by = s ? py[j] : by; bz = s ? pz[j] : bz; }
-                sbest[buf][w] = wmax; stie[buf][w] = tk;
-                sxyz[buf][w][0] = bx; sxyz[buf][w][1] = by; sxyz[buf][w][2] = bz;
-            }
+            if (lane == win) { sbest[buf][w] = wmax; stie[buf][w] = tk; }
         } else if (lane == 0) {
             sbest[buf][w] = -1.0f; stie[buf][w] = 0xffffffffu;
         }
@@ -103,20 +110,17 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps(const float* __restrict__ x
         unsigned int gt = 0xffffffffu;
         int gw = 0;
 #pragma unroll
-        for (int i = 0; i < FPS_WAVES; i++) {
+        for (int i = 0; i < NW; i++) {
             float v = sbest[buf][i];
             unsigned int t = stie[buf][i];
             bool better = v > g || (v == g && t < gt);
             g = better ? v : g; gt = better ? t : gt; gw = better ? i : gw;
         }
-        int old;
-        if (g < 0.f) {            // nobody competes: upstream returns index 0
-            old = 0;
-            x1 = P[0]; y1 = P[1]; z1 = P[2];
-        } else {
-            old = (int)(gt & 0x3fffffu);
-            x1 = sxyz[buf][gw][0]; y1 = sxyz[buf][gw][1]; z1 = sxyz[buf][gw][2];
-        }
+        // winner's coordinates: one broadcast read of the cloud (L1/L2 resident), nobody competing -> index 0
+        const int old = g < 0.f ? 0 : (int)(gt & 0x3fffffu);
+        if (LDSPTS) { x1 = spts[3 * old]; y1 = spts[3 * old + 1]; z1 = spts[3 * old + 2]; }
+        else { x1 = P[3 * (size_t)old]; y1 = P[3 * (size_t)old + 1]; z1 = P[3 * (size_t)old + 2]; }
+        (void)gw;
         if (tid == 0) out[r] = old;
     }
 }
@@ -195,11 +199,17 @@ extern "C" int buf_fps_ragged(const float* xyz, const int* lengths_host, int b, 
             nmax = n > nmax ? n : nmax;
         }
         int* out = idx_out + (size_t)c0 * m;
-        if (nmax <= 4 * FPS_THREADS) k_fps<4><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
-        else if (nmax <= 8 * FPS_THREADS) k_fps<8><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
-        else if (nmax <= 16 * FPS_THREADS) k_fps<16><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
-        else if (nmax <= 24 * FPS_THREADS) k_fps<24><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
-        else if (nmax <= 32 * FPS_THREADS) k_fps<32><<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, out);
+        // <= 12800 points: an xyz copy in LDS serves the winner lookup (one broadcast ds_read instead of an L2 round trip)
+        const size_t lds = sizeof(float) * 3 * (size_t)nmax;
+#define FPS_LAUNCH(TH, PPT_, L) \
+    do { if (L) { static bool set_ = false; if (!set_) { BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_fps<TH, PPT_, L>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_LDS_POINTS * 12)); set_ = true; } } \
+         k_fps<TH, PPT_, L><<<nb, TH, (L) ? lds : 0, s>>>(xyz, B, m, out); } while (0)
+        if (nmax <= 4 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 4, true);
+        else if (nmax <= 8 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 8, true);
+        else if (nmax <= 16 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 16, true);
+        else if (nmax <= FPS_LDS_POINTS) FPS_LAUNCH(FPS_THREADS, 25, true);
+        else if (nmax <= 32 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 32, false);
+#undef FPS_LAUNCH
         else {
             BUF_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)row, BUF_EWORKSPACE, "buf_fps: workspace too small");
             k_fps_global<<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, (float*)ws, out);

@@ -364,3 +364,35 @@ def post_refine(T_init, src, tgt, thr=0.10, iters=20):
     check(L.buf_post_refine(_ptr(T_init), _ptr(src.contiguous()), _ptr(tgt.contiguous()), src.shape[0], float(thr),
                             int(iters), _ptr(T), _ptr(info), _stream()), "buf_post_refine")
     return T, info
+
+
+# ----------------------------------------------------------------------------- fused descriptor CNN
+class CylindricalNet:
+    """Device weights of Cylindrical_Net re-laid for csrc/convnet.hip: per layer Wt[(ky*3+kx)*Cin + c][Cout]."""
+
+    def __init__(self, layers, device):
+        """layers: list of 8 (w [Cout,Cin,3,3] np.float32 with BN folded, b [Cout], relu)"""
+        self.wt, self.bias, self.cin, self.cout, self.relu = [], [], [], [], []
+        for w, b, relu in layers:
+            cout, cin = w.shape[0], w.shape[1]
+            wt = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)).reshape(9 * cin, cout), dtype=np.float32)
+            wt = np.concatenate([wt, np.zeros((32, cout), np.float32)])       # spare rows for the pipelined over-read
+            self.wt.append(torch.from_numpy(wt).to(device))
+            self.bias.append(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(device))
+            self.cin.append(cin); self.cout.append(cout); self.relu.append(1 if relu else 0)
+        n = len(layers)
+        self._wp = (C.c_void_p * n)(*[t.data_ptr() for t in self.wt])
+        self._bp = (C.c_void_p * n)(*[t.data_ptr() for t in self.bias])
+        self._ci = (C.c_int * n)(*self.cin)
+        self._co = (C.c_int * n)(*self.cout)
+        self._re = (C.c_int * n)(*self.relu)
+
+    def __call__(self, x):
+        """x f32[P,16,420] (or [P,48,140]) -> f32[P,32,7,20]"""
+        L = _lib.lib()
+        x = x.contiguous()
+        P = x.shape[0]
+        y = torch.empty((P, self.cout[-1], 7, 20), dtype=torch.float32, device=x.device)
+        check(L.buf_cylindrical_net(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(y), _stream()),
+              "buf_cylindrical_net")
+        return y

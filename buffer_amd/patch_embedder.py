@@ -56,6 +56,15 @@ class PatchEmbedder:
             w, b = _fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var'])
             self.convs.append((t(w), t(b)))
         self.last = (t(np.asarray(W[f'{p}.21.weight'], np.float32)), t(np.asarray(W[f'{p}.21.bias'], np.float32)))
+        # fused fp32-MFMA stack (csrc/convnet.hip): layer 0's radial depth folds into the channels (c16*3 + d)
+        layers = []
+        for i, (w, b) in enumerate(self.convs):
+            w = w.cpu().numpy()
+            if i == 0:
+                w = w.reshape(w.shape[0], w.shape[1] * w.shape[2], 3, 3)
+            layers.append((w, b.cpu().numpy(), True))
+        layers.append((self.last[0].cpu().numpy(), self.last[1].cpu().numpy(), False))
+        self.fused = ops.CylindricalNet(layers, device)
         q = 'Desc.pool_layer'
         w0, b0 = _fold_bn(W[f'{q}.0.weight'], W[f'{q}.0.bias'], W[f'{q}.1.running_mean'], W[f'{q}.1.running_var'],
                           W[f'{q}.1.weight'], W[f'{q}.1.bias'])
@@ -84,7 +93,7 @@ class PatchEmbedder:
         f = (x * w).mean((2, 3))
         return F.normalize(f, p=2, dim=1), F.normalize(x, p=2, dim=1)
 
-    def __call__(self, pts, kpts, axis, perm=None, chunk=1024, want_patches=False):
+    def __call__(self, pts, kpts, axis, perm=None, chunk=1024, want_patches=False, fused=True):
         """pts f32[N,3] (2 cm cloud), kpts f32[P,3], axis f32[P,3] -> dict(desc, equi, R, rand_axis[, patches])."""
         cfg = self.cfg
         if perm is None:
@@ -96,10 +105,14 @@ class PatchEmbedder:
                                                  cfg.delta / cfg.rad_n, cfg.voxel_sample, self.mlp_w, self.mlp_b,
                                                  self.mlp_s, self.mlp_t, cfg.azi_n, want_patches)
         descs, equis = [], []
-        for s in range(0, x.shape[0], chunk):
-            y = self.conv_net(x[s:s + chunk].view(-1, 16, cfg.rad_n, cfg.ele_n, cfg.azi_n))
-            f, e = self.head(y)
+        if fused:
+            f, e = self.head(self.fused(x))
             descs.append(f); equis.append(e)
+        else:       # library convolutions (kept for A/B measurement)
+            for s in range(0, x.shape[0], chunk):
+                y = self.conv_net(x[s:s + chunk].view(-1, 16, cfg.rad_n, cfg.ele_n, cfg.azi_n))
+                f, e = self.head(y)
+                descs.append(f); equis.append(e)
         out = dict(desc=torch.cat(descs), equi=torch.cat(equis), R=R, rand_axis=rand_axis, x=x)
         if want_patches:
             out['patches'] = pn

@@ -185,6 +185,16 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A11 (dense)  Cylindrical_Net (models/patchnet.py:15-85) fused: Conv3d(16->64,3^3) + 7 x Conv2d 3x3 with the
+ * reference's circular-azimuth / zero-elevation padding, BN folded, ReLU, on fp32 MFMA; activations stay in LDS.
+ * x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140] (= [np,32,7,20]).
+ * wt_host[l] / bias_host[l]: HOST arrays of 8 DEVICE pointers: weights [9*Cin][Cout] row-major with
+ * k = (ky*3+kx)*Cin + c (layer 0: c = c16*3 + depth) FOLLOWED BY 32 READABLE ROWS (zeros; the software
+ * pipeline over-reads one group), biases [Cout]; widths in cin_host/cout_host. */
+int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
+                            const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A14  hypotheses + all-vs-all scoring (models/BUFFER.py:295-311): ind f32[m] -> R f32[m,3,3], t f32[m,3],
  * inlier_num int32[m], best_out int32[1] (first arg-max), best_mask uint8[m]. */
 int     buf_hypotheses_score(const float* ind, const float* ss_kpts, const float* tt_kpts, const float* ss_R,

@@ -125,3 +125,16 @@ def test_ransac_recovers_planted_pose(dev):
     Tr, _ = ops.post_refine(t(T1), t(src), t(tgt), 0.1, 20)
     Tr = Tr.cpu().numpy()
     assert np.abs(Tr[:3, :3] - R).max() < 5e-3 and np.abs(Tr[:3, 3] - tvec).max() < 5e-3
+
+
+def test_fused_cylindrical_net_vs_library_convs(W, dev):
+    """csrc/convnet.hip (fp32 MFMA, padding folded into addressing) == torch convolutions with explicit padding."""
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    pe = PatchEmbedder(W, dev, THREEDMATCH)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = torch.rand((37, 16, 420), generator=g).to(dev)
+    want = pe.conv_net(x.view(-1, 16, 3, 7, 20))
+    got = pe.fused(x)
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-5 * max(scale, 1.0)
