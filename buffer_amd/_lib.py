@@ -62,6 +62,7 @@ _SIGNATURES = {
     "buf_patch_voxelize": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp]),
     "buf_cylindrical_net": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_cost_volume_net": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "buf_hypotheses_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_ransac_ws_bytes": (_sz, [_i]),
     "buf_ransac_kabsch": (_i, [_vp, _vp, _vp, _i, _i, C.c_uint64, _f, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -9,3 +9,4 @@
 #include "voxelize.hip"
 #include "registration.hip"
 #include "convnet.hip"
+#include "costnet.hip"

@@ -1,0 +1,270 @@
+// A13 -- CostVolume + CostNet (models/BUFFER.py:37-66, models/patchnet.py:88-147) as ONE fused fp32-MFMA kernel.
+//
+// Reference: gather the 20 circular azimuth shifts of the source map, subtract the target map
+// ([M,32,20,5,20] = 256 KB per match), ten unpadded Conv3d (3x3x3, 3x3x3, 7 x (3,1,3), (2,1,2)) with
+// BatchNorm(affine=False)+ReLU, softmax over the 20 logits, expected index.
+//
+// Here one workgroup owns one match.  The two 32x5x20 maps sit in LDS (25.6 KB); the cost volume is never
+// built: layer 0's A operand is formed on the fly as S[c][k][(l-n) mod 20] - T[c][k][l].  Layer 0 is
+// produced one shift-row (n') at a time into an 8 KB LDS row buffer and immediately consumed by layer 1,
+// whose three live output rows are accumulator tiles in registers (sliding window over n'), so the
+// 124 KB layer-0 activation never exists either.  Layers 2..9 ping-pong between two 72 KB LDS buffers.
+// All GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32), weights ([K][Cout], BN folded) stream from L2.
+#include "common.h"
+
+#define CV_THREADS 256
+#define CV_BUF 18432              // floats per ping-pong buffer (128 ch x 144 positions)
+#define CV_LAYERS 10
+
+typedef float cvx4 __attribute__((ext_vector_type(4)));
+
+struct CostNetParams {
+    const float* wt[CV_LAYERS];    // [K][Cout] row-major; K ordering documented per layer below; >= 16 spare rows not required
+    const float* bias[CV_LAYERS];
+};
+
+// ---- generic pipelined tile GEMM: acc[t][u] += sum over `total` groups of 4 k-steps -------------------------
+// Loader::load(a, g): fills a[p][t] (p = k-step inside the group, t = M-tile) for group g.
+// wl = wt + lk*cout + nt0*16 + li (lane's B element of k-step 0); rows advance by 4*cout per k-step.
+template <int MT, int NT, typename Loader>
+__device__ __forceinline__ void cv_gemm(cvx4 (&acc)[MT][NT], Loader& L, const float* __restrict__ wl, int cout, int total)
+{
+    float a0[4][MT], b0[4][NT], a1[4][MT], b1[4][NT];
+#define CV_LOAD(A, B, G)                                                                                  \
+    {                                                                                                     \
+        const int g_ = (G) < total ? (G) : total - 1;                                                     \
+        const float* wn_ = wl + (size_t)g_ * 16 * cout;                                                   \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
+            _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = wn_[(size_t)p * 4 * cout + u * 16];  \
+        }                                                                                                 \
+        L.load(A, g_);                                                                                    \
+    }
+#define CV_MMA(A, B)                                                                                      \
+    _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                       \
+        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
+            _Pragma("unroll") for (int u = 0; u < NT; u++)                                                \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][t], B[p][u], acc[t][u], 0, 0, 0);   \
+        }                                                                                                 \
+    }
+    CV_LOAD(a0, b0, 0)
+#pragma unroll 1
+    for (int g = 0; g < total; g += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        CV_LOAD(a1, b1, g + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        CV_MMA(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < total) {
+            CV_LOAD(a0, b0, g + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            CV_MMA(a1, b1)
+        }
+    }
+#undef CV_LOAD
+#undef CV_MMA
+}
+
+// layer 0: A[m=(k',l')][tap=(dn,dk,dl), c] = S[c][k'+dk][(l'+dl-n'-dn) mod 20] - T[c][k'+dk][l'+dl];  K = tap*32 + c
+struct L0Loader {
+    const float* S; const float* T;
+    int nrow, kp, lp, lk;
+    __device__ __forceinline__ void load(float (&a)[4][1], int g) const
+    {
+        const int tap = g >> 1, cg = g & 1;
+        const int dn = tap / 9, r = tap - dn * 9, dk = r / 3, dl = r - dk * 3;
+        int sh = lp + dl - nrow - dn;                    // in [-19, 19]
+        sh = sh < 0 ? sh + 20 : sh;
+        const int offS = (kp + dk) * 20 + sh, offT = (kp + dk) * 20 + lp + dl;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int c = (cg * 4 + p) * 4 + lk;
+            a[p][0] = S[c * 100 + offS] - T[c * 100 + offT];
+        }
+    }
+};
+
+// layer 1 contribution of one layer-0 row: A[m=l''][tap=(dk,dl), c] = R[c][dk*18 + l''+dl];  K = tap*32 + c (per dn)
+struct L1Loader {
+    const float* R;
+    int li, lk;
+    __device__ __forceinline__ void load(float (&a)[4][1], int g) const
+    {
+        const int tap = g >> 1, cg = g & 1;
+        const int dk = tap / 3, dl = tap - dk * 3;
+        const int off = dk * 18 + li + dl;
+#pragma unroll
+        for (int p = 0; p < 4; p++) a[p][0] = R[((cg * 4 + p) * 4 + lk) * 64 + off];
+    }
+};
+
+// layers 2..9: valid (KW x KW) convolution over an LDS-resident [cin][Win*Win] map;  K = (dn*KW + dl)*cin + c
+template <int MT>
+struct ConvLoader {
+    const float* in;
+    int base[MT];          // n*Win + l of the lane's position in tile t (clamped for padding rows)
+    int Win, plane, gpt, KW, lk;
+    __device__ __forceinline__ void load(float (&a)[4][MT], int g) const
+    {
+        const int tap = g / gpt, cg = g - tap * gpt;
+        const int dn = tap / KW, dl = tap - dn * KW;
+        const int off = dn * Win + dl;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const float* ch = in + ((cg * 4 + p) * 4 + lk) * plane + off;
+#pragma unroll
+            for (int t = 0; t < MT; t++) a[p][t] = ch[base[t]];
+        }
+    }
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wt,
+                                              const float* __restrict__ bias, int cin, int cout, int Win, int KW, int nt0, bool relu)
+{
+    const int lane = threadIdx.x & (WAVE - 1), li = lane & 15, lk = lane >> 4;
+    const int Wout = Win - KW + 1, P = Wout * Wout;
+    ConvLoader<MT> L;
+    L.in = in; L.Win = Win; L.plane = Win * Win; L.gpt = cin >> 4; L.KW = KW; L.lk = lk;
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        int m = t * 16 + li;
+        m = m < P ? m : P - 1;
+        L.base[t] = (m / Wout) * Win + (m % Wout);
+    }
+    cvx4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[t][u] = (cvx4){ 0.f, 0.f, 0.f, 0.f };
+    cv_gemm<MT, NT>(acc, L, wt + (size_t)lk * cout + nt0 * 16 + li, cout, KW * KW * (cin >> 4));
+#pragma unroll
+    for (int u = 0; u < NT; u++) {
+        const int n = (nt0 + u) * 16 + li;
+        const float bv = bias[n];
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = t * 16 + lk * 4 + r;
+                float v = acc[t][u][r] + bv;
+                if (relu) v = fmaxf(v, 0.f);
+                if (m < P) out[n * P + m] = v;
+            }
+    }
+}
+
+__global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict__ s_eq, const float* __restrict__ t_eq, CostNetParams P,
+                                                        float* __restrict__ ind_out)
+{
+    extern __shared__ float lds[];
+    float* bufA = lds;                       // layer-1 output first, then ping-pong
+    float* bufB = lds + CV_BUF;              // phase A: S, T and the layer-0 row buffer live here
+    float* S = bufB;
+    float* T = bufB + 3200;
+    float* R = bufB + 6400;                  // [32][64]
+    const int match = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE, li = lane & 15, lk = lane >> 4;
+    {
+        const cvx4* a = reinterpret_cast<const cvx4*>(s_eq + (size_t)match * 3200);
+        const cvx4* b = reinterpret_cast<const cvx4*>(t_eq + (size_t)match * 3200);
+        for (int i = tid; i < 800; i += CV_THREADS) {
+            reinterpret_cast<cvx4*>(S)[i] = a[i];
+            reinterpret_cast<cvx4*>(T)[i] = b[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase A: layer 0 row by row, layer 1 as a sliding window of three accumulator tiles ------------
+    // layer 0: wave w owns M-tile w (positions 16w..16w+15 of the 54 = 3x18 row positions), both N-tiles.
+    // layer 1: wave w owns N-tile w (16 of the 64 output channels), one M-tile = the 16 l'' of row n''.
+    cvx4 win0 = (cvx4){ 0.f, 0.f, 0.f, 0.f }, win1 = win0, win2 = win0;      // rows n', n'-1, n'-2
+    const float b1v = P.bias[1][w * 16 + li];
+    int m0 = w * 16 + li;
+    m0 = m0 < 54 ? m0 : 53;
+#pragma unroll 1
+    for (int nrow = 0; nrow < 18; nrow++) {
+        {
+            L0Loader L;
+            L.S = S; L.T = T; L.nrow = nrow; L.kp = m0 / 18; L.lp = m0 % 18; L.lk = lk;
+            cvx4 acc[1][2] = { { (cvx4){ 0.f, 0.f, 0.f, 0.f }, (cvx4){ 0.f, 0.f, 0.f, 0.f } } };
+            cv_gemm<1, 2>(acc, L, P.wt[0] + (size_t)lk * 32 + li, 32, 27 * 2);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int n = u * 16 + li;
+                const float bv = P.bias[0][n];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = w * 16 + lk * 4 + r;
+                    if (m < 54) R[n * 64 + m] = fmaxf(acc[0][u][r] + bv, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            L1Loader L;
+            L.R = R; L.li = li; L.lk = lk;
+            const float* w1 = P.wt[1] + (size_t)lk * 64 + w * 16 + li;
+            cvx4 a[1][1];
+            if (nrow <= 15) { a[0][0] = win0; cv_gemm<1, 1>(a, L, w1, 64, 18); win0 = a[0][0]; }                         // dn = 0
+            if (nrow >= 1 && nrow <= 16) { a[0][0] = win1; cv_gemm<1, 1>(a, L, w1 + (size_t)288 * 64, 64, 18); win1 = a[0][0]; }   // dn = 1
+            if (nrow >= 2) { a[0][0] = win2; cv_gemm<1, 1>(a, L, w1 + (size_t)576 * 64, 64, 18); win2 = a[0][0]; }       // dn = 2
+        }
+        if (nrow >= 2) {                     // row n'' = nrow-2 is complete
+            const int n2 = nrow - 2;
+#pragma unroll
+            for (int r = 0; r < 4; r++) bufA[(w * 16 + li) * 256 + n2 * 16 + lk * 4 + r] = fmaxf(win2[r] + b1v, 0.f);
+        }
+        win2 = win1; win1 = win0; win0 = (cvx4){ 0.f, 0.f, 0.f, 0.f };
+        __syncthreads();                     // R is rewritten by the next row
+    }
+
+    // ---- phase B: layers 2..9, ping-pong bufA <-> bufB ---------------------------------------------------
+    cv_conv_layer<13, 1>(bufA, bufB, P.wt[2], P.bias[2], 64, 64, 16, 3, w, true);            // 16x16 -> 14x14
+    __syncthreads();
+    cv_conv_layer<9, 2>(bufB, bufA, P.wt[3], P.bias[3], 64, 128, 14, 3, 2 * w, true);        // -> 12x12
+    __syncthreads();
+    cv_conv_layer<7, 2>(bufA, bufB, P.wt[4], P.bias[4], 128, 128, 12, 3, 2 * w, true);       // -> 10x10
+    __syncthreads();
+    cv_conv_layer<4, 1>(bufB, bufA, P.wt[5], P.bias[5], 128, 64, 10, 3, w, true);            // -> 8x8
+    __syncthreads();
+    cv_conv_layer<3, 1>(bufA, bufB, P.wt[6], P.bias[6], 64, 64, 8, 3, w, true);              // -> 6x6
+    __syncthreads();
+    if (w < 2) cv_conv_layer<1, 1>(bufB, bufA, P.wt[7], P.bias[7], 64, 32, 6, 3, w, true);   // -> 4x4
+    __syncthreads();
+    if (w < 2) cv_conv_layer<1, 1>(bufA, bufB, P.wt[8], P.bias[8], 32, 32, 4, 3, w, true);   // -> 2x2
+    __syncthreads();
+    if (w < 2) cv_conv_layer<1, 1>(bufB, bufA, P.wt[9], P.bias[9], 32, 32, 2, 2, w, false);  // -> 1x1, 20 (+12 zero) logits
+    __syncthreads();
+    if (w == 0) {                            // softmax over the 20 logits, expected index (BUFFER.py:63-65)
+        float v = lane < 20 ? bufA[lane] : -3.4e38f;
+        float mx = v;
+        for (int d = WAVE / 2; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, WAVE));
+        float e = lane < 20 ? expf(v - mx) : 0.f;
+        float se = e, sw = e * (float)lane;
+        for (int d = WAVE / 2; d > 0; d >>= 1) { se += __shfl_xor(se, d, WAVE); sw += __shfl_xor(sw, d, WAVE); }
+        if (lane == 0) ind_out[match] = sw / se;
+    }
+}
+
+// s_eq, t_eq f32[m,32,5,20] (elevation rows 1..5 of the equivariant maps) -> ind f32[m]
+extern "C" int buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
+                                   const float* const* bias_host, float* ind_out, void* stream)
+{
+    BUF_REQUIRE(m >= 0, BUF_EINVAL, "buf_cost_volume_net: m=%d", m);
+    if (m == 0) return BUF_OK;
+    BUF_REQUIRE(s_eq && t_eq && wt_host && bias_host && ind_out, BUF_EINVAL, "buf_cost_volume_net: null argument");
+    CostNetParams P;
+    for (int l = 0; l < CV_LAYERS; l++) {
+        P.wt[l] = wt_host[l]; P.bias[l] = bias_host[l];
+        BUF_REQUIRE(P.wt[l] && P.bias[l], BUF_EINVAL, "buf_cost_volume_net: null weights for layer %d", l);
+    }
+    size_t lds = sizeof(float) * 2 * CV_BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+        BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cost_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    k_cost_net<<<m, CV_THREADS, lds, (hipStream_t)stream>>>(s_eq, t_eq, P, ind_out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

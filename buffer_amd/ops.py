@@ -396,3 +396,33 @@ class CylindricalNet:
         check(L.buf_cylindrical_net(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(y), _stream()),
               "buf_cylindrical_net")
         return y
+
+
+class CostVolumeNet:
+    """Device weights of CostNet re-laid for csrc/costnet.hip: per layer Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout]."""
+
+    def __init__(self, layers, device):
+        """layers: 10 x (w [Cout,Cin,KD,KH,KW] np.float32 with BN folded, b [Cout])"""
+        assert len(layers) == 10
+        self.wt, self.bias = [], []
+        for i, (w, b) in enumerate(layers):
+            cout, cin = w.shape[0], w.shape[1]
+            wt = np.transpose(w, (2, 3, 4, 1, 0)).reshape(-1, cout)
+            b = np.asarray(b, np.float32)
+            if i == 9:                                    # 20 logits -> two full 16-column tiles
+                wt = np.concatenate([wt, np.zeros((wt.shape[0], 32 - cout), np.float32)], 1)
+                b = np.concatenate([b, np.zeros(32 - cout, np.float32)])
+            self.wt.append(torch.from_numpy(np.ascontiguousarray(wt, dtype=np.float32)).to(device))
+            self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
+        self._wp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.wt])
+        self._bp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.bias])
+
+    def __call__(self, s_eq, t_eq):
+        """s_eq, t_eq f32[M,32,5,20] -> f32[M]"""
+        L = _lib.lib()
+        s_eq, t_eq = s_eq.contiguous(), t_eq.contiguous()
+        m = s_eq.shape[0]
+        out = torch.empty((m,), dtype=torch.float32, device=s_eq.device)
+        check(L.buf_cost_volume_net(_ptr(s_eq), _ptr(t_eq), m, self._wp, self._bp, _ptr(out), _stream()),
+              "buf_cost_volume_net")
+        return out

@@ -19,7 +19,8 @@ def mutual_matching(src_des, tgt_des):
 
 
 class CostVolume:
-    """CostVolume + CostNet (BUFFER.py:37-66, models/patchnet.py:88-147): dense, through torch/MIOpen for now."""
+    """CostVolume + CostNet (BUFFER.py:37-66, models/patchnet.py:88-147): fused fp32-MFMA kernel
+    (csrc/costnet.hip); the library-convolution path is kept for A/B measurement."""
 
     def __init__(self, W, device, azi_n=20):
         self.azi_n = azi_n
@@ -30,12 +31,17 @@ class CostVolume:
             w, b = _fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var'])
             self.convs.append((t(w), t(b)))
         self.last = (t(np.asarray(W[f'{p}.27.weight'], np.float32)), t(np.asarray(W[f'{p}.27.bias'], np.float32)))
+        layers = [(w.cpu().numpy(), b.cpu().numpy()) for w, b in self.convs] + \
+                 [(self.last[0].cpu().numpy(), self.last[1].cpu().numpy())]
+        self.fused = ops.CostVolumeNet(layers, device) if azi_n == 20 else None     # csrc/costnet.hip
         cols = np.stack([np.roll(np.arange(azi_n), i) for i in range(azi_n)])     # BUFFER.py:41-46
         self.cols = torch.from_numpy(cols.reshape(-1)).to(device)
         self.bins = torch.arange(0, azi_n, dtype=torch.float32, device=device)
 
-    def __call__(self, d1, d2, chunk=256):
+    def __call__(self, d1, d2, chunk=256, fused=True):
         """d1,d2 f32[M,32,5,20] -> expected azimuth shift f32[M]."""
+        if fused and self.fused is not None and tuple(d1.shape[1:]) == (32, 5, 20):
+            return self.fused(d1, d2)
         outs = []
         n = self.azi_n
         for s in range(0, d1.shape[0], chunk):

@@ -195,6 +195,15 @@ int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_h
                             const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A13  CostVolume + CostNet (models/BUFFER.py:37-66, models/patchnet.py:88-147) fused on fp32 MFMA: the
+ * [m,32,20,5,20] cost tensor is never built.  s_eq,t_eq f32[m,32,5,20] (elevation rows 1..ele_n-2 of the
+ * equivariant maps) -> ind f32[m] (expected azimuth shift).  wt_host/bias_host: HOST arrays of 10 DEVICE
+ * pointers, BN folded; weights [K][Cout] row-major with K = ((dn*KH + dk)*KW + dl)*Cin + c; the last
+ * layer (20 outputs) is zero-padded to 32 columns / biases. */
+int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
+                            const float* const* bias_host, float* ind_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A14  hypotheses + all-vs-all scoring (models/BUFFER.py:295-311): ind f32[m] -> R f32[m,3,3], t f32[m,3],
  * inlier_num int32[m], best_out int32[1] (first arg-max), best_mask uint8[m]. */
 int     buf_hypotheses_score(const float* ind, const float* ss_kpts, const float* tt_kpts, const float* ss_R,

@@ -138,3 +138,20 @@ def test_fused_cylindrical_net_vs_library_convs(W, dev):
     got = pe.fused(x)
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() < 2e-5 * max(scale, 1.0)
+
+
+def test_fused_cost_volume_vs_library_convs(W, dev):
+    """csrc/costnet.hip (cost volume never materialised, sliding-window layer 0/1 fusion) == torch convolutions."""
+    from buffer_amd import registration
+    cv = registration.CostVolume(W, dev)
+    f = load("match_tiny.npz")
+    se = torch.from_numpy(f['src_equi'])[f['s_mids']][:, :, 1:6].contiguous().to(dev)
+    te = torch.from_numpy(f['tgt_equi'])[f['t_mids']][:, :, 1:6].contiguous().to(dev)
+    want = cv(se, te, fused=False)
+    got = cv(se, te, fused=True)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(got.cpu().numpy(), f['ind'], rtol=1e-4, atol=2e-4)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    a = torch.nn.functional.normalize(torch.rand((70, 32, 5, 20), generator=g), dim=1).to(dev)
+    b = torch.nn.functional.normalize(torch.rand((70, 32, 5, 20), generator=g), dim=1).to(dev)
+    np.testing.assert_allclose(cv(a, b, fused=True).cpu().numpy(), cv(a, b, fused=False).cpu().numpy(), rtol=1e-4, atol=2e-4)
