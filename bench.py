@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--keypts', type=int, default=5000, help='keypoints per fragment (BASELINE: ~5k)')
     ap.add_argument('--pairs-per-step', type=int, default=3, help='pairs registered concurrently per GPU and step (one stream each)')
+    ap.add_argument('--mode', choices=['batch', 'threads'], default='batch',
+                    help='batch: the pairs of a step share one set of stacked launches; threads: one stream per pair')
     ap.add_argument('--distinct-pairs', type=int, default=2, help='synthetic pairs generated per rank (cycled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-keypts', type=int, default=256, help='keypoint sample of the CPU baseline leg')
@@ -119,6 +121,8 @@ def main():
 
     def step(i):
         ks = [(i * a.pairs_per_step + j) % len(inputs) for j in range(a.pairs_per_step)]
+        if a.mode == 'batch':
+            return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
         if pool is None:
             return [pipe.register(inputs[k], seed=k) for k in ks]
         return list(pool.map(one_pair, ks))
@@ -171,7 +175,7 @@ def main():
             'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'one 3DMatch-shape fragment pair, full BUFFER inference (BASELINE configs[1])',
-                       'pairs_per_step_per_gpu': a.pairs_per_step, 'keypoints_per_fragment': a.keypts,
+                       'pairs_per_step_per_gpu': a.pairs_per_step, 'step_mode': a.mode, 'keypoints_per_fragment': a.keypts,
                        'fds_points': [int(s['src_fds_pts'].shape[0]) for s in samples[:1]]
                        + [int(s['tgt_fds_pts'].shape[0]) for s in samples[:1]],
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,

@@ -201,13 +201,18 @@ __global__ void __launch_bounds__(WAVE) k_grid_query(const CellGrid* __restrict_
     }
 }
 
-// Fast path: one WAVEFRONT per query.  The 9 cell runs are flattened and scanned 64 candidates at a
-// time (coalesced float4 loads), accepted (d2,index) keys are compacted into a per-wave LDS buffer
-// through ballot + popcount prefix, and every key ranks itself against the others (LDS broadcast
-// reads) -- an exact sort by (d2, index) for rows of up to QW_CAP neighbours.  Longer rows are pushed
-// on a todo list and redone by k_grid_query (lane-per-query, unbounded rows) in the same stream.
+// Fast path: a 16-lane group per query, four queries per wavefront (a neighbourhood holds 10-35 points, so a
+// full wavefront per query would leave most lanes idle in the scan and in the sort).
+//   - lanes 0..8 of a group fetch the 9 cell-run bounds, a width-16 shuffle hands every lane all nine;
+//   - the runs are flattened and scanned 16 candidates at a time per group (float4 loads, contiguous inside a
+//     run), accepted (d2,index) keys are compacted into the group's LDS slice through ballot + popcount prefix;
+//   - every key ranks itself against the group's other keys (LDS reads, broadcast inside the group): an exact
+//     sort by (d2, index) for rows of up to QW_CAP neighbours.  Longer rows are pushed on a todo list and
+//     redone by k_grid_query (lane-per-query, unbounded rows) in the same stream.
 #define QW_WAVES 4
-#define QW_CAP 256
+#define QG 16                       // lanes per query
+#define QPW (WAVE / QG)             // queries per wavefront
+#define QW_CAP 64
 
 __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellGrid* __restrict__ grids, const int* __restrict__ table,
                                                                   const float4* __restrict__ sorted, const float* __restrict__ queries,
@@ -217,84 +222,97 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
                                                                   int* __restrict__ max_count_out, int* __restrict__ todo,
                                                                   int* __restrict__ todo_n)
 {
-    __shared__ unsigned long long keys[QW_WAVES][QW_CAP];
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[QW_WAVES][QPW][QW_CAP + 8];   // + sentinels
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    int t = blockIdx.x * QW_WAVES + w;
-    if (t >= nq) return;
-    int qi = __builtin_amdgcn_readfirstlane(q_order ? q_order[t] : t);
-    int b = find_elem(q_off, nb, qi);
-    const CellGrid g = grids[b];
-    const float qx = queries[3 * (size_t)qi], qy = queries[3 * (size_t)qi + 1], qz = queries[3 * (size_t)qi + 2];
-    double fx = floor(((double)qx - (double)g.mn[0]) * g.inv_cell);
-    double fy = floor(((double)qy - (double)g.mn[1]) * g.inv_cell);
-    double fz = floor(((double)qz - (double)g.mn[2]) * g.inv_cell);
-    fx = fmin(fmax(fx, -2.0), (double)g.dim[0] + 1.0);
-    fy = fmin(fmax(fy, -2.0), (double)g.dim[1] + 1.0);
-    fz = fmin(fmax(fz, -2.0), (double)g.dim[2] + 1.0);
-    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-    // lane j < 9 owns run j; exclusive prefix of the run lengths through a 16-lane scan
+    const int grp = lane / QG, l16 = lane & (QG - 1);
+    const int t = (blockIdx.x * QW_WAVES + w) * QPW + grp;
+    const bool active = t < nq;
+    int qi = 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
     int rs = 0, len = 0;
-    if (lane < 9) {
-        int y = cy + (lane % 3) - 1, z = cz + (lane / 3) - 1;
-        if (x0 <= x1 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
-            int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
-            rs = g0 == 0 ? 0 : table[g0 - 1];
-            len = table[g0 + (x1 - x0)] - rs;
+    if (active) {
+        qi = q_order ? q_order[t] : t;
+        const int b = find_elem(q_off, nb, qi);
+        const CellGrid g = grids[b];
+        qx = queries[3 * (size_t)qi]; qy = queries[3 * (size_t)qi + 1]; qz = queries[3 * (size_t)qi + 2];
+        double fx = floor(((double)qx - (double)g.mn[0]) * g.inv_cell);
+        double fy = floor(((double)qy - (double)g.mn[1]) * g.inv_cell);
+        double fz = floor(((double)qz - (double)g.mn[2]) * g.inv_cell);
+        fx = fmin(fmax(fx, -2.0), (double)g.dim[0] + 1.0);      // far-away queries simply find no cell
+        fy = fmin(fmax(fy, -2.0), (double)g.dim[1] + 1.0);
+        fz = fmin(fmax(fz, -2.0), (double)g.dim[2] + 1.0);
+        const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        if (l16 < 9) {
+            const int y = cy + (l16 % 3) - 1, z = cz + (l16 / 3) - 1;
+            if (x0 <= x1 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+                const int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
+                rs = g0 == 0 ? 0 : table[g0 - 1];
+                len = table[g0 + (x1 - x0)] - rs;
+            }
         }
     }
-    int inc = len;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        int v = __shfl_up(inc, d, WAVE);
-        if (lane >= d) inc += v;
-    }
-    const int total = __shfl(inc, 8, WAVE);
-    int pre[9], st[9];
+    int st[9], pre[9], total = 0;
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-        pre[j] = __shfl(inc - len, j, WAVE);       // exclusive prefix of run j
-        st[j] = __shfl(rs, j, WAVE);
+        st[j] = __shfl(rs, j, QG);
+        pre[j] = total;
+        total += __shfl(len, j, QG);
     }
-    unsigned long long* K = keys[w];
+    unsigned long long* K = keys[w][grp];
+    const unsigned long long gmask_lo = (1ull << l16) - 1ull;
     int m = 0;
-    for (int c0 = 0; c0 < total; c0 += WAVE) {
-        int c = c0 + lane;
+    for (int c0 = 0; __any(c0 < total); c0 += QG) {
+        const int c = c0 + l16;
         bool hit = false;
         unsigned long long key = 0;
         if (c < total) {
             int p = st[0] + c;
 #pragma unroll
             for (int j = 1; j < 9; j++) p = c >= pre[j] ? st[j] + (c - pre[j]) : p;
-            float4 s = sorted[p];
-            float d2 = sqdist3(qx, qy, qz, s.x, s.y, s.z);
+            const float4 s = sorted[p];
+            const float d2 = sqdist3(qx, qy, qz, s.x, s.y, s.z);
             hit = d2 < r2;
             key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(s.w);
         }
-        unsigned long long mask = __ballot(hit);
-        int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long mask = (__ballot(hit) >> (grp * QG)) & 0xffffull;
+        const int pos = m + __popcll(mask & gmask_lo);
         if (hit && pos < QW_CAP) K[pos] = key;
         m += __popcll(mask);
     }
-    if (lane == 0) {
+    if (active && l16 == 0) {
         if (counts_out) counts_out[qi] = m;
         if (max_count_out && m > 0) atomicMax(max_count_out, m);
     }
     if (k_out == 0) return;
-    if (m > QW_CAP) {                    // rare: row longer than the LDS buffer -> lane-per-query fallback
-        if (lane == 0) todo[atomicAdd(todo_n, 1)] = qi;
-        return;
+    if (m > QW_CAP) {                    // rare: row longer than the LDS slice -> lane-per-query fallback
+        if (active && l16 == 0) todo[atomicAdd(todo_n, 1)] = qi;
+        m = 0;
     }
-    __builtin_amdgcn_wave_barrier();
     int* row = nbr_out + (size_t)qi * k_out;
-    for (int s0 = 0; s0 < m; s0 += WAVE) {
-        int i = s0 + lane;
-        unsigned long long mine = i < m ? K[i] : ~0ull;
+    int mmax = m;
+    for (int d = QG; d < WAVE; d <<= 1) mmax = max(mmax, __shfl_xor(mmax, d, WAVE));      // max over the 4 groups
+    mmax = __builtin_amdgcn_readfirstlane(mmax);
+    // the rank loop runs 4 keys per step up to the wavefront's longest row: pad every group's slice with sentinels
+    for (int i = m + l16; i < ((mmax + 3) & ~3); i += QG) K[i] = ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    const ulonglong2* K2 = reinterpret_cast<const ulonglong2*>(K);
+    for (int s0 = 0; s0 < mmax; s0 += QG) {
+        const int i = s0 + l16;
+        const bool have = i < m;
+        const unsigned long long mine = have ? K[i] : 0ull;       // 0 never ranks above anything
         int rank = 0;
-        for (int j = 0; j < m; j++) rank += K[j] < mine ? 1 : 0;
-        if (i < m && rank < k_out) row[rank] = (int)(unsigned int)(mine & 0xffffffffu);
+        for (int j = 0; j < mmax; j += 4) {
+            const ulonglong2 a = K2[j >> 1], b = K2[(j >> 1) + 1];
+            rank += (a.x < mine ? 1 : 0) + (a.y < mine ? 1 : 0) + (b.x < mine ? 1 : 0) + (b.y < mine ? 1 : 0);
+        }
+        if (have && rank < k_out) row[rank] = (int)(unsigned int)(mine & 0xffffffffu);
     }
-    for (int i = m + lane; i < k_out; i += WAVE) row[i] = shadow;
+    // shadow padding (skipped for rows handed to the fallback: it rewrites the whole row)
+    if (active) {
+        const int filled = m;
+        for (int i = filled + l16; i < k_out; i += QG) row[i] = shadow;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -400,7 +418,7 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
     bool timed = timing_begin(s, &span, 12.0 * nq + 12.0 * g->ns + 4.0 * (double)nq * k_out);
     // todo list (query ids of rows longer than QW_CAP) is carved behind the caller's output: it needs at
     // most nq ints; the first k_out==0 launch never produces one.
-    k_grid_query_wave<<<cdiv(nq, QW_WAVES), QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
+    k_grid_query_wave<<<cdiv(nq, QW_WAVES * QPW), QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
                                                                    queries, nq, ex.q_off, g->nb, q_order, r2, k_out, g->ns, nbr_out,
                                                                    counts_out, max_count_out, todo, ex.todo_n);
     if (timed) timing_end(s, &span);

@@ -199,11 +199,14 @@ def three_nn(unknown, known):
     return dist, idx
 
 
-def select_patches(pts, kpts, radius, nsample):
-    """pts f32[N,3] (already permuted), kpts f32[P,3] -> f32[P,nsample,3]."""
+def select_patches(pts, kpts, radius, nsample, out=None):
+    """pts f32[N,3] (already permuted), kpts f32[P,3] -> f32[P,nsample,3] (optionally into a contiguous `out` view)."""
     L = _lib.lib()
     pts, kpts = _dev(pts, torch.float32, "select_patches"), _dev(kpts, torch.float32, "select_patches")
-    out = torch.empty((kpts.shape[0], nsample, 3), dtype=torch.float32, device=pts.device)
+    if out is None:
+        out = torch.empty((kpts.shape[0], nsample, 3), dtype=torch.float32, device=pts.device)
+    elif not out.is_contiguous() or tuple(out.shape) != (kpts.shape[0], nsample, 3):
+        raise _lib.BufferHipError("select_patches: out must be a contiguous [P,nsample,3] tensor")
     check(L.buf_select_patches(_ptr(pts), _ptr(kpts), pts.shape[0], kpts.shape[0], float(radius), int(nsample),
                                _ptr(out), _stream()), "buf_select_patches")
     return out

@@ -93,6 +93,16 @@ class PatchEmbedder:
         f = (x * w).mean((2, 3))
         return F.normalize(f, p=2, dim=1), F.normalize(x, p=2, dim=1)
 
+    def embed_patches(self, patches, axis, want_patches=False):
+        """patches f32[Q,S,3] (any number of clouds stacked), axis f32[Q,3] -> dict(desc, equi, R, rand_axis)."""
+        cfg = self.cfg
+        ax = axis.contiguous() if cfg.dataset in ('3DMatch', '3DLoMatch') else None
+        x, R, rand_axis, pn = ops.patch_voxelize(patches, ax, cfg.des_r, self.centres, self.azi_cs,
+                                                 cfg.delta / cfg.rad_n, cfg.voxel_sample, self.mlp_w, self.mlp_b,
+                                                 self.mlp_s, self.mlp_t, cfg.azi_n, want_patches)
+        f, e = self.head(self.fused(x))
+        return dict(desc=f, equi=e, R=R, rand_axis=rand_axis, x=x, patches=pn)
+
     def __call__(self, pts, kpts, axis, perm=None, chunk=1024, want_patches=False, fused=True):
         """pts f32[N,3] (2 cm cloud), kpts f32[P,3], axis f32[P,3] -> dict(desc, equi, R, rand_axis[, patches])."""
         cfg = self.cfg

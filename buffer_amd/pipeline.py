@@ -76,6 +76,86 @@ class BufferPipeline:
             return pose, out
         return pose
 
+    @torch.no_grad()
+    def register_batch(self, inps, seeds=None, perms=None):
+        """Several pairs through ONE set of launches per stage (the MI355X-native form: the pyramid, the VN
+        blocks, FPS (one workgroup per cloud), voxelisation, both CNNs and the 1-NN search all take the
+        stacked batch; only the per-pair pose recovery loops).  inps: list of upload() dicts ->
+        list of pose f32[4,4] device tensors.  Per pair the arithmetic is that of register()."""
+        cfg, dev = self.cfg, self.device
+        B = len(inps)
+        if self.limits is None:
+            raise RuntimeError('neighbourhood limits not calibrated: call calibrate() or pass limits=')
+        seeds = list(range(B)) if seeds is None else list(seeds)
+        lens = np.concatenate([np.asarray(i['lengths'], np.int32) for i in inps])            # [2B]
+        pts = torch.cat([i['points'] for i in inps]) if B > 1 else inps[0]['points']
+        feats = torch.cat([i['features'] for i in inps]) if B > 1 else inps[0]['features']
+        pyr = pyramid.build_pyramid(pts, lens, self.limits, cfg)
+        pair_rows = lens.reshape(B, 2).sum(1)
+        seg = None
+        if B > 1:
+            ids = torch.repeat_interleave(torch.arange(B, device=dev), torch.from_numpy(pair_rows.astype(np.int64)).to(dev))
+            seg = (ids, torch.from_numpy(pair_rows.astype(np.float32)).to(dev))
+        axis, eps, bottle, skips, _ = self.point.efcnn(pyr, feats, seg)
+        score = self.point.detnet(pyr, bottle, skips, seg)
+        pts0 = pyr['points'][0]
+        cloud_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+        cloud_id = torch.repeat_interleave(torch.arange(2 * B, device=dev), cloud_len)
+        axis_o = orient_axes(axis, pts0)                                                    # BUFFER.py:244-249 (row-wise)
+        keep = torch.nonzero(score[:, 0] > cfg.keypts_th).flatten()                          # :255-259, ascending
+        counts = torch.bincount(cloud_id[keep], minlength=2 * B).cpu().numpy()
+        poses = [None] * B
+        if (counts == 0).any():
+            bad = set(int(c) // 2 for c in np.nonzero(counts == 0)[0])
+            if len(bad) == B:
+                return [torch.eye(4, device=dev) for _ in range(B)]
+            good = [b for b in range(B) if b not in bad]            # rare: redo the healthy pairs one by one
+            for b in good:
+                poses[b] = self.register(inps[b], seed=seeds[b])
+            return [p if p is not None else torch.eye(4, device=dev) for p in poses]
+        cand_p, cand_a = pts0[keep].contiguous(), axis_o[keep].contiguous()
+        fps = ops.furthest_point_sample_ragged(cand_p, counts, cfg.num_keypts).long()       # one workgroup per cloud
+        off = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)).to(dev)
+        gidx = (fps + off[:, None]).reshape(-1)
+        P = cfg.num_keypts
+        kp, ka = cand_p[gidx].contiguous(), cand_a[gidx].contiguous()                        # [2B*P, 3]
+        patches = torch.empty((2 * B * P, cfg.num_points_per_patch, 3), dtype=torch.float32, device=dev)
+        for b in range(B):
+            g = torch.Generator(device=dev)
+            g.manual_seed(seeds[b])
+            for j, raw in enumerate((inps[b]['src_raw'], inps[b]['tgt_raw'])):
+                c = 2 * b + j
+                perm = perms[b][j] if perms is not None else torch.randperm(raw.shape[0], device=dev, generator=g)
+                ops.select_patches(raw[perm].contiguous(), kp[c * P:(c + 1) * P], cfg.des_r, cfg.num_points_per_patch,
+                                   out=patches[c * P:(c + 1) * P])
+        emb = self.desc.embed_patches(patches, ka)
+        desc = emb['desc'].view(B, 2, P, -1)
+        _, s_idx = ops.knn(desc[:, 1].contiguous(), desc[:, 0].contiguous(), 1)            # BUFFER.py:347: ref = tgt
+        _, t_idx = ops.knn(desc[:, 0].contiguous(), desc[:, 1].contiguous(), 1)
+        s_nn, t_nn = s_idx[:, :, 0], t_idx[:, :, 0]
+        mutual = t_nn.gather(1, s_nn) == torch.arange(P, device=dev)[None]
+        mm = torch.nonzero(mutual)                                                          # (pair, s) ascending
+        pair_of, s_mid = mm[:, 0], mm[:, 1]
+        t_mid = s_nn[pair_of, s_mid]
+        m_counts = torch.bincount(pair_of, minlength=B).cpu().numpy()
+        src_row = (2 * pair_of) * P + s_mid
+        tgt_row = (2 * pair_of + 1) * P + t_mid
+        e = cfg.ele_n
+        ind = self.inlier(emb['equi'][src_row][:, :, 1:e - 1].contiguous(), emb['equi'][tgt_row][:, :, 1:e - 1].contiguous())
+        ss_all, tt_all = kp[src_row].contiguous(), kp[tgt_row].contiguous()
+        sR_all, tR_all = emb['R'][src_row].contiguous(), emb['R'][tgt_row].contiguous()
+        lo = 0
+        for b in range(B):
+            m = int(m_counts[b])
+            if m < 3:
+                poses[b] = torch.eye(4, device=dev)
+            else:
+                sl = slice(lo, lo + m)
+                poses[b], _ = registration.recover_pose(ind[sl].contiguous(), ss_all[sl], tt_all[sl], sR_all[sl], tR_all[sl],
+                                                        cfg, seeds[b])
+            lo += m
+        return poses
+
     def _identity(self, out, detail):
         pose = torch.eye(4, device=self.device)       # ThreeDMatch/test.py:242-245: failed pair -> identity
         return (pose, out) if detail else pose

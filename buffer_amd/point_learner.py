@@ -19,19 +19,26 @@ class _ScoreHead:
         self.final = final
 
     @staticmethod
-    def _inorm(h):
-        # InstanceNorm1d over the stacked (src+tgt) point axis, biased variance, eps 1e-5 (:131,133)
-        m = h.mean(0, keepdim=True)
-        v = h.var(0, unbiased=False, keepdim=True)
-        return (h - m) / torch.sqrt(v + 1e-5)
+    def _inorm(h, seg=None):
+        # InstanceNorm1d over the stacked (src+tgt) point axis OF ONE PAIR, biased variance, eps 1e-5 (:131,133).
+        # seg = (pair id per row int64[N], rows per pair f32[B]) when several pairs are stacked in one batch.
+        if seg is None:
+            m = h.mean(0, keepdim=True)
+            v = h.var(0, unbiased=False, keepdim=True)
+            return (h - m) / torch.sqrt(v + 1e-5)
+        ids, cnt = seg
+        m = torch.zeros((cnt.shape[0], h.shape[1]), dtype=h.dtype, device=h.device).index_add_(0, ids, h) / cnt[:, None]
+        d = h - m[ids]
+        v = torch.zeros_like(m).index_add_(0, ids, d * d) / cnt[:, None]
+        return d / torch.sqrt(v[ids] + 1e-5)
 
-    def __call__(self, x):
+    def __call__(self, x, seg=None):
         z = ops.vn_pointwise(self.vn1, x)
         z = ops.vn_pointwise(self.vn2, z)
         z = ops.vn_pointwise(self.lin, z)                          # [N, 9]
         h = ops.vn_std(x, z)                                       # [N, 30]
-        h = self._inorm(h @ self.w[0].t() + self.b[0])
-        h = self._inorm(h @ self.w[1].t() + self.b[1])
+        h = self._inorm(h @ self.w[0].t() + self.b[0], seg)
+        h = self._inorm(h @ self.w[1].t() + self.b[1], seg)
         h = h @ self.w[2].t() + self.b[2]
         return torch.sigmoid(h) if self.final == 'sigmoid' else F.softplus(h)
 
@@ -66,7 +73,7 @@ class PointLearner:
         sc = ops.vn_pointwise(blk['short'], sc)
         return ops.vn_pointwise(blk['unary'], x, residual=sc)
 
-    def efcnn(self, pyr, features):
+    def efcnn(self, pyr, features, seg=None):
         """-> axis f32[N0,3], eps f32[N0,1], bottle f32[N2,120], skips [f32[N0,30], f32[N1,60]]"""
         P, N, PO, UP = pyr['points'], pyr['neighbors'], pyr['pools'], pyr['upsamples']
         x0 = ops.vn_gather_block(self.b0, P[0], P[0], features.contiguous(), N[0], 6, self.scale)
@@ -77,11 +84,11 @@ class PointLearner:
         skips = [x0, x2]
         y = self.ref_dec(x4, skips, UP)
         axis = ops.vn_pointwise(self.fc1, ops.vn_pointwise(self.fc0, y))
-        eps = self.eps_head(y)
+        eps = self.eps_head(y, seg)
         return axis, eps, x4, skips, [x0, x1, x2, x3, x4, y]
 
-    def detnet(self, pyr, bottle, skips):
-        return self.key_head(self.key_dec(bottle, skips, pyr['upsamples']))
+    def detnet(self, pyr, bottle, skips, seg=None):
+        return self.key_head(self.key_dec(bottle, skips, pyr['upsamples']), seg)
 
 
 def orient_axes(axis, pts):

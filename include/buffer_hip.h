@@ -86,7 +86,7 @@ int     buf_grid_build(buf_grid_t* g, const float* supports, int ns, const int* 
 int     buf_grid_query(const buf_grid_t* g, const float* queries, int nq, const int* q_batches_host,
                        const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
                        int* max_count_out, void* todo_ws, void* stream);
-/* todo_ws: int32[nq] scratch (rows longer than 256 neighbours are redone by a second, unbounded pass);
+/* todo_ws: int32[nq] scratch (rows longer than 64 neighbours are redone by a second, unbounded pass);
  * may be null when k_out == 0.
  * Build + query in one call (what batch_query does); ws >= buf_grid_ws_bytes(ns,nb,0) + 4*nq bytes. */
 int     buf_radius_neighbors(const float* queries, int nq, const float* supports, int ns,

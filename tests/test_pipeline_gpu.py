@@ -60,3 +60,18 @@ def test_register_3dmatch_shape_pair(dev):
     rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
     rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
     assert rte < 0.3 and rre < 15.0, (rte, rre)       # the DGR success criterion of ThreeDMatch/test.py:264-270
+
+
+def test_batched_registration_equals_single(tiny, dev):
+    """register_batch (stacked launches) reproduces register() pair by pair."""
+    from buffer_amd.pipeline import BufferPipeline
+    from dataclasses import replace
+    from buffer_amd.config import THREEDMATCH
+    other = synth.make_pair(12, n_raw=40_000, size=(1.0, 1.0, 0.9), n_boxes=3)
+    pipe = BufferPipeline(replace(THREEDMATCH, num_keypts=300), dev)
+    pipe.calibrate([tiny])
+    inps = [pipe.upload(tiny), pipe.upload(other), pipe.upload(tiny)]
+    single = [pipe.register(x, seed=i) for i, x in enumerate(inps)]
+    batch = pipe.register_batch(inps, seeds=[0, 1, 2])
+    for a, b in zip(single, batch):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=2e-4)

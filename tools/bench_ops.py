@@ -1,7 +1,8 @@
 """Micro-benchmarks of single operators on the GPU (development aid)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from buffer_amd import ops, synth
 
 dev = torch.device('cuda:0')
@@ -19,3 +20,52 @@ if which == 'fps':
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t) / 3
             print(f'fps n={n} m={m}: {dt*1e3:.2f} ms  {dt/m*1e6:.2f} us/round')
+if which == 'cyl':
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    from buffer_amd.weights import load_weights
+    pe = PatchEmbedder(load_weights('3dmatch'), dev, THREEDMATCH)
+    x = torch.rand((5000, 16, 420), device=dev)
+    want = pe.conv_net(x[:64].view(-1, 16, 3, 7, 20))
+    got = pe.fused(x[:64])
+    print('max err', (got - want).abs().max().item())
+    for _ in range(2):
+        pe.fused(x)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        pe.fused(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+    print(f'cyl_net 5000 patches: {dt*1e3:.2f} ms  {5000*0.1187/dt/1e3:.1f} TFLOP/s  ({5000*0.1187/dt/1e3/157.3*100:.0f}% of fp32 MFMA peak)')
+if which == 'radius':
+    npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    samples = [synth.make_pair(3000 + i) for i in range(min(npairs, 4))]
+    pts, lens = [], []
+    for i in range(npairs):
+        s = samples[i % len(samples)]
+        pts += [s['src_sds_pts'][:, :3], s['tgt_sds_pts'][:, :3]]
+        lens += [len(s['src_sds_pts']), len(s['tgt_sds_pts'])]
+    P = torch.from_numpy(np.concatenate(pts).astype(np.float32)).to(dev)
+    lens = np.array(lens, np.int32)
+    K = 17
+    grid = ops.CellGrid(P, lens, 0.07)
+    order = grid.order
+    out = grid.query(P, lens, K, q_order=order)
+    torch.cuda.synchronize()
+    for use_order in (True, False):
+        t = time.perf_counter()
+        for _ in range(iters):
+            grid.query(P, lens, K, q_order=order if use_order else None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / iters
+        nq = P.shape[0]
+        by = 12 * nq * 2 + 4 * nq * K
+        print(f'radius self-query pairs={npairs} nq={nq} K={K} order={use_order}: {dt*1e6:.1f} us/launch (incl. host), '
+              f'{by/dt/1e9:.1f} GB/s algorithmic')
+    t = time.perf_counter()
+    for _ in range(iters):
+        g2 = ops.CellGrid(P, lens, 0.07)
+    torch.cuda.synchronize()
+    print(f'grid build: {(time.perf_counter()-t)/iters*1e6:.1f} us')
