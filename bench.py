@@ -6,8 +6,10 @@ registration pairs/sec; workload = configs[1], one 3DMatch-shape fragment pair, 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step registers `--pairs-per-step` device-resident synthetic pairs on every rank (pair-sharded, no
-data-path collective; one all_gather of the poses at the end of the timed region).  Rank 0 prints
+A step registers `--pairs-per-step` device-resident synthetic pairs on every rank through ONE set of
+stacked launches per stage (`--mode batch`; `--mode threads` runs them on separate streams instead).
+Pairs are sharded over the ranks with no data-path collective; one all_gather of the poses ends the
+timed region.  Rank 0 prints
 one JSON line (contract in the task description): whole-job pairs/s, the roofline of the dominant
 hand-written kernel (k_grid_query, timed with HIP events on its launch stream inside the library)
 and, at N=1, the CPU baseline (reference cpp_wrappers cores when oracle/_ref is built, else the
@@ -33,13 +35,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--keypts', type=int, default=5000, help='keypoints per fragment (BASELINE: ~5k)')
-    ap.add_argument('--pairs-per-step', type=int, default=3, help='pairs registered concurrently per GPU and step (one stream each)')
+    ap.add_argument('--pairs-per-step', type=int, default=8, help='pairs registered concurrently per GPU and step (one stream each)')
     ap.add_argument('--mode', choices=['batch', 'threads'], default='batch',
                     help='batch: the pairs of a step share one set of stacked launches; threads: one stream per pair')
-    ap.add_argument('--distinct-pairs', type=int, default=2, help='synthetic pairs generated per rank (cycled)')
+    ap.add_argument('--distinct-pairs', type=int, default=4, help='synthetic pairs generated per rank (cycled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-keypts', type=int, default=256, help='keypoint sample of the CPU baseline leg')
     return ap.parse_args()
@@ -80,12 +82,18 @@ def main():
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
+    local = local % torch.cuda.device_count()      # (only matters for the single-GPU gloo smoke run below)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
+    backend = os.environ.get('BENCH_BACKEND', 'nccl')   # 'gloo' = code-path smoke test of the N>1 logic on one GPU
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == 'nccl' else torch.device('cpu')
 
     from buffer_amd import _lib, synth
     from buffer_amd.config import THREEDMATCH
@@ -137,7 +145,7 @@ def main():
     all_poses = []
     for i in range(a.steps):
         all_poses += step(i)
-    mine = torch.stack(all_poses)
+    mine = torch.stack(all_poses).to(cdev)
     if dist:                                           # the path's one exchange: poses of every shard
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -149,7 +157,7 @@ def main():
     ms, by = C.c_double(0), C.c_double(0)
     launches = L.buf_timing_collect(C.byref(ms), C.byref(by))
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -168,7 +176,9 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('k_grid_query_hbm_bytes_per_launch')
+            per_pair = json.load(open(tpath)).get('k_grid_query_hbm_bytes_per_launch_per_pair')
+            # measured offline with rocprofv3 --pmc (profiles/traffic.json); a launch covers every pair of the step
+            traffic = per_pair * (a.pairs_per_step if a.mode == 'batch' else 1) if per_pair else None
         out = {
             'metric': 'registration pairs/sec', 'value': pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
