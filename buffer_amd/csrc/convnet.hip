@@ -16,12 +16,13 @@
 #include "common.h"
 
 #define CN_POS 140            // 7 elevation x 20 azimuth
+#define CN_STR 144            // LDS channel stride: 144 mod 32 = 16 keeps the 4 channel groups of a fragment on disjoint banks
 #define CN_MT 9               // ceil(140 / 16)
 #define CN_MAXC 128
 #define CN_LAYERS 8
 #define CN_THREADS 256
 #define CN_PF 4               // k-steps per software-pipeline group
-#define CN_BUF (CN_MAXC * CN_POS)                 // one activation buffer
+#define CN_BUF (CN_MAXC * CN_STR)                 // one activation buffer
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
             int y = ey[t] + ky, x = ax[t] + kx;
             x = x < 0 ? x + 20 : (x >= 20 ? x - 20 : x);
             ok[t] = y >= 0 && y < 7 && t < mt_cnt;
-            ia[t] = in + lk * CN_POS + (ok[t] ? y * 20 + x : 0);
+            ia[t] = in + lk * CN_STR + (ok[t] ? y * 20 + x : 0);
         }
         const float* ws = wrow + (size_t)s * cin * cout;
         // ping-pong register sets; sched_barriers pin "issue loads of the next group" in front of
@@ -78,7 +79,7 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
             _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = wn_[(size_t)p * 4 * cout + u * 16]; \
         }                                                                                              \
         _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
-            _Pragma("unroll") for (int t = 0; t < MT; t++) A[p][t] = ia[t][(g_ * CN_PF + p) * 4 * CN_POS]; \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) A[p][t] = ia[t][(g_ * CN_PF + p) * 4 * CN_STR]; \
         }                                                                                              \
     }
 #define CYL_MMA(A, B)                                                                                  \
@@ -118,7 +119,7 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
                 f32x4 v = acc[t][u];
                 v.x += bv; v.y += bv; v.z += bv; v.w += bv;
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                float* dst = out_glb ? out_glb + (size_t)n * CN_POS + m : out_lds + n * CN_POS + m;
+                float* dst = out_glb ? out_glb + (size_t)n * CN_POS + m : out_lds + n * CN_STR + m;
                 *reinterpret_cast<f32x4*>(dst) = v;
             }
         }
@@ -127,15 +128,17 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
 
 __global__ void __launch_bounds__(CN_THREADS) k_cyl_net(const float* __restrict__ x, CylNetParams P, float* __restrict__ y)
 {
-    extern __shared__ float lds[];                   // 2 x [128][140] fp32
+    extern __shared__ float lds[];                   // 2 x [128][144] fp32 (140 positions + bank padding)
     float* buf0 = lds;
     float* buf1 = lds + CN_BUF;
     const int patch = blockIdx.x;
     const int w = threadIdx.x / WAVE;
     {   // input: [16,3,7,20] = 48 folded channels x 140 positions, contiguous
         const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)patch * P.cin[0] * CN_POS);
-        f32x4* dst = reinterpret_cast<f32x4*>(buf0);
-        for (int i = threadIdx.x; i < P.cin[0] * CN_POS / 4; i += CN_THREADS) dst[i] = src[i];
+        for (int i = threadIdx.x; i < P.cin[0] * (CN_POS / 4); i += CN_THREADS) {
+            const int c = i / (CN_POS / 4), r = i - c * (CN_POS / 4);
+            reinterpret_cast<f32x4*>(buf0 + c * CN_STR)[r] = src[i];
+        }
     }
     __syncthreads();
     float* in = buf0;
