@@ -1,0 +1,53 @@
+"""BASELINE config #4: KITTI-shape LiDAR pair (ring pattern, 0.05 / 0.30 m voxels, KITTI constants and weights):
+device pyramid vs oracle collate, full registration vs the CPU oracle pipeline."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+import torch
+
+from buffer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kitti_pair():
+    return synth.make_kitti_pair(5)
+
+
+def test_kitti_pyramid_equals_oracle(kitti_pair, oracle, dev):
+    from buffer_amd import pyramid
+    from buffer_amd.config import KITTI as cfg
+    from oracle import torch_ref as T
+    limits = T.calibrate_limits([kitti_pair], cfg.voxel_size_0, cfg.conv_radius)
+    assert np.array_equal(limits, pyramid.calibrate_limits([kitti_pair], cfg, dev))
+    want = T.collate(kitti_pair, limits, cfg.voxel_size_0, cfg.conv_radius)
+    pts, lens, *_ = pyramid.stack_sample(kitti_pair, dev)
+    got = pyramid.build_pyramid(pts, lens, limits, cfg)
+    for l in range(3):
+        assert np.array_equal(got['points'][l].cpu().numpy().view(np.uint32), want['points'][l].numpy().view(np.uint32))
+        assert np.array_equal(got['neighbors'][l].cpu().numpy(), want['neighbors'][l].numpy())
+        if l < 2:
+            assert np.array_equal(got['pools'][l].cpu().numpy(), want['pools'][l].numpy())
+            assert np.array_equal(got['upsamples'][l].cpu().numpy(), want['upsamples'][l].numpy())
+
+
+def test_kitti_registration_matches_cpu_oracle(kitti_pair, dev):
+    from buffer_amd.config import KITTI
+    from buffer_amd.pipeline import BufferPipeline
+    from buffer_amd.weights import load_weights
+    from oracle import pipeline_ref
+    cfg = replace(KITTI, num_keypts=256)
+    pipe = BufferPipeline(cfg, dev)
+    limits = pipe.calibrate([kitti_pair])
+    rng = np.random.default_rng(0)
+    perms = [rng.permutation(len(kitti_pair['src_fds_pts'])), rng.permutation(len(kitti_pair['tgt_fds_pts']))]
+    pose, d = pipe.register(pipe.upload(kitti_pair), seed=0, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
+    W = {k: torch.from_numpy(v) for k, v in load_weights(cfg.weights).items()}
+    want, wd = pipeline_ref.register_pair(kitti_pair, W, limits, cfg, 0, perms)
+    for i in range(2):
+        assert np.array_equal(d['kpts'][i].cpu().numpy(), wd['kpts'][i].numpy())
+    assert np.array_equal(d['s_mids'].cpu().numpy(), wd['s_mids'])
+    np.testing.assert_allclose(d['ind'].cpu().numpy(), wd['ind'].numpy(), rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(pose.cpu().numpy(), want, rtol=0, atol=2e-3)
