@@ -10,7 +10,7 @@
 //     k = s*Cin + c with s = ky*3 + kx,  A[m][k] = in[c][ele+ky-1][(azi+kx-1) mod 20]  (0 outside 0 <= ele < 7)
 // on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain).  Activations never leave LDS
 // (two 128x140 fp32 buffers, 140 KB); A fragments are gathered from LDS with the padding folded into
-// the address (one ds_read_b32 + one select per fragment), B fragments (BN-folded weights, [K][Cout]
+// the address (one ds_read_b32 per fragment; invalid taps read a zero column), B fragments (BN-folded weights, [K][Cout]
 // row-major, 1.7 MB for the whole net, L2-resident) stream from global memory through a register ring.
 // HBM traffic per patch: 26.9 KB in, 17.9 KB out.
 #include "common.h"
@@ -25,6 +25,25 @@
 #define CN_BUF (CN_MAXC * CN_STR)                 // one activation buffer
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// timing experiments only (-DCYL_EXP=1: no LDS fragment loads, 2: no weight loads, 3: neither); default = real loads
+#ifndef CYL_EXP
+#define CYL_EXP 0
+#endif
+#if CYL_EXP & 1
+#define CYL_EXP_A(x) (1.0f + (float)(g_ + p + t))
+#else
+#define CYL_EXP_A(x) (x)
+#endif
+#if CYL_EXP & 4
+#define CYL_EXP_OK(x) true
+#else
+#define CYL_EXP_OK(x) (x)
+#endif
+#if CYL_EXP & 2
+#define CYL_EXP_B(x) (0.5f + (float)(g_ + p + u))
+#else
+#define CYL_EXP_B(x) (x)
+#endif
 
 struct CylNetParams {
     const float* wt[CN_LAYERS];     // [9*Cin][Cout] row-major, BN folded
@@ -65,7 +84,7 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
             int y = ey[t] + ky, x = ax[t] + kx;
             x = x < 0 ? x + 20 : (x >= 20 ? x - 20 : x);
             ok[t] = y >= 0 && y < 7 && t < mt_cnt;
-            ia[t] = in + lk * CN_STR + (ok[t] ? y * 20 + x : 0);
+            ia[t] = in + lk * CN_STR + (ok[t] ? y * 20 + x : CN_POS);   // pad column 140 of every channel row holds 0
         }
         const float* ws = wrow + (size_t)s * cin * cout;
         // ping-pong register sets; sched_barriers pin "issue loads of the next group" in front of
@@ -76,16 +95,16 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         const int g_ = (G) < groups ? (G) : groups - 1;   /* prefetch past the tap re-reads its last group */ \
         const float* wn_ = ws + (size_t)g_ * CN_PF * 4 * cout;                                         \
         _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
-            _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = wn_[(size_t)p * 4 * cout + u * 16]; \
+            _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = CYL_EXP_B(wn_[(size_t)p * 4 * cout + u * 16]); \
         }                                                                                              \
         _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
-            _Pragma("unroll") for (int t = 0; t < MT; t++) A[p][t] = ia[t][(g_ * CN_PF + p) * 4 * CN_STR]; \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) A[p][t] = CYL_EXP_A(ia[t][(g_ * CN_PF + p) * 4 * CN_STR]); \
         }                                                                                              \
     }
 #define CYL_MMA(A, B)                                                                                  \
     _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                                \
         _Pragma("unroll") for (int t = 0; t < MT; t++) {                                               \
-            const float av_ = ok[t] ? A[p][t] : 0.f;                                                   \
+            const float av_ = A[p][t];      /* zero padding comes from the address, no select here */ \
             _Pragma("unroll") for (int u = 0; u < NT; u++)                                             \
                 acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, B[p][u], acc[t][u], 0, 0, 0);    \
         }                                                                                              \
@@ -139,6 +158,12 @@ __global__ void __launch_bounds__(CN_THREADS) k_cyl_net(const float* __restrict_
             const int c = i / (CN_POS / 4), r = i - c * (CN_POS / 4);
             reinterpret_cast<f32x4*>(buf0 + c * CN_STR)[r] = src[i];
         }
+    }
+    // columns 140..143 of every channel row (the bank padding) stay zero for the whole kernel: out-of-range
+    // elevation taps and unused tile rows read column 140 instead of being masked after the load
+    if (threadIdx.x < CN_MAXC) {
+        *reinterpret_cast<f32x4*>(buf0 + threadIdx.x * CN_STR + CN_POS) = (f32x4){ 0.f, 0.f, 0.f, 0.f };
+        *reinterpret_cast<f32x4*>(buf1 + threadIdx.x * CN_STR + CN_POS) = (f32x4){ 0.f, 0.f, 0.f, 0.f };
     }
     __syncthreads();
     float* in = buf0;
