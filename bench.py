@@ -38,9 +38,12 @@ def parse():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--keypts', type=int, default=5000, help='keypoints per fragment (BASELINE: ~5k)')
-    ap.add_argument('--pairs-per-step', type=int, default=8, help='pairs registered concurrently per GPU and step (one stream each)')
+    ap.add_argument('--pairs-per-step', type=int, default=16, help='pairs registered per GPU and step')
     ap.add_argument('--mode', choices=['batch', 'threads'], default='batch',
                     help='batch: the pairs of a step share one set of stacked launches; threads: one stream per pair')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='batch mode: the pairs of a step are split into this many stacked batches, one host thread + HIP '
+                         'stream each, so that the latency-bound FPS of one batch overlaps the CNN kernels of another')
     ap.add_argument('--distinct-pairs', type=int, default=4, help='synthetic pairs generated per rank (cycled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-keypts', type=int, default=256, help='keypoint sample of the CPU baseline leg')
@@ -111,26 +114,40 @@ def main():
     # one pair (FPS occupies 2 CUs for milliseconds) overlap the chip-filling stages of another
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    nconc = max(1, a.pairs_per_step)
+    nconc = max(1, a.pairs_per_step) if a.mode == 'threads' else max(1, min(a.streams, a.pairs_per_step))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nconc)]
     tls = threading.local()
     slot_lock = threading.Lock()
     free_slots = list(range(nconc))
 
-    def one_pair(k):
+    def _bind():
         if not hasattr(tls, 'slot'):
             with slot_lock:
                 tls.slot = free_slots.pop()
             torch.cuda.set_device(local)
-        with torch.cuda.stream(streams[tls.slot]):
+        return streams[tls.slot]
+
+    def one_pair(k):
+        with torch.cuda.stream(_bind()):
             return pipe.register(inputs[k], seed=k)
+
+    def one_batch(ks):
+        with torch.cuda.stream(_bind()):
+            return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
 
     pool = ThreadPoolExecutor(max_workers=nconc) if nconc > 1 else None
 
     def step(i):
         ks = [(i * a.pairs_per_step + j) % len(inputs) for j in range(a.pairs_per_step)]
         if a.mode == 'batch':
-            return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
+            if pool is None:
+                return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
+            parts = [ks[j::nconc] for j in range(nconc)]
+            outs = list(pool.map(one_batch, parts))
+            poses = [None] * len(ks)
+            for j, o in enumerate(outs):
+                poses[j::nconc] = o
+            return poses
         if pool is None:
             return [pipe.register(inputs[k], seed=k) for k in ks]
         return list(pool.map(one_pair, ks))
@@ -178,14 +195,14 @@ def main():
         if os.path.exists(tpath):
             per_pair = json.load(open(tpath)).get('k_grid_query_hbm_bytes_per_launch_per_pair')
             # measured offline with rocprofv3 --pmc (profiles/traffic.json); a launch covers every pair of the step
-            traffic = per_pair * (a.pairs_per_step if a.mode == 'batch' else 1) if per_pair else None
+            traffic = per_pair * (a.pairs_per_step / nconc if a.mode == 'batch' else 1) if per_pair else None
         out = {
             'metric': 'registration pairs/sec', 'value': pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'one 3DMatch-shape fragment pair, full BUFFER inference (BASELINE configs[1])',
-                       'pairs_per_step_per_gpu': a.pairs_per_step, 'step_mode': a.mode, 'keypoints_per_fragment': a.keypts,
+                       'pairs_per_step_per_gpu': a.pairs_per_step, 'step_mode': a.mode, 'streams': nconc, 'keypoints_per_fragment': a.keypts,
                        'fds_points': [int(s['src_fds_pts'].shape[0]) for s in samples[:1]]
                        + [int(s['tgt_fds_pts'].shape[0]) for s in samples[:1]],
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,

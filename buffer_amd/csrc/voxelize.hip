@@ -4,14 +4,15 @@
 // Reference: axis_align -> normalize -> sphere_query (420 ball queries of 10 samples per patch,
 // materialising [P,420,10,3]) -> var_to_invar -> Conv2d1x1(3->16)+BN+ReLU -> max over the 10 samples.
 // Here: one workgroup per patch; the aligned, normalised 512-point patch sits in LDS (8 KB); one lane
-// per cylindrical voxel centre scans it in index order (LDS broadcast reads), and every accepted
-// sample goes straight through the azimuth de-rotation, the 3->16 MLP, BN, ReLU and the running max.
+// per cylindrical voxel centre scans it in index order (LDS broadcast reads) and notes its first 10 hits;
+// then all centre lanes run the azimuth de-rotation, the 3->16 MLP, BN, ReLU and the running max slot by slot.
 // HBM traffic: 6 KB in, 26.9 KB out per patch; [P,420,10,3] never exists.
 #include "common.h"
 
 #define VOX_THREADS 448     // 7 wavefronts >= 420 centres
 #define VOX_MAXPTS 1024
 #define VOX_CH 16
+#define VOX_MAXS 16           // max samples per voxel kept in the hit list
 
 struct VoxMlp {
     float w[VOX_CH][3];     // Desc.pnt_layer.0.weight
@@ -83,27 +84,43 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
         int az = c % azi_n;                                      // ordering rad -> ele -> azi (utils/common.py:422-428)
         ca = azi_cs[2 * az]; sa = azi_cs[2 * az + 1];            // cos/sin of -az * 2pi/azi_n (:485-491)
     }
+    // Phase 1: every centre lane records the indices of its first `nsample` hits (index order).  Only a tiny
+    // store sits in the divergent branch: running the 16-channel MLP right here would execute it once per point
+    // for one or two active lanes (a point is inside ~8 of the 420 balls).
+    __shared__ unsigned short hits[VOX_MAXS][VOX_THREADS];
+    int cnt = 0, nreal = 0;                                      // accepted samples / samples kept in the list
+    bool zero_slot = false;
+    // branch-light scan, 8 points per step so that the LDS reads of a step are in flight together
+    for (int k0 = 0; k0 < npts; k0 += 8) {
+        float4 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) q[j] = pts[min(k0 + j, npts - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = k0 + j;
+            const bool hit = active && k < npts && cnt < nsample && sqdist3(cx, cy, cz, q[j].x, q[j].y, q[j].z) < voxel_r2;
+            const bool keep = hit && k != 0;                     // utils/common.py:447-449: a hit on point 0 is zeroed
+            if (keep) hits[nreal][tid] = (unsigned short)k;
+            nreal += keep ? 1 : 0;
+            cnt += hit ? 1 : 0;
+            zero_slot = zero_slot || (hit && k == 0);
+        }
+        if ((k0 & 31) == 24 && !__any(active && cnt < nsample)) break;
+    }
+    // Phase 2: slot by slot, all centre lanes evaluate de-rotation -> 3->16 MLP -> BN -> ReLU -> running max together.
     float acc[VOX_CH];
 #pragma unroll
     for (int ch = 0; ch < VOX_CH; ch++) acc[ch] = -3.4e38f;
-    int cnt = 0;
-    bool zero_slot = false;
-    for (int k = 0; k < npts; k++) {
-        float4 q = pts[k];
-        bool hit = active && cnt < nsample && sqdist3(cx, cy, cz, q.x, q.y, q.z) < voxel_r2;
-        if (hit) {
-            cnt++;
-            if (k == 0) zero_slot = true;                        // utils/common.py:447-449
-            else {
-                float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz = q.z;
+    for (int sidx = 0; __any(sidx < nreal); sidx++) {
+        if (sidx < nreal) {
+            float4 q = pts[hits[sidx][tid]];
+            float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz = q.z;
 #pragma unroll
-                for (int ch = 0; ch < VOX_CH; ch++) {
-                    float h = M.w[ch][0] * nx + M.w[ch][1] * ny + M.w[ch][2] * nz + M.b[ch];
-                    acc[ch] = fmaxf(acc[ch], fmaxf(h * M.s[ch] + M.t[ch], 0.f));
-                }
+            for (int ch = 0; ch < VOX_CH; ch++) {
+                float h = M.w[ch][0] * nx + M.w[ch][1] * ny + M.w[ch][2] * nz + M.b[ch];
+                acc[ch] = fmaxf(acc[ch], fmaxf(h * M.s[ch] + M.t[ch], 0.f));
             }
         }
-        if (!__any(active && cnt < nsample)) break;
     }
     if (active) {
         bool padded = cnt < nsample || zero_slot;                // zeroed slots go through the MLP as the origin
@@ -123,6 +140,7 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
                                   void* stream)
 {
     BUF_REQUIRE(npatch >= 0 && npts > 0 && npts <= VOX_MAXPTS, BUF_EINVAL, "buf_patch_voxelize: npts=%d (max %d)", npts, VOX_MAXPTS);
+    BUF_REQUIRE(nsample <= VOX_MAXS, BUF_EINVAL, "buf_patch_voxelize: nsample=%d (max %d)", nsample, VOX_MAXS);
     BUF_REQUIRE(ncentres > 0 && ncentres <= VOX_THREADS && azi_n > 0 && nsample > 0, BUF_EINVAL,
                 "buf_patch_voxelize: ncentres=%d (max %d)", ncentres, VOX_THREADS);
     if (npatch == 0) return BUF_OK;

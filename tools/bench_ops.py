@@ -69,3 +69,28 @@ if which == 'radius':
         g2 = ops.CellGrid(P, lens, 0.07)
     torch.cuda.synchronize()
     print(f'grid build: {(time.perf_counter()-t)/iters*1e6:.1f} us')
+if which == 'vox':
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    from buffer_amd.weights import load_weights
+    cfg = THREEDMATCH
+    pe = PatchEmbedder(load_weights('3dmatch'), dev, cfg)
+    s = synth.make_pair(3)
+    raw = torch.from_numpy(s['src_fds_pts'].astype(np.float32)).to(dev)
+    kp = raw[torch.randperm(raw.shape[0], device=dev)[:5000]].contiguous()
+    ax = torch.nn.functional.normalize(torch.randn(5000, 3, device=dev), dim=1)
+    patches = ops.select_patches(raw, kp, cfg.des_r, 512)
+    def run():
+        return ops.patch_voxelize(patches, ax, cfg.des_r, pe.centres, pe.azi_cs, cfg.delta / cfg.rad_n, cfg.voxel_sample,
+                                  pe.mlp_w, pe.mlp_b, pe.mlp_s, pe.mlp_t, cfg.azi_n, False)
+    run(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
+    print(f'voxelize 5000 patches: {(time.perf_counter()-t)/10*1e3:.3f} ms')
+    t = time.perf_counter()
+    for _ in range(10):
+        ops.select_patches(raw, kp, cfg.des_r, 512)
+    torch.cuda.synchronize()
+    print(f'select_patches 5000 kpts x {raw.shape[0]} pts: {(time.perf_counter()-t)/10*1e3:.3f} ms')
