@@ -64,24 +64,33 @@ __device__ __forceinline__ void cv_gemm(cvx4 (&acc)[MT][NT], Loader& L, const fl
 #undef CV_MMA
 }
 
-// layer 0: A[m=(k',l')][tap=(dn,dk,dl), c] = S[c][k'+dk][(l'+dl-n'-dn) mod 20] - T[c][k'+dk][l'+dl];  K = tap*32 + c
+// layer 0: A[m=(k',l')][tap=(dn,dk,dl), c] = cost[c][n'+dn][k'+dk][l'+dl];  K = tap*32 + c.
+// The three shift rows n', n'+1, n'+2 of the cost volume (cost[c][n][k][l] = S[c][k][(l-n) mod 20] - T[c][k][l])
+// live in a 3-slot ring D[c][n mod 3][5][20], so a fragment is ONE LDS read (no arithmetic between load and MFMA).
 struct L0Loader {
-    const float* S; const float* T;
-    int nrow, kp, lp, lk;
+    const float* D;
+    int nrow, base, lk;                                  // base = k'*20 + l'
     __device__ __forceinline__ void load(float (&a)[4][1], int g) const
     {
         const int tap = g >> 1, cg = g & 1;
         const int dn = tap / 9, r = tap - dn * 9, dk = r / 3, dl = r - dk * 3;
-        int sh = lp + dl - nrow - dn;                    // in [-19, 19]
-        sh = sh < 0 ? sh + 20 : sh;
-        const int offS = (kp + dk) * 20 + sh, offT = (kp + dk) * 20 + lp + dl;
+        const int off = ((nrow + dn) % 3) * 100 + dk * 20 + dl + base;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int c = (cg * 4 + p) * 4 + lk;
-            a[p][0] = S[c * 100 + offS] - T[c * 100 + offT];
-        }
+        for (int p = 0; p < 4; p++) a[p][0] = D[((cg * 4 + p) * 4 + lk) * 300 + off];
     }
 };
+
+// one shift row of the cost volume into its ring slot (all threads of the workgroup)
+__device__ __forceinline__ void cost_row(float* __restrict__ D, const float* __restrict__ S, const float* __restrict__ T, int n)
+{
+    const int slot = n % 3;
+    for (int i = threadIdx.x; i < 3200; i += CV_THREADS) {
+        const int c = i / 100, r = i - c * 100, k = r / 20, l = r - k * 20;
+        int sh = l - n;
+        sh = sh < 0 ? sh + 20 : sh;
+        D[c * 300 + slot * 100 + r] = S[c * 100 + k * 20 + sh] - T[c * 100 + r];
+    }
+}
 
 // layer 1 contribution of one layer-0 row: A[m=l''][tap=(dk,dl), c] = R[c][dk*18 + l''+dl];  K = tap*32 + c (per dn)
 struct L1Loader {
@@ -162,6 +171,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     float* S = bufB;
     float* T = bufB + 3200;
     float* R = bufB + 6400;                  // [32][64]
+    float* D = bufB + 8448;                  // [32][3][100] ring of cost-volume shift rows (ends at 18048 <= CV_BUF)
     const int match = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE, li = lane & 15, lk = lane >> 4;
     {
@@ -173,6 +183,8 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         }
     }
     __syncthreads();
+    cost_row(D, S, T, 0);
+    cost_row(D, S, T, 1);
 
     // ---- phase A: layer 0 row by row, layer 1 as a sliding window of three accumulator tiles ------------
     // layer 0: wave w owns M-tile w (positions 16w..16w+15 of the 54 = 3x18 row positions), both N-tiles.
@@ -183,9 +195,11 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     m0 = m0 < 54 ? m0 : 53;
 #pragma unroll 1
     for (int nrow = 0; nrow < 18; nrow++) {
+        cost_row(D, S, T, nrow + 2);         // slot of row nrow-1, which nobody reads any more
+        __syncthreads();
         {
             L0Loader L;
-            L.S = S; L.T = T; L.nrow = nrow; L.kp = m0 / 18; L.lp = m0 % 18; L.lk = lk;
+            L.D = D; L.nrow = nrow; L.base = (m0 / 18) * 20 + (m0 % 18); L.lk = lk;
             cvx4 acc[1][2] = { { (cvx4){ 0.f, 0.f, 0.f, 0.f }, (cvx4){ 0.f, 0.f, 0.f, 0.f } } };
             cv_gemm<1, 2>(acc, L, P.wt[0] + (size_t)lk * 32 + li, 32, 27 * 2);
 #pragma unroll

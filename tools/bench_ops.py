@@ -94,3 +94,20 @@ if which == 'vox':
         ops.select_patches(raw, kp, cfg.des_r, 512)
     torch.cuda.synchronize()
     print(f'select_patches 5000 kpts x {raw.shape[0]} pts: {(time.perf_counter()-t)/10*1e3:.3f} ms')
+if which == 'cost':
+    from buffer_amd import registration
+    from buffer_amd.weights import load_weights
+    cv = registration.CostVolume(load_weights('3dmatch'), dev)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    a = torch.nn.functional.normalize(torch.rand((2500, 32, 5, 20), generator=g), dim=1).to(dev)
+    b = torch.nn.functional.normalize(torch.rand((2500, 32, 5, 20), generator=g), dim=1).to(dev)
+    want = cv(a[:64], b[:64], fused=False)
+    got = cv(a[:64], b[:64], fused=True)
+    print('max err', (got - want).abs().max().item())
+    cv(a, b); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        cv(a, b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+    print(f'cost_net 2500 matches: {dt*1e3:.2f} ms  {2500*0.160/dt/1e3:.1f} TFLOP/s')
