@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--pairs-per-step', type=int, default=16, help='pairs registered per GPU and step')
     ap.add_argument('--mode', choices=['batch', 'threads'], default='batch',
                     help='batch: the pairs of a step share one set of stacked launches; threads: one stream per pair')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--streams', type=int, default=1,
                     help='batch mode: the pairs of a step are split into this many stacked batches, one host thread + HIP '
                          'stream each, so that the latency-bound FPS of one batch overlaps the CNN kernels of another')
     ap.add_argument('--distinct-pairs', type=int, default=4, help='synthetic pairs generated per rank (cycled)')

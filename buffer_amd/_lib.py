@@ -51,6 +51,8 @@ _SIGNATURES = {
     "buf_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "buf_three_nn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "buf_select_patches": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp]),
+    "buf_compact_ws_bytes": (_sz, [_i]),
+    "buf_compact_greater": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "buf_knn_ws_bytes": (_sz, [_i, _i, _i]),
     "buf_knn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "buf_fps_ragged": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -559,3 +559,57 @@ extern "C" int buf_knn(const float* ref, const float* query, int b, int n, int n
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
+
+// ------------------------------------------------------------------------------------------ A5b
+// Ordered stream compaction of `score > threshold` (torch.where at models/BUFFER.py:255-259): indices come out
+// ascending.  Pass 1 counts hits per 256-lane workgroup (ballot + popcount), an exclusive scan turns the counts
+// into offsets, pass 2 places every hit at offset + (hits in lower wavefronts) + (popcount of lower lanes).
+__global__ void __launch_bounds__(256) k_compact_count(const float* __restrict__ x, int stride, int n, float thr, int* __restrict__ counts)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    bool hit = i < n && x[(size_t)i * stride] > thr;
+    unsigned long long m = __ballot(hit);
+    __shared__ int wc[4];
+    if ((threadIdx.x & (WAVE - 1)) == 0) wc[threadIdx.x / WAVE] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ void __launch_bounds__(256) k_compact_scatter(const float* __restrict__ x, int stride, int n, float thr,
+                                                       const int* __restrict__ offsets, int* __restrict__ idx_out)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    bool hit = i < n && x[(size_t)i * stride] > thr;
+    unsigned long long m = __ballot(hit);
+    __shared__ int wc[4];
+    if (lane == 0) wc[w] = __popcll(m);
+    __syncthreads();
+    int base = offsets[blockIdx.x];
+    for (int k = 0; k < w; k++) base += wc[k];
+    if (hit) idx_out[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+extern "C" size_t buf_compact_ws_bytes(int n) { return sizeof(int) * ((size_t)cdiv(n > 0 ? n : 1, 256) + scan_tmp_ints() + 64); }
+
+// x f32[n] read with element stride `stride`; idx_out int32[n] capacity; count_out int32[1] (device).
+extern "C" int buf_compact_greater(const float* x, int stride, int n, float threshold, int* idx_out, int* count_out,
+                                   void* ws, size_t ws_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    BUF_REQUIRE(n >= 0 && stride >= 1, BUF_EINVAL, "buf_compact_greater: n=%d stride=%d", n, stride);
+    BUF_REQUIRE(count_out && ws, BUF_EINVAL, "buf_compact_greater: null argument");
+    if (n == 0) { BUF_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int), s)); return BUF_OK; }
+    BUF_REQUIRE(x && idx_out, BUF_EINVAL, "buf_compact_greater: null argument");
+    int blocks = cdiv(n, 256);
+    WsCarver w(ws, ws_bytes);
+    int* counts = w.take<int>((size_t)blocks);
+    int* tmp = w.take<int>(scan_tmp_ints());
+    BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_compact_greater: workspace %zu < %zu", ws_bytes, w.used());
+    k_compact_count<<<blocks, 256, 0, s>>>(x, stride, n, threshold, counts);
+    int rc = exclusive_scan_i32(counts, blocks, tmp, count_out, s);
+    if (rc) return rc;
+    k_compact_scatter<<<blocks, 256, 0, s>>>(x, stride, n, threshold, counts, idx_out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

@@ -212,6 +212,20 @@ def select_patches(pts, kpts, radius, nsample, out=None):
     return out
 
 
+def compact_greater(x, threshold):
+    """ascending int32 indices i with x[i] > threshold (x f32[n] or [n,1]); one host read-back for the count."""
+    L = _lib.lib()
+    x = _dev(x, torch.float32, "compact_greater").reshape(-1)
+    n = int(x.shape[0])
+    idx = torch.empty((max(n, 1),), dtype=torch.int32, device=x.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=x.device)
+    nbytes = L.buf_compact_ws_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.buf_compact_greater(_ptr(x), 1, n, float(threshold), _ptr(idx), _ptr(cnt), _ptr(ws), nbytes, _stream()),
+          "buf_compact_greater")
+    return idx[:int(cnt.item())]
+
+
 def knn(ref, query, k):
     """ref f32[B,N,D], query f32[B,Q,D] -> (dist f32[B,Q,k], idx int64[B,Q,k])."""
     L = _lib.lib()

@@ -47,7 +47,7 @@ class BufferPipeline:
         for lo, hi in ((0, n_src), (n_src, pts0.shape[0])):
             p = pts0[lo:hi]
             a = orient_axes(axis[lo:hi], p)
-            keep = torch.nonzero(score[lo:hi, 0] > cfg.keypts_th).flatten()         # BUFFER.py:255-259
+            keep = ops.compact_greater(score[lo:hi, 0], cfg.keypts_th).long()       # BUFFER.py:255-259
             if keep.shape[0] == 0:
                 return self._identity(out, detail)
             cand_p.append(p[keep]); cand_a.append(a[keep])
@@ -102,7 +102,7 @@ class BufferPipeline:
         cloud_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
         cloud_id = torch.repeat_interleave(torch.arange(2 * B, device=dev), cloud_len)
         axis_o = orient_axes(axis, pts0)                                                    # BUFFER.py:244-249 (row-wise)
-        keep = torch.nonzero(score[:, 0] > cfg.keypts_th).flatten()                          # :255-259, ascending
+        keep = ops.compact_greater(score[:, 0], cfg.keypts_th).long()                        # :255-259, ascending
         counts = torch.bincount(cloud_id[keep], minlength=2 * B).cpu().numpy()
         poses = [None] * B
         if (counts == 0).any():

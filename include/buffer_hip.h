@@ -139,6 +139,13 @@ int     buf_three_nn(const float* unknown, const float* known, int b, int n, int
 int     buf_select_patches(const float* pts, const float* kpts, int n, int m, float radius, int nsample,
                            float* patches, void* stream);
 
+/* A5b  ordered compaction of `x > threshold` (torch.where at models/BUFFER.py:255-259): ascending indices.
+ * x f32 read with element stride `stride` (score[:,0] of an [n,1] tensor: stride 1); idx_out int32[n] capacity;
+ * count_out int32[1] on the device. */
+size_t  buf_compact_ws_bytes(int n);
+int     buf_compact_greater(const float* x, int stride, int n, float threshold, int* idx_out, int* count_out,
+                            void* ws, size_t ws_bytes, void* stream);
+
 /* knn_cuda.KNN(k, transpose_mode=True) (README.md:32; models/BUFFER.py:347,352):
  * ref f32[b,n,d], query f32[b,q,d] -> dist f32[b,q,k] (Euclidean, ascending), idx int64[b,q,k]. d,k <= 64. */
 size_t  buf_knn_ws_bytes(int b, int q, int k);

@@ -113,3 +113,18 @@ def test_svd3x3(dev):
     assert (s[:, 0] >= s[:, 1]).all() and (s[:, 1] >= s[:, 2]).all()
     np.testing.assert_allclose(s, np.linalg.svd(a.astype(np.float64), compute_uv=False), rtol=1e-4,
                                atol=1e-5 * scale.max())
+
+
+def test_compact_greater(dev):
+    """A5b: ordered compaction == torch.where(score > th) (models/BUFFER.py:255-259), incl. NaN / empty / all"""
+    from buffer_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for n in (0, 1, 255, 256, 257, 100_003):
+        x = torch.rand(n, generator=g)
+        if n > 10:
+            x[3] = float('nan'); x[7] = 0.5
+        got = ops.compact_greater(x.to(dev), 0.5).cpu()
+        assert torch.equal(got.long(), torch.where(x > 0.5)[0])
+    x = torch.ones(1000)
+    assert torch.equal(ops.compact_greater(x.to(dev), 0.0).cpu().long(), torch.arange(1000))
+    assert ops.compact_greater(x.to(dev), 2.0).numel() == 0
