@@ -2,21 +2,27 @@
 // (replaces cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:5-106,109-211).
 //
 // The reference accumulates points into an unordered_map keyed by the voxel index and emits the
-// barycentres in hash-map order.  Here: dense voxel table per batch element, counting sort of the
-// points by voxel (ties ranked by input index, so each voxel's run is in INPUT ORDER and the fp32
-// sum is the reference's, bit for bit), one lane per voxel run, rows emitted in ascending voxel-key
-// order.
+// barycentres in hash-map order.  Here: a table of key buckets per batch element, counting sort of the
+// points by bucket, every point ranks itself by (key, input index) inside its bucket (so each voxel's run
+// is contiguous and in INPUT ORDER and the fp32 sum is the reference's, bit for bit), one lane per voxel
+// run, rows emitted in ascending voxel-key order.
 #include "common.h"
 
+// The table is indexed by BUCKETS of B consecutive voxel keys (B = 1 whenever the bounding box fits `max_cells`,
+// which is the normal case: bucket == voxel).  Buckets are contiguous key ranges, so "ascending (bucket, key)" is
+// "ascending key"; inside a bucket every point ranks itself by (key, input index).  Keys use the reference's own
+// 64-bit wrapping arithmetic, so even its (size_t)floor(negative) corner case lands where the reference puts it
+// (such keys are huge and are parked in the element's last bucket).
 struct VoxGrid {
-    float o[3];            // originCorner (grid_subsampling.cpp:27)
+    float o[3];                    // originCorner (grid_subsampling.cpp:27)
     float dl;
-    long long NX, NY, NZ;  // sampleNX, sampleNY (:30-31) and the z extent for the dense table
-    long long table_off;   // first slot of this element in the concatenated table
-    int lo, hi;            // point range
+    unsigned long long NX, NY;     // sampleNX, sampleNY (:30-31)
+    double cells;                  // NX*NY*NZ of the bounding box (budgeting only)
+    long long nbuckets, table_off; // buckets of this element / first table slot (concatenated)
+    int lo, hi;                    // point range
 };
 
-struct VoxStatus { int error; int total_rows; };
+struct VoxStatus { int error; unsigned long long B; };
 
 __global__ void __launch_bounds__(1024) k_vox_bbox(const float* __restrict__ pts, const int* __restrict__ off,
                                                  VoxGrid* __restrict__ grids, float dl)
@@ -49,16 +55,18 @@ __global__ void __launch_bounds__(1024) k_vox_bbox(const float* __restrict__ pts
         g.dl = dl;
         g.lo = lo; g.hi = hi;
         float inv = __fdiv_rn(1.0f, dl);                       // (1/sampleDl), fp32
-        long long N[3];
+        double N[3];
         for (int c = 0; c < 3; c++) {
             float a = smn[c][0], z = smx[c][0];
             for (int i = 1; i < 16; i++) { a = fminf(a, smn[c][i]); z = fmaxf(z, smx[c][i]); }
             if (hi <= lo) { a = 0.f; z = 0.f; }
             g.o[c] = __fmul_rn(floorf(__fmul_rn(a, inv)), dl);  // floor(min * (1/dl)) * dl
-            N[c] = (long long)floorf(__fdiv_rn(__fsub_rn(z, g.o[c]), dl)) + 1;
+            N[c] = (double)floorf(__fdiv_rn(__fsub_rn(z, g.o[c]), dl)) + 1.0;
         }
-        g.NX = N[0]; g.NY = N[1]; g.NZ = N[2];
-        g.table_off = 0;
+        g.NX = (unsigned long long)(long long)N[0];
+        g.NY = (unsigned long long)(long long)N[1];
+        g.cells = fmax(N[0], 1.0) * fmax(N[1], 1.0) * fmax(N[2], 1.0);
+        g.nbuckets = 1; g.table_off = 0;
         grids[b] = g;
     }
 }
@@ -66,85 +74,110 @@ __global__ void __launch_bounds__(1024) k_vox_bbox(const float* __restrict__ pts
 __global__ void k_vox_offsets(VoxGrid* __restrict__ grids, int nb, long long max_cells, VoxStatus* __restrict__ st)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    long long run = 0;
-    int err = 0;
-    for (int b = 0; b < nb; b++) {
-        VoxGrid g = grids[b];
-        grids[b].table_off = run;
-        if (g.hi > g.lo) {
-            if (g.NX <= 0 || g.NY <= 0 || g.NZ <= 0) err = 1;
-            else {
-                double cells = (double)g.NX * (double)g.NY * (double)g.NZ;
-                if (cells > (double)max_cells) err = 1; else run += g.NX * g.NY * g.NZ;
-            }
-        }
-        if (run > max_cells) err = 1;
+    double Bd = 1.0;
+    for (int it = 0; it < 200; it++) {             // smallest power-of-two bucket width that fits the table
+        double need = 0.0;
+        for (int b = 0; b < nb; b++) need += grids[b].hi > grids[b].lo ? floor(grids[b].cells / Bd) + 2.0 : 1.0;
+        if (need <= (double)max_cells) break;
+        Bd *= 2.0;
     }
-    st->error = err;
-    st->total_rows = 0;
+    long long run = 0;
+    for (int b = 0; b < nb; b++) {
+        long long nbk = grids[b].hi > grids[b].lo ? (long long)(floor(grids[b].cells / Bd) + 2.0) : 1;
+        grids[b].nbuckets = nbk;
+        grids[b].table_off = run;
+        run += nbk;
+    }
+    st->error = run > max_cells ? 1 : 0;
+    st->B = (unsigned long long)Bd;
 }
 
 __global__ void __launch_bounds__(256) k_vox_count(const float* __restrict__ pts, int n, const int* __restrict__ off, int nb,
-                                                 const VoxGrid* __restrict__ grids, VoxStatus* __restrict__ st,
-                                                 int* __restrict__ table, int* __restrict__ cell_of)
+                                                 const VoxGrid* __restrict__ grids, const VoxStatus* __restrict__ st,
+                                                 int* __restrict__ table, int* __restrict__ cell_of,
+                                                 unsigned long long* __restrict__ keys)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || st->error) return;
     int b = find_elem(off, nb, i);
     VoxGrid g = grids[b];
-    // (size_t)floor((p - origin) / dl), fp32 (grid_subsampling.cpp:53-55)
-    long long iX = (long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i], g.o[0]), g.dl));
-    long long iY = (long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], g.o[1]), g.dl));
-    long long iZ = (long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], g.o[2]), g.dl));
-    if (iX < 0 || iY < 0 || iZ < 0 || iX >= g.NX || iY >= g.NY || iZ >= g.NZ) {
-        // The reference's size_t cast of a negative floor (origin rounding) yields a wrapped key;
-        // a dense table cannot hold it.
-        atomicExch(&st->error, 2);
-        return;
-    }
-    long long c = g.table_off + iX + g.NX * iY + g.NX * g.NY * iZ;   // mapIdx (:56) + element offset
-    cell_of[i] = (int)c;
+    // (size_t)floor((p - origin) / dl), fp32, 64-bit wrapping like the reference (grid_subsampling.cpp:53-56)
+    unsigned long long iX = (unsigned long long)(long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i], g.o[0]), g.dl));
+    unsigned long long iY = (unsigned long long)(long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 1], g.o[1]), g.dl));
+    unsigned long long iZ = (unsigned long long)(long long)floorf(__fdiv_rn(__fsub_rn(pts[3 * (size_t)i + 2], g.o[2]), g.dl));
+    unsigned long long key = iX + g.NX * iY + g.NX * g.NY * iZ;         // mapIdx
+    unsigned long long bk = key / st->B;
+    if (bk > (unsigned long long)(g.nbuckets - 1)) bk = (unsigned long long)(g.nbuckets - 1);
+    int c = (int)(g.table_off + (long long)bk);
+    keys[i] = key;
+    cell_of[i] = c;
     atomicAdd(&table[c], 1);
 }
 
-// heads: sorted position p starts a voxel run
-__global__ void __launch_bounds__(256) k_vox_heads(const float4* __restrict__ sorted, const int* __restrict__ cell_of, int n,
-                                                 const VoxStatus* __restrict__ st, int* __restrict__ head)
+// rank inside a bucket by (voxel key, input index): runs of equal key end up contiguous and in INPUT ORDER
+__global__ void __launch_bounds__(256) k_vox_rank(const int* __restrict__ cell_of, const unsigned long long* __restrict__ keys,
+                                                const int* __restrict__ table, const float4* __restrict__ sorted_in, int n,
+                                                const VoxStatus* __restrict__ st, float4* __restrict__ sorted_out,
+                                                unsigned long long* __restrict__ key_sorted, int* __restrict__ cell_sorted)
+{
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n || st->error) return;
+    float4 me = sorted_in[p];
+    int i = __float_as_int(me.w);
+    int c = cell_of[i];
+    unsigned long long k = keys[i];
+    int s = c == 0 ? 0 : table[c - 1], e = table[c];
+    int rank = 0;
+    for (int t = s; t < e; t++) {
+        int j = __float_as_int(sorted_in[t].w);
+        unsigned long long kj = keys[j];
+        rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+    }
+    sorted_out[s + rank] = me;
+    key_sorted[s + rank] = k;
+    cell_sorted[s + rank] = c;
+}
+
+__device__ __forceinline__ bool vox_is_head(const unsigned long long* __restrict__ key_sorted, const int* __restrict__ cell_sorted, int p)
+{
+    return p == 0 || cell_sorted[p] != cell_sorted[p - 1] || key_sorted[p] != key_sorted[p - 1];
+}
+
+__global__ void __launch_bounds__(256) k_vox_heads(const unsigned long long* __restrict__ key_sorted, const int* __restrict__ cell_sorted,
+                                                 int n, const VoxStatus* __restrict__ st, int* __restrict__ head)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    if (st->error) { head[p] = 0; return; }
-    int c = cell_of[__float_as_int(sorted[p].w)];
-    int prev = p == 0 ? -1 : cell_of[__float_as_int(sorted[p - 1].w)];
-    head[p] = c != prev ? 1 : 0;
+    head[p] = (!st->error && vox_is_head(key_sorted, cell_sorted, p)) ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_vox_emit(const float4* __restrict__ sorted, const int* __restrict__ cell_of,
-                                                const int* __restrict__ table, const int* __restrict__ rowidx,
+__global__ void __launch_bounds__(256) k_vox_emit(const float4* __restrict__ sorted, const unsigned long long* __restrict__ key_sorted,
+                                                const int* __restrict__ cell_sorted, const int* __restrict__ rowidx,
                                                 int n, const VoxStatus* __restrict__ st, float* __restrict__ out,
                                                 const float* __restrict__ feats, int fdim, float* __restrict__ out_feats)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n || st->error) return;
-    int c = cell_of[__float_as_int(sorted[p].w)];
-    int s = c == 0 ? 0 : table[c - 1];
-    if (p != s) return;                      // not a run head
-    int e = table[c];
+    if (!vox_is_head(key_sorted, cell_sorted, p)) return;
+    const unsigned long long k = key_sorted[p];
+    const int c = cell_sorted[p];
+    int e = p + 1;
+    while (e < n && cell_sorted[e] == c && key_sorted[e] == k) e++;
     float sx = 0.f, sy = 0.f, sz = 0.f;      // SampledData.point += p, in input order (grid_subsampling.h:95-100)
-    for (int t = s; t < e; t++) {
+    for (int t = p; t < e; t++) {
         float4 q = sorted[t];
         sx = __fadd_rn(sx, q.x); sy = __fadd_rn(sy, q.y); sz = __fadd_rn(sz, q.z);
     }
-    float w = (float)(1.0 / (double)(e - s));          // point * (1.0 / count): double -> float (:87)
+    float w = (float)(1.0 / (double)(e - p));          // point * (1.0 / count): double -> float (:87)
     int r = rowidx[p];
     out[3 * (size_t)r] = __fmul_rn(sx, w);
     out[3 * (size_t)r + 1] = __fmul_rn(sy, w);
     out[3 * (size_t)r + 2] = __fmul_rn(sz, w);
     if (feats) {                             // features summed in input order, then f / (float)count (:90-96)
-        float cf = (float)(e - s);
+        float cf = (float)(e - p);
         for (int d = 0; d < fdim; d++) {
             float acc = 0.f;
-            for (int t = s; t < e; t++) acc = __fadd_rn(acc, feats[(size_t)__float_as_int(sorted[t].w) * fdim + d]);
+            for (int t = p; t < e; t++) acc = __fadd_rn(acc, feats[(size_t)__float_as_int(sorted[t].w) * fdim + d]);
             out_feats[(size_t)r * fdim + d] = __fdiv_rn(acc, cf);
         }
     }
@@ -167,6 +200,7 @@ __global__ void k_vox_counts(const int* __restrict__ rowidx, const int* __restri
 struct VoxWs {
     VoxGrid* grids; VoxStatus* st; int* off; int* table; int* cell_of; float4* sorted_tmp; float4* sorted;
     int* order; int* head; int* scan_tmp; int* total; int* counts; float* out_tmp; float* feat_tmp;
+    unsigned long long* keys; unsigned long long* key_sorted; int* cell_sorted;
 };
 
 static VoxWs carve_vox(WsCarver& w, int n, int nb, int64_t max_cells, int fdim)
@@ -187,6 +221,9 @@ static VoxWs carve_vox(WsCarver& w, int n, int nb, int64_t max_cells, int fdim)
     v.counts = w.take<int>((size_t)nb + 2);
     v.out_tmp = w.take<float>(3 * nn);
     v.feat_tmp = w.take<float>((size_t)(fdim > 0 ? fdim : 0) * nn + 1);
+    v.keys = w.take<unsigned long long>(nn);
+    v.key_sorted = w.take<unsigned long long>(nn);
+    v.cell_sorted = w.take<int>(nn);
     return v;
 }
 
@@ -206,7 +243,7 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     BUF_REQUIRE(batches_host && out_batches_host && out_m_host && ws, BUF_EINVAL, "buf_grid_subsample_batch: null argument");
     BUF_REQUIRE(n >= 0 && nb > 0, BUF_EINVAL, "buf_grid_subsample_batch: n=%d nb=%d", n, nb);
     BUF_REQUIRE(dl > 0.f, BUF_EINVAL, "buf_grid_subsample_batch: sampleDl=%g must be > 0", dl);
-    BUF_REQUIRE(max_cells > 0 && max_cells < 0x7fffffffLL, BUF_EINVAL, "buf_grid_subsample_batch: max_cells=%lld", (long long)max_cells);
+    BUF_REQUIRE(max_cells >= 2LL * nb && max_cells < 0x7fffffffLL, BUF_EINVAL, "buf_grid_subsample_batch: max_cells=%lld (need >= 2 per batch element)", (long long)max_cells);
     BUF_REQUIRE(n == 0 || (pts && out_pts), BUF_EINVAL, "buf_grid_subsample_batch: null points");
     WsCarver w(ws, ws_bytes);
     BUF_REQUIRE(fdim >= 0 && (fdim == 0 || (feats && out_feats)), BUF_EINVAL, "buf_grid_subsample_batch: features");
@@ -224,17 +261,17 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     k_vox_bbox<<<nb, 1024, 0, s>>>(pts, v.off, v.grids, dl);
     k_vox_offsets<<<1, 1, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
     int blocks = cdiv(n, 256);
-    k_vox_count<<<blocks, 256, 0, s>>>(pts, n, v.off, nb, v.grids, v.st, v.table, v.cell_of);
+    k_vox_count<<<blocks, 256, 0, s>>>(pts, n, v.off, nb, v.grids, v.st, v.table, v.cell_of, v.keys);
     rc = exclusive_scan_i32(v.table, (long long)max_cells, v.scan_tmp, nullptr, s);
     if (rc) return rc;
     k_cell_scatter<<<blocks, 256, 0, s>>>(pts, n, v.cell_of, &v.st->error, v.table, v.sorted_tmp);
-    k_cell_rank<<<blocks, 256, 0, s>>>(v.cell_of, v.table, v.sorted_tmp, n, &v.st->error, v.sorted, v.order);
-    k_vox_heads<<<blocks, 256, 0, s>>>(v.sorted, v.cell_of, n, v.st, v.head);
+    k_vox_rank<<<blocks, 256, 0, s>>>(v.cell_of, v.keys, v.table, v.sorted_tmp, n, v.st, v.sorted, v.key_sorted, v.cell_sorted);
+    k_vox_heads<<<blocks, 256, 0, s>>>(v.key_sorted, v.cell_sorted, n, v.st, v.head);
     rc = exclusive_scan_i32(v.head, n, v.scan_tmp, v.total, s);
     if (rc) return rc;
     float* dst = max_p > 0 ? v.out_tmp : out_pts;
     float* fdst = max_p > 0 ? v.feat_tmp : out_feats;
-    k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.cell_of, v.table, v.head, n, v.st, dst, fdim > 0 ? feats : nullptr, fdim, fdst);
+    k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.key_sorted, v.cell_sorted, v.head, n, v.st, dst, fdim > 0 ? feats : nullptr, fdim, fdst);
     k_vox_counts<<<cdiv(nb + 1, 64), 64, 0, s>>>(v.head, v.off, nb, n, 0, v.total, v.st, v.counts);
     BUF_LAUNCH_CHECK();
     int stackc[66];
@@ -245,8 +282,7 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     int m = 0;
     rc = BUF_OK;
     if (e != hipSuccess) { buf_set_error("buf_grid_subsample_batch: %s", hipGetErrorString(e)); rc = BUF_EHIP; }
-    else if (err == 1) { buf_set_error("buf_grid_subsample_batch: dense voxel table needs more than max_cells=%lld cells", (long long)max_cells); rc = BUF_ECAPACITY; }
-    else if (err == 2) { buf_set_error("buf_grid_subsample_batch: point below the grid origin (reference wraps the voxel key here)"); rc = BUF_ECAPACITY; }
+    else if (err) { buf_set_error("buf_grid_subsample_batch: bucket table does not fit max_cells=%lld", (long long)max_cells); rc = BUF_ECAPACITY; }
     else {
         int src = 0;
         for (int b = 0; b < nb; b++) {

@@ -1,0 +1,104 @@
+"""Edge cases through the C ABI: sparse extents, the reference's wrapped voxel key, truncation, degenerate
+inputs, argument errors (error codes, no crashes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_sub(oracle, dev, pts, lens, dl, **kw):
+    from buffer_amd import ops
+    want, wl = oracle.grid_subsample_batch(pts, lens, dl, **{k: v for k, v in kw.items() if k == 'max_p'})
+    got, gl = ops.grid_subsample_batch(torch.from_numpy(pts).to(dev), lens, dl, **kw)
+    assert np.array_equal(gl, wl)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_subsample_sparse_extent_uses_key_buckets(oracle, dev):
+    """an outlier 10 km away: 3e15 voxels in the bounding box, the bucketed table still reproduces the oracle"""
+    rng = np.random.default_rng(0)
+    pts = rng.random((5000, 3)).astype(np.float32)
+    pts[17] = [10000.0, -8000.0, 9000.0]
+    pts[4000] = [-5000.0, 3.0, 2.0]
+    lens = np.array([3000, 2000], np.int32)
+    _eq_sub(oracle, dev, pts, lens, 0.05)
+    _eq_sub(oracle, dev, pts, lens, 0.05, max_cells=4096)          # tiny table: many voxels per bucket
+
+
+def test_subsample_wrapped_key_corner_case(oracle, dev):
+    """floor(min*(1/dl))*dl can round ABOVE min (e.g. dl = 0.6 -- KITTI's first pooling -- with min = 6.6): the reference then casts floor(negative) to size_t and the voxel key wraps.  We land where the restated
+    reference lands (the wrapped keys are the largest ones)."""
+    rng = np.random.default_rng(1)
+    for dl, m in ((0.6, np.float32(6.6)), (0.6, np.float32(20.4)), (0.3, np.float32(25.5)), (0.3, np.float32(20.4))):
+        d = np.float32(dl)
+        o = np.floor(m * (np.float32(1) / d)) * d
+        assert np.floor((m - o) / d) < 0, "not a counter-example any more?"
+        pts = (rng.random((3000, 3)) * 4 + float(m) + 0.5).astype(np.float32)
+        pts[5, 0] = m
+        pts[9, 1] = m
+        pts[2000, 2] = m
+        _eq_sub(oracle, dev, pts, np.array([1800, 1200], np.int32), dl)
+
+
+def test_subsample_max_p_and_single_voxel(oracle, dev):
+    rng = np.random.default_rng(2)
+    pts = rng.random((3000, 3)).astype(np.float32)
+    lens = np.array([1000, 2000], np.int32)
+    _eq_sub(oracle, dev, pts, lens, 0.2, max_p=50)
+    _eq_sub(oracle, dev, pts, lens, 100.0)                          # everything in one voxel: a 2000-term ordered sum
+    same = np.tile(np.array([[0.3, 0.4, 0.5]], np.float32), (500, 1))
+    _eq_sub(oracle, dev, same, np.array([500], np.int32), 0.1)
+
+
+def test_degenerate_point_ops(oracle, dev):
+    from buffer_amd import ops
+    rng = np.random.default_rng(3)
+    xyz = (rng.random((1, 40, 3)) + 1).astype(np.float32)
+    t = torch.from_numpy(xyz).to(dev)
+    # more samples than points: FPS keeps going (upstream semantics), ball query pads, kNN with k > n pads
+    assert np.array_equal(ops.furthest_point_sample(t, 100).cpu().numpy(), oracle.fps(xyz, 100))
+    assert np.array_equal(ops.ball_query(0.2, 64, t, t).cpu().numpy(), oracle.ball_query(0.2, 64, xyz, xyz))
+    feat = rng.normal(size=(1, 5, 8)).astype(np.float32)
+    q = rng.normal(size=(1, 3, 8)).astype(np.float32)
+    gd, gi = ops.knn(torch.from_numpy(feat).to(dev), torch.from_numpy(q).to(dev), 7)
+    wd, wi = oracle.knn(feat, q, 7)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(np.isinf(gd.cpu().numpy()), np.isinf(wd))
+    # a cloud the upstream FPS kernel skips entirely (all points within sqrt(1e-3) of the origin)
+    tiny = (rng.random((1, 300, 3)) * 0.01).astype(np.float32)
+    assert np.array_equal(ops.furthest_point_sample(torch.from_numpy(tiny).to(dev), 20).cpu().numpy(), oracle.fps(tiny, 20))
+    # radius search with queries far outside the support bounding box and a zero radius
+    s = (rng.random((500, 3))).astype(np.float32)
+    qf = s + 50.0
+    out = ops.radius_neighbors(torch.from_numpy(qf).to(dev), torch.from_numpy(s).to(dev), [500], [500], 0.1, k=4)
+    assert bool((out == 500).all())
+    out = ops.radius_neighbors(torch.from_numpy(s).to(dev), torch.from_numpy(s).to(dev), [500], [500], 0.0, k=3)
+    assert bool((out == 500).all())                                 # strict '<': d2 = 0 is not < 0
+
+
+def test_c_abi_error_codes(dev):
+    """bad arguments come back as BUF_E* codes with a message; nothing faults"""
+    from buffer_amd import _lib
+    L = _lib.lib()
+    t = torch.rand(100, 3, device=dev)
+    lens = (C.c_int * 1)(100)
+    out = torch.empty(100, 4, dtype=torch.int32, device=dev)
+    ws = torch.empty(1024, dtype=torch.uint8, device=dev)           # far too small
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.buf_radius_neighbors(t.data_ptr(), 100, t.data_ptr(), 100, lens, lens, 1, 0.1, 4, out.data_ptr(), None, None,
+                                ws.data_ptr(), 1024, s)
+    assert rc == -3 and b"workspace" in L.buf_last_error()
+    bad = (C.c_int * 1)(99)                                         # lengths do not sum to n
+    big = torch.empty(L.buf_grid_ws_bytes(100, 1, 0) + 400, dtype=torch.uint8, device=dev)
+    rc = L.buf_radius_neighbors(t.data_ptr(), 100, t.data_ptr(), 100, bad, lens, 1, 0.1, 4, out.data_ptr(), None, None,
+                                big.data_ptr(), big.numel(), s)
+    assert rc == -1 and b"sum" in L.buf_last_error()
+    rc = L.buf_knn(t.data_ptr(), t.data_ptr(), 1, 100, 100, 3, 100, None, None, None, 0, s)
+    assert rc == -1                                                 # k > 64
+    rc = L.buf_fps(None, 1, 100, 10, None, None, 0, s)
+    assert rc == -1
+    rc = L.buf_vn_gather_block(None, None, None, None, 10, 10, 4, 2, 4, 3, 1.0, None, None, None, None, 0.2, None, s)
+    assert rc == -1 and b"mode" in L.buf_last_error()
+    torch.cuda.synchronize()
