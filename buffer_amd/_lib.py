@@ -22,6 +22,7 @@ class buf_grid_t(C.Structure):
         ("ns", C.c_int), ("nb", C.c_int),
         ("cells_per_elem", C.c_int64),
         ("radius", C.c_float),
+        ("supports", C.c_void_p),
         ("desc", C.c_void_p), ("s_off", C.c_void_p), ("table", C.c_void_p),
         ("sorted", C.c_void_p), ("order", C.c_void_p), ("scan_tmp", C.c_void_p),
     ]

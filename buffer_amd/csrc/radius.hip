@@ -214,27 +214,49 @@ __global__ void __launch_bounds__(WAVE) k_grid_query(const CellGrid* __restrict_
 #define QPW (WAVE / QG)             // queries per wavefront
 #define QW_CAP 64
 
+#define QMAXB 128                   // batch elements whose descriptors are staged in LDS per workgroup
+
 __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellGrid* __restrict__ grids, const int* __restrict__ table,
                                                                   const float4* __restrict__ sorted, const float* __restrict__ queries,
                                                                   int nq, const int* __restrict__ q_off, int nb,
-                                                                  const int* __restrict__ q_order, float r2, int k_out, int shadow,
+                                                                  const int* __restrict__ q_order, int self_query, float r2,
+                                                                  int k_out, int shadow,
                                                                   int* __restrict__ nbr_out, int* __restrict__ counts_out,
                                                                   int* __restrict__ max_count_out, int* __restrict__ todo,
                                                                   int* __restrict__ todo_n)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long keys[QW_WAVES][QPW][QW_CAP + 8];   // + sentinels
+    __shared__ int s_off[QMAXB + 1];
+    __shared__ CellGrid s_grid[QMAXB];
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int grp = lane / QG, l16 = lane & (QG - 1);
     const int t = (blockIdx.x * QW_WAVES + w) * QPW + grp;
     const bool active = t < nq;
+    // The dependent-load chain of a query is what bounds this kernel: element offsets and grid descriptors are
+    // staged once per workgroup, a self query reads index AND coordinates from the cell-ordered array in one
+    // load, and all candidate chunks of a pass are requested before the first one is consumed.
+    const bool staged = nb <= QMAXB;
+    if (staged) {
+        for (int i = threadIdx.x; i <= nb; i += QW_WAVES * WAVE) s_off[i] = q_off[i];
+        for (int i = threadIdx.x; i < nb * (int)(sizeof(CellGrid) / 4); i += QW_WAVES * WAVE)
+            reinterpret_cast<int*>(s_grid)[i] = reinterpret_cast<const int*>(grids)[i];
+    }
     int qi = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) {
+        if (self_query) {
+            const float4 s = sorted[t];
+            qi = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z;
+        } else {
+            qi = q_order ? q_order[t] : t;
+            qx = queries[3 * (size_t)qi]; qy = queries[3 * (size_t)qi + 1]; qz = queries[3 * (size_t)qi + 2];
+        }
+    }
+    if (staged) __syncthreads();
     int rs = 0, len = 0;
     if (active) {
-        qi = q_order ? q_order[t] : t;
-        const int b = find_elem(q_off, nb, qi);
-        const CellGrid g = grids[b];
-        qx = queries[3 * (size_t)qi]; qy = queries[3 * (size_t)qi + 1]; qz = queries[3 * (size_t)qi + 2];
+        const int b = find_elem(staged ? s_off : q_off, nb, qi);
+        const CellGrid g = staged ? s_grid[b] : grids[b];
         double fx = floor(((double)qx - (double)g.mn[0]) * g.inv_cell);
         double fy = floor(((double)qy - (double)g.mn[1]) * g.inv_cell);
         double fz = floor(((double)qz - (double)g.mn[2]) * g.inv_cell);
@@ -262,23 +284,27 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     unsigned long long* K = keys[w][grp];
     const unsigned long long gmask_lo = (1ull << l16) - 1ull;
     int m = 0;
-    for (int c0 = 0; __any(c0 < total); c0 += QG) {
-        const int c = c0 + l16;
-        bool hit = false;
-        unsigned long long key = 0;
-        if (c < total) {
+    for (int c0 = 0; __any(c0 < total); c0 += 4 * QG) {
+        float4 cand[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {               // all four chunk loads of the pass are in flight together
+            const int c = c0 + u * QG + l16;
             int p = st[0] + c;
 #pragma unroll
             for (int j = 1; j < 9; j++) p = c >= pre[j] ? st[j] + (c - pre[j]) : p;
-            const float4 s = sorted[p];
-            const float d2 = sqdist3(qx, qy, qz, s.x, s.y, s.z);
-            hit = d2 < r2;
-            key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(s.w);
+            cand[u] = c < total ? sorted[p] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const unsigned long long mask = (__ballot(hit) >> (grp * QG)) & 0xffffull;
-        const int pos = m + __popcll(mask & gmask_lo);
-        if (hit && pos < QW_CAP) K[pos] = key;
-        m += __popcll(mask);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c0 + u * QG + l16;
+            const float d2 = sqdist3(qx, qy, qz, cand[u].x, cand[u].y, cand[u].z);
+            const bool hit = c < total && d2 < r2;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(cand[u].w);
+            const unsigned long long mask = (__ballot(hit) >> (grp * QG)) & 0xffffull;
+            const int pos = m + __popcll(mask & gmask_lo);
+            if (hit && pos < QW_CAP) K[pos] = key;
+            m += __popcll(mask);
+        }
     }
     if (active && l16 == 0) {
         if (counts_out) counts_out[qi] = m;
@@ -373,6 +399,7 @@ extern "C" int buf_grid_build(buf_grid_t* g, const float* supports, int ns, cons
     GridExtra ex = carve_extra(w, ns, nb);
     BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_grid_build: workspace %zu < %zu bytes", ws_bytes, w.used());
     g->ws = ws; g->ws_bytes = ws_bytes; g->ns = ns; g->nb = nb; g->cells_per_elem = cells_per_elem; g->radius = radius;
+    g->supports = supports;
 
     int rc = upload_offsets(g->s_off, s_batches_host, nb, ns, "buf_grid_build", s);
     if (rc) return rc;
@@ -394,6 +421,8 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
                               const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
                               int* max_count_out, void* todo_ws, void* stream)
 {
+    // self query in cell order: index and coordinates of query t come from the cell-ordered array itself
+    const int self_query = (q_order == g->order && queries == g->supports && nq == g->ns) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     BUF_REQUIRE(g && g->ws && q_batches_host, BUF_EINVAL, "buf_grid_query: null argument");
     BUF_REQUIRE(nq >= 0 && k_out >= 0, BUF_EINVAL, "buf_grid_query: nq=%d k_out=%d", nq, k_out);
@@ -419,7 +448,7 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
     // todo list (query ids of rows longer than QW_CAP) is carved behind the caller's output: it needs at
     // most nq ints; the first k_out==0 launch never produces one.
     k_grid_query_wave<<<cdiv(nq, QW_WAVES * QPW), QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
-                                                                   queries, nq, ex.q_off, g->nb, q_order, r2, k_out, g->ns, nbr_out,
+                                                                   queries, nq, ex.q_off, g->nb, q_order, self_query, r2, k_out, g->ns, nbr_out,
                                                                    counts_out, max_count_out, todo, ex.todo_n);
     if (timed) timing_end(s, &span);
     if (k_out > 0) {

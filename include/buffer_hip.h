@@ -64,6 +64,7 @@ typedef struct buf_grid {
     int     ns, nb;
     int64_t cells_per_elem;
     float   radius;
+    const float* supports; /* the support array the grid was built from (must stay alive while queried) */
     /* device sub-allocations inside ws */
     void*   desc;          /* per-element grid descriptors                         */
     int*    s_off;         /* int32[nb+1] support offsets                          */
@@ -79,7 +80,8 @@ int     buf_grid_build(buf_grid_t* g, const float* supports, int ns, const int* 
                        float radius, int64_t cells_per_elem, void* ws, size_t ws_bytes, void* stream);
 /* queries f32[nq,3]; q_order (nullable) int32[nq]: processing order (thread t handles query
  * q_order[t]) -- a spatially coherent order keeps a wavefront inside few cells; the result
- * does not depend on it.  nbr_out int32[nq,k_out] (k_out may be 0: count only);
+ * does not depend on it.  Passing the grid's own supports with q_order == g->order (a self query in
+ * cell order) lets the kernel take index and coordinates from the cell-ordered array in one load.  nbr_out int32[nq,k_out] (k_out may be 0: count only);
  * counts_out (nullable) int32[nq] = untruncated neighbour counts; max_count_out (nullable)
  * int32[1], atomically max-ed (caller zeroes it).  radius may differ from the build radius
  * as long as it is <= the grid's cell edge. */
