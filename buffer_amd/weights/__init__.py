@@ -1,5 +1,5 @@
 """Released BUFFER weights converted to flat f32 arrays keyed by the reference's parameter names
-(tools/make_golden.py: the four per-stage best.pth files merged with the reference's substring
+(tests/golden/make_golden.py: the four per-stage best.pth files merged with the reference's substring
 stage filter, ThreeDMatch/test.py:207-214)."""
 import os
 

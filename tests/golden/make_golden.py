@@ -10,7 +10,7 @@ installed here are stubbed:
   * torch_batch_svd, kornia, easydict, open3d, nibabel, tensorboardX -> minimal stand-ins
   * torch.Tensor.cuda         -> identity
 
-Usage: python tools/make_golden.py
+Usage: python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -19,7 +19,7 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 REF = '/root/reference'
 GOLD = os.path.join(ROOT, 'tests', 'golden')

@@ -1,5 +1,5 @@
 """Pin the CPU oracle (oracle/*.c, oracle/torch_ref.py) against the golden vectors that the
-reference itself produced (tools/make_golden.py).  CPU only."""
+reference itself produced (tests/golden/make_golden.py).  CPU only."""
 import os
 
 import numpy as np
