@@ -9,7 +9,7 @@
 //     out[n][m] = relu( sum_k A[m][k] * Wt[k][n] + b[n] ),  m = ele*20 + azi (140 positions, 9 tiles of 16),
 //     k = s*Cin + c with s = ky*3 + kx,  A[m][k] = in[c][ele+ky-1][(azi+kx-1) mod 20]  (0 outside 0 <= ele < 7)
 // on v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain).  Activations never leave LDS
-// (two 128x140 fp32 buffers, 140 KB); A fragments are gathered from LDS with the padding folded into
+// (one [128][144] fp32 buffer, 72 KB, rewritten in place after each layer -> two workgroups per CU); A fragments are gathered from LDS with the padding folded into
 // the address (one ds_read_b32 per fragment; invalid taps read a zero column), B fragments (BN-folded weights, [K][Cout]
 // row-major, 1.7 MB for the whole net, L2-resident) stream from global memory through a register ring.
 // HBM traffic per patch: 26.9 KB in, 17.9 KB out.
@@ -126,6 +126,9 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
 #undef CYL_LOAD
 #undef CYL_MMA
     }
+    // The layer's output overwrites its input IN PLACE (one 72 KB LDS buffer per workgroup, so two workgroups
+    // fit a CU and one computes while the other loads/stores): every wavefront has finished reading `in` here.
+    __syncthreads();
     // epilogue: bias (+ReLU); C/D layout: col = lane & 15 (n), rows (lane >> 4)*4 + r (m)
 #pragma unroll
     for (int u = 0; u < NT; u++) {
@@ -138,18 +141,18 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
                 f32x4 v = acc[t][u];
                 v.x += bv; v.y += bv; v.z += bv; v.w += bv;
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                float* dst = out_glb ? out_glb + (size_t)n * CN_POS + m : out_lds + n * CN_STR + m;
-                *reinterpret_cast<f32x4*>(dst) = v;
+                // two typed stores (global_store / ds_write), not one flat store through a selected pointer
+                if (out_glb) *reinterpret_cast<f32x4*>(out_glb + (size_t)n * CN_POS + m) = v;
+                else         *reinterpret_cast<f32x4*>(out_lds + n * CN_STR + m) = v;
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(CN_THREADS) k_cyl_net(const float* __restrict__ x, CylNetParams P, float* __restrict__ y)
+__global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restrict__ x, CylNetParams P, float* __restrict__ y)
 {
-    extern __shared__ float lds[];                   // 2 x [128][144] fp32 (140 positions + bank padding)
+    extern __shared__ float lds[];                   // [128][144] fp32 (140 positions + bank padding)
     float* buf0 = lds;
-    float* buf1 = lds + CN_BUF;
     const int patch = blockIdx.x;
     const int w = threadIdx.x / WAVE;
     {   // input: [16,3,7,20] = 48 folded channels x 140 positions, contiguous
@@ -161,13 +164,11 @@ __global__ void __launch_bounds__(CN_THREADS) k_cyl_net(const float* __restrict_
     }
     // columns 140..143 of every channel row (the bank padding) stay zero for the whole kernel: out-of-range
     // elevation taps and unused tile rows read column 140 instead of being masked after the load
-    if (threadIdx.x < CN_MAXC) {
+    if (threadIdx.x < CN_MAXC)
         *reinterpret_cast<f32x4*>(buf0 + threadIdx.x * CN_STR + CN_POS) = (f32x4){ 0.f, 0.f, 0.f, 0.f };
-        *reinterpret_cast<f32x4*>(buf1 + threadIdx.x * CN_STR + CN_POS) = (f32x4){ 0.f, 0.f, 0.f, 0.f };
-    }
     __syncthreads();
     float* in = buf0;
-    float* out = buf1;
+    float* out = buf0;
 #pragma unroll 1
     for (int l = 0; l < CN_LAYERS; l++) {
         const int cin = P.cin[l], cout = P.cout[l];
@@ -179,7 +180,6 @@ __global__ void __launch_bounds__(CN_THREADS) k_cyl_net(const float* __restrict_
             cyl_layer<5, 1>(in, out, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], half * 5, half ? 4 : 5, w >> 1);
         }
         __syncthreads();
-        float* tmp = in; in = out; out = tmp;
     }
 }
 
@@ -199,7 +199,7 @@ extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* cons
                     BUF_EINVAL, "buf_cylindrical_net: layer %d has unsupported widths %d -> %d", l, P.cin[l], P.cout[l]);
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net: layer %d width mismatch", l);
     }
-    size_t lds = sizeof(float) * 2 * CN_BUF;
+    size_t lds = sizeof(float) * CN_BUF;
     static bool attr_set = false;
     if (!attr_set) {
         BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cyl_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -15,8 +15,12 @@
 #define CV_THREADS 256
 #define CV_BUF 18432              // floats per ping-pong buffer (128 ch x 144 positions)
 #define CV_LAYERS 10
+#ifndef CV_EXP
+#define CV_EXP 0     // timing experiments only: 1 = no layer-0 GEMM, 2 = no layer-1 GEMM, 4 = no layers 2..9, 8 = no cost rows
+#endif
 
 typedef float cvx4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) float* cv_gptr;
 
 struct CostNetParams {
     const float* wt[CV_LAYERS];    // [K][Cout] row-major; K ordering documented per layer below; >= 16 spare rows not required
@@ -64,19 +68,97 @@ __device__ __forceinline__ void cv_gemm(cvx4 (&acc)[MT][NT], Loader& L, const fl
 #undef CV_MMA
 }
 
+// Same GEMM for small tiles (MT*NT <= 4 MFMAs per k-step): a group of 4 k-steps is then only 128-512 MFMA cycles,
+// less than an L2 round trip for the weight loads, so operands are prefetched D-1 groups ahead through a
+// register ring of depth D (fully unrolled, static indices).
+template <int MT, int NT, int D, typename Loader>
+__device__ __forceinline__ void cv_gemm_deep(cvx4 (&acc)[MT][NT], Loader& L, const float* __restrict__ wl, int cout, int total)
+{
+    float a[D][4][MT], b[D][4][NT];
+#define CVD_LOAD(SLOT, G)                                                                                 \
+    {                                                                                                     \
+        const int g_ = (G) < total ? (G) : total - 1;                                                     \
+        const float* wn_ = wl + (size_t)g_ * 16 * cout;                                                   \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
+            _Pragma("unroll") for (int u = 0; u < NT; u++) b[SLOT][p][u] = wn_[(size_t)p * 4 * cout + u * 16]; \
+        }                                                                                                 \
+        L.load(a[SLOT], g_);                                                                              \
+    }
+#define CVD_MMA(SLOT)                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                       \
+        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
+            _Pragma("unroll") for (int u = 0; u < NT; u++)                                                \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][p][t], b[SLOT][p][u], acc[t][u], 0, 0, 0); \
+        }                                                                                                 \
+    }
+#pragma unroll
+    for (int i = 0; i < D - 1; i++) CVD_LOAD(i, i)
+    const int main_groups = total - total % D;
+#pragma unroll 1
+    for (int g = 0; g < main_groups; g += D) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            __builtin_amdgcn_sched_barrier(0);
+            CVD_LOAD((i + D - 1) % D, g + i + D - 1)
+            __builtin_amdgcn_sched_barrier(0);
+            CVD_MMA(i)
+        }
+    }
+    // tail: groups main_groups .. total-1 are already in slots 0 .. D-2
+#pragma unroll
+    for (int i = 0; i < D - 1; i++)
+        if (main_groups + i < total) CVD_MMA(i)
+#undef CVD_LOAD
+#undef CVD_MMA
+}
+
+// Fully unrolled variant for a compile-time group count: every tap/channel-group index, LDS offset and weight
+// offset folds to an immediate, so a group costs no address arithmetic at all (the operand loads of the small
+// layer-0/1 tiles otherwise take as many issue cycles as their 4-8 MFMAs).
+template <int MT, int NT, int D, int TOTAL, typename Loader>
+__device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, const float* __restrict__ wl, int cout)
+{
+    float a[D][4][MT], b[D][4][NT];
+#define CVS_LOAD(SLOT, G)                                                                                 \
+    {                                                                                                     \
+        /* one address per group, pinned here (not hoisted out of the caller's loop) and typed as global  \
+           memory so that the loads stay global_load (in-order vmcnt), not flat_load */                   \
+        cv_gptr wg_ = (cv_gptr)(wl + (G) * 16 * cout);                                                    \
+        asm volatile("" : "+v"(wg_));                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
+            _Pragma("unroll") for (int u = 0; u < NT; u++) b[SLOT][p][u] = wg_[p * 4 * cout + u * 16];    \
+        }                                                                                                 \
+        L.load(a[SLOT], (G));                                                                             \
+    }
+#pragma unroll
+    for (int i = 0; i < D - 1; i++) CVS_LOAD(i, i)
+#pragma unroll
+    for (int g = 0; g < TOTAL; g++) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + D - 1 < TOTAL) CVS_LOAD((g + D - 1) % D, g + D - 1)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int u = 0; u < NT; u++)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % D][p][t], b[g % D][p][u], acc[t][u], 0, 0, 0);
+    }
+#undef CVS_LOAD
+}
+
 // layer 0: A[m=(k',l')][tap=(dn,dk,dl), c] = cost[c][n'+dn][k'+dk][l'+dl];  K = tap*32 + c.
 // The three shift rows n', n'+1, n'+2 of the cost volume (cost[c][n][k][l] = S[c][k][(l-n) mod 20] - T[c][k][l])
 // live in a 3-slot ring D[c][n mod 3][5][20], so a fragment is ONE LDS read (no arithmetic between load and MFMA).
 struct L0Loader {
-    const float* D;
-    int nrow, base, lk;                                  // base = k'*20 + l'
+    const float* row[3];                                 // lane's element of shift row n'+dn: D + lk*300 + slot*100 + k'*20 + l'
     __device__ __forceinline__ void load(float (&a)[4][1], int g) const
     {
         const int tap = g >> 1, cg = g & 1;
         const int dn = tap / 9, r = tap - dn * 9, dk = r / 3, dl = r - dk * 3;
-        const int off = ((nrow + dn) % 3) * 100 + dk * 20 + dl + base;
 #pragma unroll
-        for (int p = 0; p < 4; p++) a[p][0] = D[((cg * 4 + p) * 4 + lk) * 300 + off];
+        for (int p = 0; p < 4; p++) a[p][0] = row[dn][(cg * 4 + p) * 1200 + dk * 20 + dl];
     }
 };
 
@@ -94,58 +176,85 @@ __device__ __forceinline__ void cost_row(float* __restrict__ D, const float* __r
 
 // layer 1 contribution of one layer-0 row: A[m=l''][tap=(dk,dl), c] = R[c][dk*18 + l''+dl];  K = tap*32 + c (per dn)
 struct L1Loader {
-    const float* R;
-    int li, lk;
+    const float* base;                                   // R + lk*64 + l''
     __device__ __forceinline__ void load(float (&a)[4][1], int g) const
     {
         const int tap = g >> 1, cg = g & 1;
         const int dk = tap / 3, dl = tap - dk * 3;
-        const int off = dk * 18 + li + dl;
 #pragma unroll
-        for (int p = 0; p < 4; p++) a[p][0] = R[((cg * 4 + p) * 4 + lk) * 64 + off];
+        for (int p = 0; p < 4; p++) a[p][0] = base[(cg * 4 + p) * 256 + dk * 18 + dl];
     }
 };
 
-// layers 2..9: valid (KW x KW) convolution over an LDS-resident [cin][Win*Win] map;  K = (dn*KW + dl)*cin + c
-template <int MT>
-struct ConvLoader {
-    const float* in;
-    int base[MT];          // n*Win + l of the lane's position in tile t (clamped for padding rows)
-    int Win, plane, gpt, KW, lk;
-    __device__ __forceinline__ void load(float (&a)[4][MT], int g) const
-    {
-        const int tap = g / gpt, cg = g - tap * gpt;
-        const int dn = tap / KW, dl = tap - dn * KW;
-        const int off = dn * Win + dl;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const float* ch = in + ((cg * 4 + p) * 4 + lk) * plane + off;
-#pragma unroll
-            for (int t = 0; t < MT; t++) a[p][t] = ch[base[t]];
-        }
-    }
-};
-
-template <int MT, int NT>
+// layers 2..9: valid (KW x KW) convolution over an LDS-resident [CIN][WIN*WIN] map;  K = (dn*KW + dl)*CIN + c.
+// The tap loop is a runtime loop, the CIN/16 channel groups of a tap are unrolled: inside a tap every LDS and
+// weight offset is an immediate on one per-tile base register, so a group of 4 k-steps issues only its loads
+// and MFMAs (the generic runtime-indexed form spent more issue cycles on addresses than on MFMAs).
+// Operands of group g+1 (possibly the first group of the next tap) are loaded while group g multiplies.
+template <int MT, int NT, int CIN, int COUT, int WIN, int KW>
 __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wt,
-                                              const float* __restrict__ bias, int cin, int cout, int Win, int KW, int nt0, bool relu)
+                                              const float* __restrict__ bias, int nt0, bool relu)
 {
+    constexpr int WOUT = WIN - KW + 1, P = WOUT * WOUT, PLANE = WIN * WIN, GPT = CIN / 16, TAPS = KW * KW;
+    static_assert(GPT % 2 == 0, "two pipeline slots alternate per channel group");
     const int lane = threadIdx.x & (WAVE - 1), li = lane & 15, lk = lane >> 4;
-    const int Wout = Win - KW + 1, P = Wout * Wout;
-    ConvLoader<MT> L;
-    L.in = in; L.Win = Win; L.plane = Win * Win; L.gpt = cin >> 4; L.KW = KW; L.lk = lk;
+    const float* pa[MT];                 // lane's A element of tile t at tap (0,0), channel lk
 #pragma unroll
     for (int t = 0; t < MT; t++) {
         int m = t * 16 + li;
-        m = m < P ? m : P - 1;
-        L.base[t] = (m / Wout) * Win + (m % Wout);
+        m = m < P ? m : P - 1;           // padding rows of the last tile recompute position P-1 (never stored)
+        pa[t] = in + lk * PLANE + (m / WOUT) * WIN + (m % WOUT);
     }
+    const float* wl = wt + (size_t)lk * COUT + nt0 * 16 + li;
     cvx4 acc[MT][NT];
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
         for (int u = 0; u < NT; u++) acc[t][u] = (cvx4){ 0.f, 0.f, 0.f, 0.f };
-    cv_gemm<MT, NT>(acc, L, wt + (size_t)lk * cout + nt0 * 16 + li, cout, KW * KW * (cin >> 4));
+    float a[2][4][MT], b[2][4][NT];
+#define CVC_LOAD(SLOT, PTRS, WTAP, CG)                                                                    \
+    {                                                                                                     \
+        cv_gptr wg_ = (cv_gptr)((WTAP) + (CG) * 16 * COUT);                                               \
+        asm volatile("" : "+v"(wg_));                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
+            _Pragma("unroll") for (int u = 0; u < NT; u++) b[SLOT][p][u] = wg_[p * 4 * COUT + u * 16];    \
+        }                                                                                                 \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) a[SLOT][p][t] = PTRS[t][((CG) * 4 + p) * 4 * PLANE]; \
+        }                                                                                                 \
+    }
+    const float* cur[MT];
+    const float* nxt[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) cur[t] = pa[t];
+    const float* wcur = wl;
+    CVC_LOAD(0, cur, wcur, 0)
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; tap++) {
+        const int tn = tap + 1 < TAPS ? tap + 1 : tap;       // the last tap prefetches itself again (unused)
+        const int offn = (tn / KW) * WIN + (tn % KW);
+#pragma unroll
+        for (int t = 0; t < MT; t++) nxt[t] = pa[t] + offn;
+        const float* wnxt = wl + (size_t)tn * CIN * COUT;
+#pragma unroll
+        for (int cg = 0; cg < GPT; cg++) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (cg + 1 < GPT) CVC_LOAD((cg + 1) & 1, cur, wcur, cg + 1)
+            else              CVC_LOAD((cg + 1) & 1, nxt, wnxt, 0)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int t = 0; t < MT; t++)
+#pragma unroll
+                    for (int u = 0; u < NT; u++)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg & 1][p][t], b[cg & 1][p][u], acc[t][u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; t++) cur[t] = nxt[t];
+        wcur = wnxt;
+    }
+#undef CVC_LOAD
 #pragma unroll
     for (int u = 0; u < NT; u++) {
         const int n = (nt0 + u) * 16 + li;
@@ -195,13 +304,14 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     m0 = m0 < 54 ? m0 : 53;
 #pragma unroll 1
     for (int nrow = 0; nrow < 18; nrow++) {
-        cost_row(D, S, T, nrow + 2);         // slot of row nrow-1, which nobody reads any more
+        if (!(CV_EXP & 8)) cost_row(D, S, T, nrow + 2);         // slot of row nrow-1, which nobody reads any more
         __syncthreads();
         {
             L0Loader L;
-            L.D = D; L.nrow = nrow; L.base = (m0 / 18) * 20 + (m0 % 18); L.lk = lk;
+#pragma unroll
+            for (int dn = 0; dn < 3; dn++) L.row[dn] = D + lk * 300 + ((nrow + dn) % 3) * 100 + (m0 / 18) * 20 + (m0 % 18);
             cvx4 acc[1][2] = { { (cvx4){ 0.f, 0.f, 0.f, 0.f }, (cvx4){ 0.f, 0.f, 0.f, 0.f } } };
-            cv_gemm<1, 2>(acc, L, P.wt[0] + (size_t)lk * 32 + li, 32, 27 * 2);
+            if (!(CV_EXP & 1)) cv_gemm_static<1, 2, 4, 54>(acc, L, P.wt[0] + (size_t)lk * 32 + li, 32);
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int n = u * 16 + li;
@@ -214,14 +324,14 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
             }
         }
         __syncthreads();
-        {
+        if (!(CV_EXP & 2)) {
             L1Loader L;
-            L.R = R; L.li = li; L.lk = lk;
+            L.base = R + lk * 64 + li;
             const float* w1 = P.wt[1] + (size_t)lk * 64 + w * 16 + li;
             cvx4 a[1][1];
-            if (nrow <= 15) { a[0][0] = win0; cv_gemm<1, 1>(a, L, w1, 64, 18); win0 = a[0][0]; }                         // dn = 0
-            if (nrow >= 1 && nrow <= 16) { a[0][0] = win1; cv_gemm<1, 1>(a, L, w1 + (size_t)288 * 64, 64, 18); win1 = a[0][0]; }   // dn = 1
-            if (nrow >= 2) { a[0][0] = win2; cv_gemm<1, 1>(a, L, w1 + (size_t)576 * 64, 64, 18); win2 = a[0][0]; }       // dn = 2
+            if (nrow <= 15) { a[0][0] = win0; cv_gemm_static<1, 1, 4, 18>(a, L, w1, 64); win0 = a[0][0]; }                         // dn = 0
+            if (nrow >= 1 && nrow <= 16) { a[0][0] = win1; cv_gemm_static<1, 1, 4, 18>(a, L, w1 + (size_t)288 * 64, 64); win1 = a[0][0]; }   // dn = 1
+            if (nrow >= 2) { a[0][0] = win2; cv_gemm_static<1, 1, 4, 18>(a, L, w1 + (size_t)576 * 64, 64); win2 = a[0][0]; }       // dn = 2
         }
         if (nrow >= 2) {                     // row n'' = nrow-2 is complete
             const int n2 = nrow - 2;
@@ -233,21 +343,22 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     }
 
     // ---- phase B: layers 2..9, ping-pong bufA <-> bufB ---------------------------------------------------
-    cv_conv_layer<13, 1>(bufA, bufB, P.wt[2], P.bias[2], 64, 64, 16, 3, w, true);            // 16x16 -> 14x14
+    if (CV_EXP & 4) return;
+    cv_conv_layer<13, 1, 64, 64, 16, 3>(bufA, bufB, P.wt[2], P.bias[2], w, true);            // 16x16 -> 14x14
     __syncthreads();
-    cv_conv_layer<9, 2>(bufB, bufA, P.wt[3], P.bias[3], 64, 128, 14, 3, 2 * w, true);        // -> 12x12
+    cv_conv_layer<9, 2, 64, 128, 14, 3>(bufB, bufA, P.wt[3], P.bias[3], 2 * w, true);        // -> 12x12
     __syncthreads();
-    cv_conv_layer<7, 2>(bufA, bufB, P.wt[4], P.bias[4], 128, 128, 12, 3, 2 * w, true);       // -> 10x10
+    cv_conv_layer<7, 2, 128, 128, 12, 3>(bufA, bufB, P.wt[4], P.bias[4], 2 * w, true);       // -> 10x10
     __syncthreads();
-    cv_conv_layer<4, 1>(bufB, bufA, P.wt[5], P.bias[5], 128, 64, 10, 3, w, true);            // -> 8x8
+    cv_conv_layer<4, 1, 128, 64, 10, 3>(bufB, bufA, P.wt[5], P.bias[5], w, true);            // -> 8x8
     __syncthreads();
-    cv_conv_layer<3, 1>(bufA, bufB, P.wt[6], P.bias[6], 64, 64, 8, 3, w, true);              // -> 6x6
+    cv_conv_layer<3, 1, 64, 64, 8, 3>(bufA, bufB, P.wt[6], P.bias[6], w, true);              // -> 6x6
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1>(bufB, bufA, P.wt[7], P.bias[7], 64, 32, 6, 3, w, true);   // -> 4x4
+    if (w < 2) cv_conv_layer<1, 1, 64, 32, 6, 3>(bufB, bufA, P.wt[7], P.bias[7], w, true);   // -> 4x4
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1>(bufA, bufB, P.wt[8], P.bias[8], 32, 32, 4, 3, w, true);   // -> 2x2
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 4, 3>(bufA, bufB, P.wt[8], P.bias[8], w, true);   // -> 2x2
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1>(bufB, bufA, P.wt[9], P.bias[9], 32, 32, 2, 2, w, false);  // -> 1x1, 20 (+12 zero) logits
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2>(bufB, bufA, P.wt[9], P.bias[9], w, false);  // -> 1x1, 20 (+12 zero) logits
     __syncthreads();
     if (w == 0) {                            // softmax over the 20 logits, expected index (BUFFER.py:63-65)
         float v = lane < 20 ? bufA[lane] : -3.4e38f;
