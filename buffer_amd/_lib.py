@@ -65,6 +65,7 @@ _SIGNATURES = {
     "buf_patch_voxelize": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp]),
     "buf_cylindrical_net": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_descriptor_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_cost_volume_net": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "buf_hypotheses_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_ransac_ws_bytes": (_sz, [_i]),

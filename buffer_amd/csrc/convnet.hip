@@ -209,3 +209,84 @@ extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* cons
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
+
+
+// ---- A11 (head): attention pooling + normalisation (models/patch_embedder.py:81-84, :66-72) ----------------
+// Reference: w = pool_layer(y) (Conv2d 1x1 32->16, BN, ReLU, Conv2d 1x1 16->1, BN, ReLU), f = mean(y * w) over the
+// 7x20 map, desc = F.normalize(f), equi = F.normalize(y, dim=channel) -- five library launches over [P,32,7,20].
+// Here: one workgroup per patch, the 17.9 KB map sits in LDS; one lane per position evaluates the two 1x1
+// convolutions (BN folded) and the channel norm, then the map is written back normalised and reduced to the
+// 32-vector.  HBM traffic: 17.9 KB in, 17.9 KB + 128 B out per patch.
+#define DH_THREADS 256
+#define DH_C 32
+#define DH_HID 16
+
+struct DescHeadParams {
+    float w0[DH_HID][DH_C];   // pool_layer.0 with pool_layer.1 (BatchNorm) folded
+    float b0[DH_HID];
+    float w3[DH_HID];         // pool_layer.3 with pool_layer.4 folded
+    float b3;
+};
+
+__global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restrict__ y, DescHeadParams H,
+                                                       float* __restrict__ desc, float* __restrict__ equi)
+{
+    __shared__ float ys[DH_C * CN_POS];
+    __shared__ float wgt[CN_POS], nrm[CN_POS], fs[DH_C];
+    const int patch = blockIdx.x, tid = threadIdx.x;
+    const f32x4* src = reinterpret_cast<const f32x4*>(y + (size_t)patch * DH_C * CN_POS);
+    for (int i = tid; i < DH_C * CN_POS / 4; i += DH_THREADS) reinterpret_cast<f32x4*>(ys)[i] = src[i];
+    __syncthreads();
+    if (tid < CN_POS) {
+        float h[DH_HID];
+#pragma unroll
+        for (int j = 0; j < DH_HID; j++) h[j] = H.b0[j];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH_C; c++) {
+            const float v = ys[c * CN_POS + tid];
+            ss += v * v;
+#pragma unroll
+            for (int j = 0; j < DH_HID; j++) h[j] += H.w0[j][c] * v;
+        }
+        float a = H.b3;
+#pragma unroll
+        for (int j = 0; j < DH_HID; j++) a += H.w3[j] * fmaxf(h[j], 0.f);
+        wgt[tid] = fmaxf(a, 0.f);
+        nrm[tid] = fmaxf(sqrtf(ss), 1e-12f);                     // F.normalize: x / max(||x||, eps)
+    }
+    __syncthreads();
+    float* eq = equi + (size_t)patch * DH_C * CN_POS;
+    for (int i = tid; i < DH_C * CN_POS; i += DH_THREADS) eq[i] = ys[i] / nrm[i % CN_POS];
+    {   // f[c] = mean_pos y[c][pos] * w[pos]: 8 lanes per channel
+        const int c = tid >> 3, sub = tid & 7;
+        float acc = 0.f;
+        for (int pos = sub; pos < CN_POS; pos += 8) acc += ys[c * CN_POS + pos] * wgt[pos];
+        acc += __shfl_xor(acc, 1, WAVE);
+        acc += __shfl_xor(acc, 2, WAVE);
+        acc += __shfl_xor(acc, 4, WAVE);
+        if (sub == 0) fs[c] = acc / (float)CN_POS;
+    }
+    __syncthreads();
+    if (tid < DH_C) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH_C; c++) ss += fs[c] * fs[c];
+        desc[(size_t)patch * DH_C + tid] = fs[tid] / fmaxf(sqrtf(ss), 1e-12f);
+    }
+}
+
+// y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].  w0 [16][32], b0 [16], w3 [16], b3 [1]: HOST arrays (BN folded).
+extern "C" int buf_descriptor_head(const float* y, int npatch, const float* w0_host, const float* b0_host,
+                                   const float* w3_host, const float* b3_host, float* desc, float* equi, void* stream)
+{
+    BUF_REQUIRE(npatch >= 0, BUF_EINVAL, "buf_descriptor_head: npatch=%d", npatch);
+    if (npatch == 0) return BUF_OK;
+    BUF_REQUIRE(y && w0_host && b0_host && w3_host && b3_host && desc && equi, BUF_EINVAL, "buf_descriptor_head: null argument");
+    DescHeadParams H;
+    memcpy(H.w0, w0_host, sizeof(H.w0)); memcpy(H.b0, b0_host, sizeof(H.b0));
+    memcpy(H.w3, w3_host, sizeof(H.w3)); H.b3 = b3_host[0];
+    k_desc_head<<<npatch, DH_THREADS, 0, (hipStream_t)stream>>>(y, H, desc, equi);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

@@ -71,6 +71,7 @@ class PatchEmbedder:
         w3, b3 = _fold_bn(W[f'{q}.3.weight'], W[f'{q}.3.bias'], W[f'{q}.4.running_mean'], W[f'{q}.4.running_var'],
                           W[f'{q}.4.weight'], W[f'{q}.4.bias'])
         self.pool = [(t(w0), t(b0)), (t(w3), t(b3))]
+        self.fused_head = ops.DescriptorHead(w0, b0, w3, b3)
 
     @staticmethod
     def _pad(x):
@@ -87,7 +88,11 @@ class PatchEmbedder:
         return F.conv2d(self._pad(x), *self.last)
 
     def head(self, x):
-        """attention pooling + normalisation (patch_embedder.py:81-84)."""
+        """attention pooling + normalisation (patch_embedder.py:81-84), one fused launch."""
+        return self.fused_head(x)
+
+    def head_library(self, x):
+        """the same head on library convolutions (kept for A/B measurement and the parity test)."""
         w = F.relu(F.conv2d(x, *self.pool[0]))
         w = F.relu(F.conv2d(w, *self.pool[1]))
         f = (x * w).mean((2, 3))
@@ -121,7 +126,7 @@ class PatchEmbedder:
         else:       # library convolutions (kept for A/B measurement)
             for s in range(0, x.shape[0], chunk):
                 y = self.conv_net(x[s:s + chunk].view(-1, 16, cfg.rad_n, cfg.ele_n, cfg.azi_n))
-                f, e = self.head(y)
+                f, e = self.head_library(y)
                 descs.append(f); equis.append(e)
         out = dict(desc=torch.cat(descs), equi=torch.cat(equis), R=R, rand_axis=rand_axis, x=x)
         if want_patches:

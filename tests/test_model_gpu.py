@@ -140,6 +140,24 @@ def test_fused_cylindrical_net_vs_library_convs(W, dev):
     assert (got - want).abs().max().item() < 2e-5 * max(scale, 1.0)
 
 
+def test_fused_descriptor_head_vs_library(W, dev):
+    """k_desc_head (attention pooling + both normalisations in one launch) == the torch restatement
+    (patch_embedder.py:81-84) on conv-net outputs, on an all-zero map (eps clamps) and on P = 0."""
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    pe = PatchEmbedder(W, dev, THREEDMATCH)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.rand((41, 16, 420), generator=g).to(dev)
+    y = pe.fused(x)
+    y[5] = 0.0
+    want_d, want_e = pe.head_library(y)
+    got_d, got_e = pe.head(y)
+    np.testing.assert_allclose(got_d.cpu().numpy(), want_d.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got_e.cpu().numpy(), want_e.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    d0, e0 = pe.head(y[:0])
+    assert d0.shape == (0, 32) and e0.shape == (0, 32, 7, 20)
+
+
 def test_fused_cost_volume_vs_library_convs(W, dev):
     """csrc/costnet.hip (cost volume never materialised, sliding-window layer 0/1 fusion) == torch convolutions."""
     from buffer_amd import registration
