@@ -3,9 +3,13 @@
 //
 // Reference: axis_align -> normalize -> sphere_query (420 ball queries of 10 samples per patch,
 // materialising [P,420,10,3]) -> var_to_invar -> Conv2d1x1(3->16)+BN+ReLU -> max over the 10 samples.
-// Here: one workgroup per patch; the aligned, normalised 512-point patch sits in LDS (8 KB); one lane
-// per cylindrical voxel centre scans it in index order (LDS broadcast reads) and notes its first 10 hits;
-// then all centre lanes run the azimuth de-rotation, the 3->16 MLP, BN, ReLU and the running max slot by slot.
+// Here: one workgroup per patch; the aligned, normalised 512-point patch sits in LDS (8 KB).
+//   1. point-parallel: every point looks up the voxel balls that can contain it (a 16^3 lookup grid over the
+//      unit ball, cell -> candidate centres, built once per call) and sets its bit in the hit mask of each
+//      ball that does (exact d^2 test, LDS atomicOr) -- ~19 tests per point instead of 420;
+//   2. centre-parallel: one lane per voxel centre reads its mask in index order and notes its first 10 hits
+//      (= pointnet2 ball_query's "first nsample in index order");
+//   3. all centre lanes run the azimuth de-rotation, the 3->16 MLP, BN, ReLU and the running max slot by slot.
 // HBM traffic: 6 KB in, 26.9 KB out per patch; [P,420,10,3] never exists.
 #include "common.h"
 
@@ -13,29 +17,42 @@
 #define VOX_MAXPTS 1024
 #define VOX_CH 16
 #define VOX_MAXS 16           // max samples per voxel kept in the hit list
+#define VOX_GRID 16           // lookup grid cells per axis
+#ifndef VOX_EXP
+#define VOX_EXP 0             // timing experiments only: 1 no phase 1, 2 no phase 2, 4 no phase 3, 8 no Rodrigues, 16 no stores
+#endif
+#define VOX_PP 4              // points per step of a lane group in phase 1
+#define VOX_SENT 0xFFFFu      // end-of-list filler of a lookup row
 
-struct VoxMlp {
-    float w[VOX_CH][3];     // Desc.pnt_layer.0.weight
-    float b[VOX_CH];        // Desc.pnt_layer.0.bias
-    float s[VOX_CH];        // BN folded: gamma / sqrt(var + 1e-5)
-    float t[VOX_CH];        //            beta - mean * s
+// entries per lookup row: the cell's candidate centres, then at least 24 VOX_SENT (a lane group reads 24 unconditionally)
+__host__ __device__ static inline int vox_row_stride(int ncentres) { return ((ncentres + 7) & ~7) + 24; }
+
+struct VoxMlp {             // Conv2d1x1(3->16) with the eval-mode BatchNorm folded in: 64 scalars, SGPR-resident
+    float w[VOX_CH][3];     // s * Desc.pnt_layer.0.weight,  s = gamma / sqrt(var + 1e-5)
+    float b[VOX_CH];        // s * Desc.pnt_layer.0.bias + (beta - mean * s)
 };
 
 __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __restrict__ patches, const float* __restrict__ axis,
                                                              int npts, float des_r, const float* __restrict__ centres,
                                                              int ncentres, int azi_n, const float* __restrict__ azi_cs,
                                                              float voxel_r2, int nsample, VoxMlp M,
+                                                             const float* __restrict__ tab_hdr, const unsigned short* __restrict__ tab,
                                                              float* __restrict__ out_x, float* __restrict__ out_R,
                                                              float* __restrict__ out_rand, float* __restrict__ out_patches)
 {
-    __shared__ float4 pts[VOX_MAXPTS];
+    // dynamic LDS, sized by the launch (52.8 KB at 512 points x 10 samples -> three workgroups per CU):
+    extern __shared__ float4 pts[];                              // [npts] aligned, normalised patch
+    const int W = (npts + 31) >> 5;                              // mask words per centre
+    unsigned* mask = reinterpret_cast<unsigned*>(pts + npts);    // [W][VOX_THREADS] hit bits
+    unsigned short* hits = reinterpret_cast<unsigned short*>(mask + W * VOX_THREADS);   // [nsample][VOX_THREADS]
+    __shared__ float4 cen[VOX_THREADS];
     __shared__ float Rs[9];
     const int p = blockIdx.x, tid = threadIdx.x;
     const float* src = patches + (size_t)p * npts * 3;
     if (tid == 0) {
         float R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
         float rx = 1.f, ry = 0.f, rz = 0.f;                      // KITTI/ETH: rand_axis = e_x, R = I (:143-147)
-        if (axis) {
+        if (axis && !(VOX_EXP & 8)) {
             // RodsRotatFormula(z_axis, e_z) (utils/common.py:501-525), returned transposed
             float ax = axis[3 * (size_t)p], ay = axis[3 * (size_t)p + 1], az = axis[3 * (size_t)p + 2];
             float cx = ay, cy = -ax, cz = 0.f;                   // a x e_z
@@ -78,66 +95,156 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
 
     const int c = tid;
     const bool active = c < ncentres;
-    float cx = 0.f, cy = 0.f, cz = 0.f, ca = 1.f, sa = 0.f;
-    if (active) {
-        cx = centres[3 * c]; cy = centres[3 * c + 1]; cz = centres[3 * c + 2];
-        int az = c % azi_n;                                      // ordering rad -> ele -> azi (utils/common.py:422-428)
-        ca = azi_cs[2 * az]; sa = azi_cs[2 * az + 1];            // cos/sin of -az * 2pi/azi_n (:485-491)
-    }
-    // Phase 1: every centre lane records the indices of its first `nsample` hits (index order).  Only a tiny
-    // store sits in the divergent branch: running the 16-channel MLP right here would execute it once per point
-    // for one or two active lanes (a point is inside ~8 of the 420 balls).
-    __shared__ unsigned short hits[VOX_MAXS][VOX_THREADS];
-    int cnt = 0, nreal = 0;                                      // accepted samples / samples kept in the list
-    bool zero_slot = false;
-    // branch-light scan, 8 points per step so that the LDS reads of a step are in flight together
-    for (int k0 = 0; k0 < npts; k0 += 8) {
-        float4 q[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) q[j] = pts[min(k0 + j, npts - 1)];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = k0 + j;
-            const bool hit = active && k < npts && cnt < nsample && sqdist3(cx, cy, cz, q[j].x, q[j].y, q[j].z) < voxel_r2;
-            const bool keep = hit && k != 0;                     // utils/common.py:447-449: a hit on point 0 is zeroed
-            if (keep) hits[nreal][tid] = (unsigned short)k;
-            nreal += keep ? 1 : 0;
-            cnt += hit ? 1 : 0;
-            zero_slot = zero_slot || (hit && k == 0);
+    float ca = 1.f, sa = 0.f;
+    {
+        float4 cc = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+        if (active) {
+            cc = make_float4(centres[3 * c], centres[3 * c + 1], centres[3 * c + 2], 0.f);
+            int az = c % azi_n;                                  // ordering rad -> ele -> azi (utils/common.py:422-428)
+            ca = azi_cs[2 * az]; sa = azi_cs[2 * az + 1];        // cos/sin of -az * 2pi/azi_n (:485-491)
         }
-        if ((k0 & 31) == 24 && !__any(active && cnt < nsample)) break;
+        cen[tid] = cc;
     }
-    // Phase 2: slot by slot, all centre lanes evaluate de-rotation -> 3->16 MLP -> BN -> ReLU -> running max together.
-    float acc[VOX_CH];
+    for (int i = tid; i < W * VOX_THREADS; i += VOX_THREADS) mask[i] = 0u;
+    __syncthreads();
+    // Phase 1: 8 lanes share a point and split its candidate list; VOX_PP points per step so that 3*VOX_PP table
+    // loads (L2 hits) are in flight per lane.  The d^2 test is the one a full scan would do (same operand order),
+    // the lookup grid only removes centres that cannot pass it.  Rows end in >= 8 VOX_SENT entries.
+    if (!(VOX_EXP & 1)) {
+        const float lo = tab_hdr[0], inv_h = tab_hdr[1];
+        const int sub = tid & 7, rs = vox_row_stride(ncentres);
+        auto test = [&](unsigned short cj, const float4& q, unsigned* mrow, unsigned bit) {
+            if (cj == VOX_SENT) return;
+            const float4 cc = cen[cj];
+            if (sqdist3(cc.x, cc.y, cc.z, q.x, q.y, q.z) < voxel_r2) atomicOr(&mrow[cj], bit);
+        };
+        for (int k0 = tid >> 3; k0 < npts; k0 += VOX_PP * (VOX_THREADS / 8)) {
+            float4 q[VOX_PP];
+            const unsigned short* row[VOX_PP];
+            bool ok[VOX_PP];
+            unsigned short e[VOX_PP][3];
 #pragma unroll
-    for (int ch = 0; ch < VOX_CH; ch++) acc[ch] = -3.4e38f;
-    for (int sidx = 0; __any(sidx < nreal); sidx++) {
-        if (sidx < nreal) {
-            float4 q = pts[hits[sidx][tid]];
-            float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz = q.z;
+            for (int u = 0; u < VOX_PP; u++) {
+                const int k = k0 + u * (VOX_THREADS / 8);
+                q[u] = pts[k < npts ? k : npts - 1];
+                const int ix = (int)floorf((q[u].x - lo) * inv_h), iy = (int)floorf((q[u].y - lo) * inv_h),
+                          iz = (int)floorf((q[u].z - lo) * inv_h);
+                ok[u] = k < npts && ix >= 0 && iy >= 0 && iz >= 0 && ix < VOX_GRID && iy < VOX_GRID && iz < VOX_GRID;
+                row[u] = tab + (ok[u] ? (size_t)((ix * VOX_GRID + iy) * VOX_GRID + iz) * rs : 0);   // else: outside every ball
+            }
 #pragma unroll
-            for (int ch = 0; ch < VOX_CH; ch++) {
-                float h = M.w[ch][0] * nx + M.w[ch][1] * ny + M.w[ch][2] * nz + M.b[ch];
-                acc[ch] = fmaxf(acc[ch], fmaxf(h * M.s[ch] + M.t[ch], 0.f));
+            for (int u = 0; u < VOX_PP; u++)
+#pragma unroll
+                for (int v = 0; v < 3; v++) e[u][v] = row[u][sub + 8 * v];
+#pragma unroll
+            for (int u = 0; u < VOX_PP; u++) {
+                if (!ok[u]) continue;
+                const int k = k0 + u * (VOX_THREADS / 8);
+                const unsigned bit = 1u << (k & 31);
+                unsigned* mrow = mask + (k >> 5) * VOX_THREADS;
+#pragma unroll
+                for (int v = 0; v < 3; v++) test(e[u][v], q[u], mrow, bit);
+                // long list (points near the keypoint): four more entries per lane at a time
+                for (int j = sub + 24; j < rs && e[u][2] != VOX_SENT; j += 32) {
+                    unsigned short f[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) f[v] = row[u][min(j + 8 * v, rs - 1)];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) test(f[v], q[u], mrow, bit);
+                    e[u][2] = f[3];
+                }
             }
         }
     }
-    if (active) {
+    __syncthreads();
+    // Phase 2: every centre lane lists its first `nsample` hits in index order.
+    int cnt = 0, nreal = 0;                                      // accepted samples / samples kept in the list
+    bool zero_slot = false;
+    if (active && !(VOX_EXP & 2)) {
+        for (int w = 0; w < W && cnt < nsample; w++) {
+            unsigned word = mask[w * VOX_THREADS + tid];
+            while (word && cnt < nsample) {
+                const int k = w * 32 + __ffs(word) - 1;
+                word &= word - 1;
+                if (k != 0) hits[(nreal++) * VOX_THREADS + tid] = (unsigned short)k;   // utils/common.py:447-449: a hit on point 0 is zeroed
+                else zero_slot = true;
+                cnt++;
+            }
+        }
+    }
+    // Phase 3: slot by slot, all centre lanes evaluate de-rotation -> 3->16 MLP -> BN -> ReLU -> running max together.
+    float acc[VOX_CH];
+#pragma unroll
+    for (int ch = 0; ch < VOX_CH; ch++) acc[ch] = -3.4e38f;
+    for (int sidx = 0; !(VOX_EXP & 4) && __any(sidx < nreal); sidx++) {
+        if (sidx < nreal) {
+            float4 q = pts[hits[sidx * VOX_THREADS + tid]];
+            float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz = q.z;
+#pragma unroll
+            for (int ch = 0; ch < VOX_CH; ch++) {
+                const float h = fmaf(M.w[ch][2], nz, fmaf(M.w[ch][1], ny, fmaf(M.w[ch][0], nx, M.b[ch])));
+                acc[ch] = fmaxf(fmaxf(acc[ch], h), 0.f);         // v_max3: ReLU and the running max
+            }
+        }
+    }
+    if (active && !(VOX_EXP & 16)) {
         bool padded = cnt < nsample || zero_slot;                // zeroed slots go through the MLP as the origin
 #pragma unroll
         for (int ch = 0; ch < VOX_CH; ch++) {
             float v = acc[ch];
-            if (padded) v = fmaxf(v, fmaxf(M.b[ch] * M.s[ch] + M.t[ch], 0.f));
+            if (padded) v = fmaxf(v, fmaxf(M.b[ch], 0.f));
             out_x[((size_t)p * VOX_CH + ch) * ncentres + c] = v;
         }
     }
+}
+
+// Lookup grid over [-L, L]^3, L = max |centre coordinate| + r: cell -> the centres whose ball can reach the cell
+// (box-to-centre distance <= r plus a rounding margin).  tab[cell][0..n) = centre ids, the rest of the row VOX_SENT.
+__global__ void __launch_bounds__(WAVE) k_vox_table(const float* __restrict__ centres, int ncentres, float r,
+                                                    float* __restrict__ hdr, unsigned short* __restrict__ tab)
+{
+    // one wavefront per cell; lanes stride over the centres and append in centre order (ballot prefix)
+    const int cell = blockIdx.x, lane = threadIdx.x;
+    float L = 0.f;
+    for (int i = lane; i < 3 * ncentres; i += WAVE) L = fmaxf(L, fabsf(centres[i]));
+    for (int d = WAVE / 2; d > 0; d >>= 1) L = fmaxf(L, __shfl_xor(L, d, WAVE));
+    L += r;
+    const float h = 2.f * L / (float)VOX_GRID;
+    if (cell == 0 && lane == 0) { hdr[0] = -L; hdr[1] = 1.f / h; hdr[2] = h; hdr[3] = 0.f; }
+    const int ix = cell / (VOX_GRID * VOX_GRID), iy = (cell / VOX_GRID) % VOX_GRID, iz = cell % VOX_GRID;
+    const float bx = -L + ix * h, by = -L + iy * h, bz = -L + iz * h;
+    const float rr = r * 1.001f + 1e-3f * h;
+    const int rs = vox_row_stride(ncentres);
+    unsigned short* list = tab + (size_t)cell * rs;
+    int n = 0;
+    for (int c0 = 0; c0 < ncentres; c0 += WAVE) {
+        const int c = c0 + lane;
+        bool in = false;
+        if (c < ncentres) {
+            const float cx = centres[3 * c], cy = centres[3 * c + 1], cz = centres[3 * c + 2];
+            const float dx = fmaxf(fmaxf(bx - cx, cx - (bx + h)), 0.f);
+            const float dy = fmaxf(fmaxf(by - cy, cy - (by + h)), 0.f);
+            const float dz = fmaxf(fmaxf(bz - cz, cz - (bz + h)), 0.f);
+            in = dx * dx + dy * dy + dz * dz <= rr * rr;
+        }
+        const unsigned long long m = __ballot(in);
+        if (in) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)c;
+        n += __popcll(m);
+    }
+    for (int i = n + lane; i < rs; i += WAVE) list[i] = (unsigned short)VOX_SENT;
+}
+
+extern "C" size_t buf_patch_voxelize_ws_bytes(int ncentres)
+{
+    if (ncentres <= 0) return 0;
+    return 256 + sizeof(unsigned short) * (size_t)VOX_GRID * VOX_GRID * VOX_GRID * (size_t)vox_row_stride(ncentres);
 }
 
 extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int npatch, int npts, float des_r,
                                   const float* centres, int ncentres, int azi_n, const float* azi_cs, float voxel_r,
                                   int nsample, const float* mlp_w, const float* mlp_b, const float* bn_scale,
                                   const float* bn_shift, float* out_x, float* out_R, float* out_rand, float* out_patches,
-                                  void* stream)
+                                  void* ws, size_t ws_bytes, void* stream)
 {
     BUF_REQUIRE(npatch >= 0 && npts > 0 && npts <= VOX_MAXPTS, BUF_EINVAL, "buf_patch_voxelize: npts=%d (max %d)", npts, VOX_MAXPTS);
     BUF_REQUIRE(nsample <= VOX_MAXS, BUF_EINVAL, "buf_patch_voxelize: nsample=%d (max %d)", nsample, VOX_MAXS);
@@ -146,12 +253,28 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
     if (npatch == 0) return BUF_OK;
     BUF_REQUIRE(patches && centres && azi_cs && mlp_w && mlp_b && bn_scale && bn_shift && out_x && out_R && out_rand,
                 BUF_EINVAL, "buf_patch_voxelize: null argument");
+    BUF_REQUIRE(ws && ws_bytes >= buf_patch_voxelize_ws_bytes(ncentres), BUF_EWORKSPACE,
+                "buf_patch_voxelize: workspace of %zu bytes, need %zu", ws_bytes, buf_patch_voxelize_ws_bytes(ncentres));
+    float* hdr = (float*)ws;
+    unsigned short* tab = (unsigned short*)((char*)ws + 256);
+    const int ncell = VOX_GRID * VOX_GRID * VOX_GRID;
+    k_vox_table<<<ncell, WAVE, 0, (hipStream_t)stream>>>(centres, ncentres, voxel_r, hdr, tab);
+    BUF_LAUNCH_CHECK();
     VoxMlp M;   // host copies of the 16x3 MLP (HOST pointers: tiny, passed by value to the kernel)
-    memcpy(M.w, mlp_w, sizeof(M.w)); memcpy(M.b, mlp_b, sizeof(M.b));
-    memcpy(M.s, bn_scale, sizeof(M.s)); memcpy(M.t, bn_shift, sizeof(M.t));
-    k_patch_voxelize<<<npatch, VOX_THREADS, 0, (hipStream_t)stream>>>(patches, axis, npts, des_r, centres, ncentres, azi_n,
-                                                                    azi_cs, voxel_r * voxel_r, nsample, M, out_x, out_R,
-                                                                    out_rand, out_patches);
+    for (int ch = 0; ch < VOX_CH; ch++) {
+        for (int j = 0; j < 3; j++) M.w[ch][j] = bn_scale[ch] * mlp_w[3 * ch + j];
+        M.b[ch] = bn_scale[ch] * mlp_b[ch] + bn_shift[ch];
+    }
+    const size_t lds = sizeof(float4) * (size_t)npts + sizeof(unsigned) * (size_t)((npts + 31) / 32) * VOX_THREADS +
+                       sizeof(unsigned short) * (size_t)nsample * VOX_THREADS;
+    static size_t lds_allowed = 48 * 1024;
+    if (lds > lds_allowed) {
+        BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_patch_voxelize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_allowed = lds;
+    }
+    k_patch_voxelize<<<npatch, VOX_THREADS, lds, (hipStream_t)stream>>>(patches, axis, npts, des_r, centres, ncentres, azi_n,
+                                                                      azi_cs, voxel_r * voxel_r, nsample, M, hdr, tab, out_x,
+                                                                      out_R, out_rand, out_patches);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

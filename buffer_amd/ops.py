@@ -334,9 +334,11 @@ def patch_voxelize(patches, axis, des_r, centres, azi_cs, voxel_r, nsample, mlp_
     ra = torch.empty((P, 3), dtype=torch.float32, device=dev)
     pn = torch.empty((P, S, 3), dtype=torch.float32, device=dev) if want_patches else None
     hw = [np.ascontiguousarray(a, dtype=np.float32) for a in (mlp_w, mlp_b, bn_scale, bn_shift)]
+    wsb = L.buf_patch_voxelize_ws_bytes(nc)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     check(L.buf_patch_voxelize(_ptr(patches), _ptr(axis), P, S, float(des_r), _ptr(centres), nc, int(azi_n),
                                _ptr(azi_cs), float(voxel_r), int(nsample), _hptr(hw[0]), _hptr(hw[1]), _hptr(hw[2]),
-                               _hptr(hw[3]), _ptr(x), _ptr(R), _ptr(ra), _ptr(pn), _stream()), "buf_patch_voxelize")
+                               _hptr(hw[3]), _ptr(x), _ptr(R), _ptr(ra), _ptr(pn), _ptr(ws), wsb, _stream()), "buf_patch_voxelize")
     return x, R, ra, pn
 
 

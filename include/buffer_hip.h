@@ -186,12 +186,15 @@ int     buf_vn_std(const float* x, const float* z, int n, int c, float* out, voi
  * centres f32[ncentres,3]; azi_cs f32[azi_n,2] = cos,sin of -i*2pi/azi_n; mlp_* are HOST arrays
  * (w[16,3], b[16], bn_scale[16], bn_shift[16]).  out_x f32[np,16,ncentres]; out_R f32[np,3,3];
  * out_rand f32[np,3]; out_patches (nullable) f32[np,npts,3].
+ * ws: device workspace of buf_patch_voxelize_ws_bytes(ncentres) bytes (cell -> candidate-centre lookup grid,
+ * rebuilt by every call; BUF_EWORKSPACE when too small).
  */
+size_t  buf_patch_voxelize_ws_bytes(int ncentres);
 int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, int npts, float des_r,
                            const float* centres, int ncentres, int azi_n, const float* azi_cs, float voxel_r,
                            int nsample, const float* mlp_w_host, const float* mlp_b_host, const float* bn_scale_host,
                            const float* bn_shift_host, float* out_x, float* out_R, float* out_rand, float* out_patches,
-                           void* stream);
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A11 (dense)  Cylindrical_Net (models/patchnet.py:15-85) fused: Conv3d(16->64,3^3) + 7 x Conv2d 3x3 with the
