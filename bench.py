@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+COST_NET_FLOPS_PER_MATCH = 159994880.0   # csrc/costnet.hip (0.160 GFLOP/match)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32), 64 FLOP/clk/SIMD
 
 
 def parse():
@@ -171,8 +173,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     L.buf_timing_enable(0)
-    ms, by = C.c_double(0), C.c_double(0)
-    launches = L.buf_timing_collect(C.byref(ms), C.byref(by))
+    timed = {}
+    for kid, name in ((0, 'grid_query'), (1, 'cyl_net'), (2, 'cost_net')):
+        ms, work = C.c_double(0), C.c_double(0)
+        n = L.buf_timing_collect_kernel(kid, C.byref(ms), C.byref(work))
+        timed[name] = (int(n), ms.value, work.value)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -189,13 +194,23 @@ def main():
 
     if rank == 0:
         pairs = world * a.steps * a.pairs_per_step
-        achieved = (by.value / launches) / (ms.value / launches * 1e-3) / 1e9 if launches else 0.0
-        traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
-            per_pair = json.load(open(tpath)).get('k_grid_query_hbm_bytes_per_launch_per_pair')
-            # measured offline with rocprofv3 --pmc (profiles/traffic.json); a launch covers every pair of the step
-            traffic = per_pair * (a.pairs_per_step / nconc if a.mode == 'batch' else 1) if per_pair else None
+        pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        per_launch = a.pairs_per_step / nconc if a.mode == 'batch' else 1      # pairs covered by one launch
+
+        def roof(name, label, bound, peak, unit, scale, traffic):
+            n, ms, work = timed[name]
+            ach = (work / n) / (ms / n * 1e-3) / scale if n else 0.0
+            return {'kernel': label, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak,
+                    'traffic': traffic, 'launches': n, 'avg_us': (ms / n * 1e3) if n else None,
+                    'avg_algorithmic_' + ('bytes' if bound == 'hbm' else 'flops'): (work / n) if n else None}
+
+        # HBM bytes per launch measured offline with rocprofv3 --pmc (profiles/traffic.json, separate passes)
+        t_cyl = pmc.get('k_cyl_net_hbm_bytes_per_patch')
+        t_cost = pmc.get('k_cost_net_hbm_bytes_per_match')
+        t_grid = pmc.get('k_grid_query_hbm_bytes_per_launch_per_pair')
+        npatch = 2 * a.keypts * per_launch
+        gpu_ms = {k: v[1] / a.steps for k, v in timed.items()}
         out = {
             'metric': 'registration pairs/sec', 'value': pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -208,10 +223,15 @@ def main():
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,
                        'weights': '3DMatch 06132318 (released)', 'parallelism': f'pair-sharded x{world}',
                        'registered_ok': f'{ok}/{len(all_poses)} (rank 0, RTE<0.3 m & RRE<15 deg)'},
-            'roofline': {'kernel': 'k_grid_query (A2 radius neighbours)', 'bound': 'hbm', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'launches': int(launches), 'avg_us': (ms.value / launches * 1e3) if launches else None,
-                         'avg_algorithmic_bytes': (by.value / launches) if launches else None},
+            # the dominant kernel of the step (k_cyl_net: ~60 % of the GPU time, profiles/r01_kernel_stats.csv)
+            'roofline': roof('cyl_net', 'k_cyl_net (A11 Cylindrical_Net, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s',
+                             1e12, t_cyl * npatch if t_cyl else None),
+            'roofline_other': [
+                roof('cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s',
+                     1e12, t_cost * timed['cost_net'][2] / max(timed['cost_net'][0], 1) / COST_NET_FLOPS_PER_MATCH if t_cost else None),
+                roof('grid_query', 'k_grid_query (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                     t_grid * per_launch if t_grid else None)],
+            'timed_kernel_ms_per_step': gpu_ms,
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits, a.keypts, a.cpu_keypts)

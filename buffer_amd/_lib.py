@@ -38,6 +38,7 @@ _SIGNATURES = {
     "buf_device_count": (_i, []),
     "buf_timing_enable": (None, [_i]),
     "buf_timing_collect": (C.c_longlong, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "buf_timing_collect_kernel": (C.c_longlong, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "buf_grid_default_cells": (_i64, [_i, _i]),
     "buf_grid_ws_bytes": (_sz, [_i, _i, _i64]),
     "buf_grid_build": (_i, [C.POINTER(buf_grid_t), _vp, _i, _vp, _i, _f, _i64, _vp, _sz, _vp]),

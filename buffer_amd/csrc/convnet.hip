@@ -205,7 +205,13 @@ extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* cons
         BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cyl_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // algorithmic flops of this launch: 2 * 140 positions * sum over layers of 9*Cin*Cout, per patch (0.1186 GFLOP)
+    double macs = 0;
+    for (int l = 0; l < CN_LAYERS; l++) macs += 9.0 * P.cin[l] * P.cout[l];
+    TimedSpan span;
+    bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * CN_POS * macs * npatch, BUF_TIMED_CYL_NET);
     k_cyl_net<<<npatch, CN_THREADS, lds, (hipStream_t)stream>>>(x, P, y);
+    if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

@@ -16,20 +16,22 @@ extern "C" const char* buf_last_error(void) { return g_err; }
 extern "C" int buf_version(void) { return 100; }
 
 // ------------------------------------------------------------------------------------------
-// Optional per-kernel timing for bench.py's roofline line: HIP events recorded on the launch
-// stream directly around the dominant kernel (k_grid_query).  Off by default; profiling state only.
+// Optional per-kernel timing for bench.py's roofline objects: HIP events recorded on the launch stream
+// directly around the kernels below.  Off by default; profiling state only.
+// kernel ids: BUF_TIMED_* of include/buffer_hip.h
 #include <mutex>
 #include <vector>
-struct TimedSpan { hipEvent_t a, b; double bytes; };
+struct TimedSpan { hipEvent_t a, b; double bytes; int id; };   // bytes = algorithmic bytes (HBM kernels) or flops (MFMA kernels)
 static std::mutex g_time_mu;
 static std::vector<TimedSpan> g_spans;
 static int g_timing_on = 0;
 
 extern "C" void buf_timing_enable(int on) { std::lock_guard<std::mutex> l(g_time_mu); g_timing_on = on; }
 
-static bool timing_begin(hipStream_t s, TimedSpan* sp, double bytes)
+static bool timing_begin(hipStream_t s, TimedSpan* sp, double bytes, int id = BUF_TIMED_GRID_QUERY)
 {
     if (!g_timing_on) return false;
+    sp->id = id;
     if (hipEventCreate(&sp->a) != hipSuccess || hipEventCreate(&sp->b) != hipSuccess) return false;
     sp->bytes = bytes;
     (void)hipEventRecord(sp->a, s);
@@ -43,21 +45,28 @@ static void timing_end(hipStream_t s, TimedSpan* sp)
     g_spans.push_back(*sp);
 }
 
-// Synchronises on the recorded events; returns the number of launches collected and resets.
-extern "C" long long buf_timing_collect(double* total_ms, double* total_bytes)
+// Synchronises on the recorded events of kernel `id`; returns the number of launches collected and drops them.
+extern "C" long long buf_timing_collect_kernel(int id, double* total_ms, double* total_work)
 {
     std::lock_guard<std::mutex> l(g_time_mu);
     double ms = 0, by = 0;
     long long n = 0;
+    std::vector<TimedSpan> keep;
     for (auto& sp : g_spans) {
+        if (sp.id != id) { keep.push_back(sp); continue; }
         float t = 0.f;
         if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) { ms += t; by += sp.bytes; n++; }
         (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
     }
-    g_spans.clear();
+    g_spans.swap(keep);
     if (total_ms) *total_ms = ms;
-    if (total_bytes) *total_bytes = by;
+    if (total_work) *total_work = by;
     return n;
+}
+
+extern "C" long long buf_timing_collect(double* total_ms, double* total_bytes)
+{
+    return buf_timing_collect_kernel(BUF_TIMED_GRID_QUERY, total_ms, total_bytes);
 }
 
 extern "C" int buf_device_count(void)

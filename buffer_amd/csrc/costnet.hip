@@ -389,7 +389,15 @@ extern "C" int buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, 
         BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cost_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // algorithmic flops per match (valid convolutions 20x5x20 -> 18x3x18 -> 16x1x16 -> 14 -> 12 -> 10 -> 8 -> 6 -> 4 -> 2 -> 1):
+    // 2 * sum(out positions * K * Cout) = 0.160 GFLOP
+    static const double macs_per_match =
+        972.0 * 864 * 32 + 256.0 * 864 * 64 + 196.0 * 576 * 64 + 144.0 * 576 * 128 + 100.0 * 1152 * 128 + 64.0 * 1152 * 64 +
+        36.0 * 576 * 64 + 16.0 * 576 * 32 + 4.0 * 288 * 32 + 1.0 * 128 * 20;
+    TimedSpan span;
+    bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * macs_per_match * m, BUF_TIMED_COST_NET);
     k_cost_net<<<m, CV_THREADS, lds, (hipStream_t)stream>>>(s_eq, t_eq, P, ind_out);
+    if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

@@ -41,11 +41,17 @@ const char* buf_last_error(void);
 int         buf_version(void);
 /* Number of visible HIP devices (<0 on error); does not create a context. */
 int         buf_device_count(void);
-/* Measurement aid (off by default): when enabled, buf_grid_query brackets its kernel with HIP events on
- * the launch stream; buf_timing_collect synchronises on them, returns the number of launches and
- * their summed duration / algorithmic bytes, and resets. */
+/* Measurement aid (off by default): when enabled, buf_grid_query (kernel id 0), buf_cylindrical_net (1) and
+ * buf_cost_volume_net (2) bracket their kernel with HIP events on the launch stream.
+ * buf_timing_collect_kernel synchronises on the events of one kernel id, returns the number of launches and
+ * their summed duration / algorithmic work (bytes for id 0, flops for ids 1 and 2), and drops them.
+ * buf_timing_collect = buf_timing_collect_kernel(0, ...). */
+#define BUF_TIMED_GRID_QUERY 0
+#define BUF_TIMED_CYL_NET    1
+#define BUF_TIMED_COST_NET   2
 void        buf_timing_enable(int on);
 long long   buf_timing_collect(double* total_ms, double* total_bytes);
+long long   buf_timing_collect_kernel(int kernel_id, double* total_ms, double* total_work);
 
 /* ------------------------------------------------------------------------------------------
  * A2  radius neighbours -- cpp_neighbors.batch_query (neighbors.cpp:211-332).
