@@ -14,6 +14,7 @@
 // row-major, 1.7 MB for the whole net, L2-resident) stream from global memory through a register ring.
 // HBM traffic per patch: 26.9 KB in, 17.9 KB out.
 #include "common.h"
+#include <type_traits>
 
 #define CN_POS 140            // 7 elevation x 20 azimuth
 #define CN_STR 144            // LDS channel stride: 144 mod 32 = 16 keeps the 4 channel groups of a fragment on disjoint banks
@@ -75,20 +76,12 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
     }
     const int groups = cin >> 4;                     // groups of CN_PF (=4) k-steps per kernel tap
     const float* wrow = wt + (size_t)lk * cout + nt0 * 16 + li;
-    for (int s = 0; s < 9; s++) {
-        const int ky = s / 3 - 1, kx = s % 3 - 1;
-        const float* ia[MT];
-        bool ok[MT];
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            int y = ey[t] + ky, x = ax[t] + kx;
-            x = x < 0 ? x + 20 : (x >= 20 ? x - 20 : x);
-            ok[t] = y >= 0 && y < 7 && t < mt_cnt;
-            ia[t] = in + lk * CN_STR + (ok[t] ? y * 20 + x : CN_POS);   // pad column 140 of every channel row holds 0
-        }
-        const float* ws = wrow + (size_t)s * cin * cout;
-        // ping-pong register sets; sched_barriers pin "issue loads of the next group" in front of
-        // "MFMAs of the current group" (the compiler otherwise rotates the loop and exposes the latency)
+    const float* ib = in + lk * CN_STR;              // lane's channel row of k-step 0
+    // One kernel tap over the wavefront's M-tiles [T0, T1) (compile-time bounds): ping-pong register sets;
+    // sched_barriers pin "issue loads of the next group" in front of "MFMAs of the current group" (the compiler
+    // otherwise rotates the loop and exposes the latency).
+    auto run_tap = [&](auto t0c, auto t1c, const int (&io)[MT], const float* ws) __attribute__((always_inline)) {
+        constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
         float a0[CN_PF][MT], b0[CN_PF][NT], a1[CN_PF][MT], b1[CN_PF][NT];
 #define CYL_LOAD(A, B, G)                                                                              \
     {                                                                                                  \
@@ -98,12 +91,12 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
             _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = CYL_EXP_B(wn_[(size_t)p * 4 * cout + u * 16]); \
         }                                                                                              \
         _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
-            _Pragma("unroll") for (int t = 0; t < MT; t++) A[p][t] = CYL_EXP_A(ia[t][(g_ * CN_PF + p) * 4 * CN_STR]); \
+            _Pragma("unroll") for (int t = T0; t < T1; t++) A[p][t] = CYL_EXP_A(ib[io[t] + (g_ * CN_PF + p) * 4 * CN_STR]); \
         }                                                                                              \
     }
 #define CYL_MMA(A, B)                                                                                  \
     _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                                \
-        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                               \
+        _Pragma("unroll") for (int t = T0; t < T1; t++) {                                              \
             const float av_ = A[p][t];      /* zero padding comes from the address, no select here */ \
             _Pragma("unroll") for (int u = 0; u < NT; u++)                                             \
                 acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, B[p][u], acc[t][u], 0, 0, 0);    \
@@ -125,6 +118,30 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         }
 #undef CYL_LOAD
 #undef CYL_MMA
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int s = 0; s < 9; s++) {
+        const int ky = s / 3 - 1, kx = s % 3 - 1;
+        int io[MT];                                                     // lane's position in its channel row, per tile
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            int y = ey[t] + ky, x = ax[t] + kx;
+            x = x < 0 ? x + 20 : (x >= 20 ? x - 20 : x);
+            const bool ok = y >= 0 && y < 7 && t < mt_cnt;
+            io[t] = ok ? y * 20 + x : CN_POS;                           // pad column 140 of every channel row holds 0
+        }
+        const float* ws = wrow + (size_t)s * cin * cout;
+        // M-tiles whose 16 positions all read the zero elevation padding under this tap contribute exactly 0 and are
+        // skipped: tile 0 (positions 0..15, elevation row 0) for ky = -1, tile 8 (128..143: row 6 + the 4 padding
+        // positions) for ky = +1 -- 6 of 81 (tap, tile) pairs; a 4-tile wavefront of the 32-channel layers also
+        // drops its unused fifth tile.
+        const bool skip_first = ky < 0 && mt0 == 0;
+        const int t1 = mt_cnt - ((ky > 0 && mt0 + mt_cnt == CN_MT) ? 1 : 0);
+        if (skip_first) run_tap(integral_constant<int, 1>{}, integral_constant<int, MT>{}, io, ws);
+        else if (t1 == MT) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT>{}, io, ws);
+        else if (t1 == MT - 1) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT - 1>{}, io, ws);
+        else if constexpr (MT == 5) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT - 2>{}, io, ws);
     }
     // The layer's output overwrites its input IN PLACE (one 72 KB LDS buffer per workgroup, so two workgroups
     // fit a CU and one computes while the other loads/stores): every wavefront has finished reading `in` here.
@@ -154,7 +171,7 @@ __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restri
     extern __shared__ float lds[];                   // [128][144] fp32 (140 positions + bank padding)
     float* buf0 = lds;
     const int patch = blockIdx.x;
-    const int w = threadIdx.x / WAVE;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);     // wave-uniform: tile ranges branch on it
     {   // input: [16,3,7,20] = 48 folded channels x 140 positions, contiguous
         const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)patch * P.cin[0] * CN_POS);
         for (int i = threadIdx.x; i < P.cin[0] * (CN_POS / 4); i += CN_THREADS) {
