@@ -10,3 +10,4 @@
 #include "registration.hip"
 #include "convnet.hip"
 #include "costnet.hip"
+#include "preprocess.hip"

@@ -1,0 +1,100 @@
+"""N1 -- the open3d pre-processing of the reference's datasets on device
+(ThreeDMatch/dataset.py:89-153, KITTI/dataset.py): `voxel_down_sample`, `estimate_normals` (30-NN),
+`orient_normals_towards_camera_location`, behind csrc/preprocess.hip.  open3d (0.13.0, README.md:28) is absent from
+/root/reference and from this image: parity unpinned, algorithms restated from its published sources."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import _dev, _ptr, _stream
+
+
+def voxel_down_sample(points, voxel_size, normals=None, max_cells=0):
+    """open3d PointCloud.voxel_down_sample: points f32|f64[n,3] (device) -> f64[m,3] voxel means
+    (, f64[m,3] mean normals), rows in ascending voxel-key order."""
+    L = _lib.lib()
+    if not isinstance(points, torch.Tensor) or not points.is_cuda:
+        raise _lib.BufferHipError("voxel_down_sample: expected a tensor in device memory (buffer_amd has no CPU path)")
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise _lib.BufferHipError("voxel_down_sample: points.shape is not (N, 3)")
+    if not voxel_size > 0:
+        raise _lib.BufferHipError("voxel_down_sample: voxel_size <= 0.")          # open3d's message
+    dt = torch.float64 if points.dtype == torch.float64 else torch.float32
+    points = points.to(dt).contiguous()
+    if normals is not None:
+        normals = _dev(normals, dt, "voxel_down_sample.normals")
+    n = int(points.shape[0])
+    if max_cells <= 0:
+        max_cells = max(1 << 22, 64 * n)
+    nbytes = L.buf_voxel_downsample_ws_bytes(n, max_cells)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
+    out = torch.empty((max(n, 1), 3), dtype=torch.float64, device=points.device)
+    out_n = torch.empty((max(n, 1), 3), dtype=torch.float64, device=points.device) if normals is not None else None
+    m = C.c_int(0)
+    check(L.buf_voxel_downsample(_ptr(points), _ptr(normals), 1 if dt == torch.float64 else 0, n, float(voxel_size),
+                                 _ptr(out), _ptr(out_n), C.byref(m), max_cells, _ptr(ws), nbytes, _stream()),
+          "buf_voxel_downsample")
+    if normals is not None:
+        return out[:m.value], out_n[:m.value]
+    return out[:m.value]
+
+
+def estimate_normals(points, knn=30, camera=(0.0, 0.0, 0.0), orient=True, radius=None, ncand=40, grow=1.35):
+    """open3d estimate_normals(KDTreeSearchParamKNN(knn)) [+ orient_normals_towards_camera_location(camera)]:
+    points f32[n,3] (device) -> unit normals f32[n,3].
+
+    k-NN through the cell grid of the radius search: candidates = the `ncand` nearest inside a ball (fp32, sorted), re-ranked
+    in fp64 by the kernel; rows whose ball held fewer than min(knn, n) points are retried with a `grow` times larger
+    radius (small steps keep the balls under the 64 candidates the wave-per-query radius kernel handles in one pass)."""
+    L = _lib.lib()
+    pts = _dev(points, torch.float32, "estimate_normals")
+    n = int(pts.shape[0])
+    out = torch.zeros((n, 3), dtype=torch.float32, device=pts.device)
+    if n == 0:
+        return out
+    ncand = max(int(ncand), int(knn))
+    if radius is None:
+        # pilot: distance to the knn-th neighbour for a few hundred queries (plumbing; sets only the first radius)
+        g = torch.Generator(device=pts.device).manual_seed(0)
+        sel = torch.randperm(n, generator=g, device=pts.device)[:256]
+        d = torch.cdist(pts[sel].double(), pts.double())
+        kth = torch.topk(d, min(int(knn), n), dim=1, largest=False).values[:, -1]
+        radius = float(kth.median().item()) * 1.1 + 1e-9
+    cam = (C.c_double * 3)(*[float(c) for c in camera])
+    todo = None
+    r = float(radius)
+    for _ in range(200):
+        grid = ops.CellGrid(pts, [n], r)
+        q = pts if todo is None else pts[todo.long()].contiguous()
+        nq = int(q.shape[0])
+        cand = grid.query(q, [nq], ncand)
+        deficient = torch.empty((nq,), dtype=torch.uint8, device=pts.device)
+        check(L.buf_knn_normals(_ptr(pts), n, _ptr(todo), nq, _ptr(cand), ncand, int(knn), cam, 1 if orient else 0,
+                                _ptr(out), _ptr(deficient), _stream()), "buf_knn_normals")
+        bad = torch.nonzero(deficient).reshape(-1).to(torch.int32)
+        if bad.numel() == 0:
+            return out
+        todo = bad if todo is None else todo[bad.long()].contiguous()
+        r *= grow
+    raise _lib.BufferHipError("estimate_normals: neighbourhood search did not converge")
+
+
+def prepare_fragment(raw_points, downsample, voxel_size_0, max_num_pts=30000, seed=0, with_normals=True):
+    """The test-split branch of ThreeDMatchDataset.__getitem__ for one fragment (dataset.py:93-95,125-153):
+    raw f32[n,3] -> dict(fds_pts f32[N,3] shuffled, sds_pts f32[M,6] = shuffled second-level points + normals).
+    The second voxel level is taken on the first level's fp64 means, like open3d's chained calls."""
+    dev = raw_points.device
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    fds = voxel_down_sample(raw_points, downsample)
+    sds = voxel_down_sample(fds, voxel_size_0)
+    fds32 = fds[torch.randperm(fds.shape[0], generator=g, device=dev)].float()             # np.random.shuffle
+    sds32 = sds[torch.randperm(sds.shape[0], generator=g, device=dev)].float()
+    if sds32.shape[0] > max_num_pts:                                                       # dataset.py:131-137
+        sds32 = sds32[torch.randperm(sds32.shape[0], generator=g, device=dev)[:max_num_pts]]
+    if with_normals:
+        nrm = estimate_normals(sds32)
+        sds32 = torch.cat([sds32, nrm], dim=1)
+    return dict(fds_pts=fds32.contiguous(), sds_pts=sds32.contiguous())

@@ -246,6 +246,27 @@ int     buf_ransac_kabsch(const float* src, const float* tgt, const int* corr, i
 int     buf_post_refine(const float* T_init, const float* src, const float* tgt, int m, float inlier_threshold,
                         int iters, float* T_out, int* info_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * N1  pre-processing that feeds the path (ThreeDMatch/dataset.py:93,104,125-153; KITTI/dataset.py): the open3d
+ * 0.13.0 calls of the reference's datasets, restated from open3d's published algorithms (parity unpinned).
+ *
+ * buf_voxel_downsample = PointCloud.voxel_down_sample: voxel index floor((p - (min - voxel/2)) / voxel), one row per
+ * occupied voxel = fp64 mean of its points (and normals, not re-normalised), rows in ascending voxel-key order.
+ * pts / normals: f32[n,3] (is_f64 = 0) or f64[n,3] (is_f64 = 1), normals nullable; out_pts / out_normals f64[>=n,3];
+ * *out_m_host = rows written.  max_cells as in buf_grid_subsample_batch.
+ *
+ * buf_knn_normals = estimate_normals(KDTreeSearchParamKNN(knn)) + orient_normals_towards_camera_location on the
+ * candidate lists of a radius search: cand int32[nq,ncand] = buf_grid_query output (sorted by distance, >= ns = empty),
+ * knn <= ncand <= 48.  The knn nearest are re-ranked in fp64; covariance by cumulants, normal = eigenvector of the
+ * smallest eigenvalue (open3d FastEigen3x3).  qidx (nullable) maps row -> point (for retries on a subset);
+ * deficient[row] = 1 when the row holds fewer than min(knn, ns) points (its search ball was too small: retry with a
+ * larger radius), else the normal of point qidx[row] is written.  camera_host: HOST double[3]. */
+size_t  buf_voxel_downsample_ws_bytes(int n, int64_t max_cells);
+int     buf_voxel_downsample(const void* pts, const void* normals, int is_f64, int n, double voxel_size, double* out_pts,
+                             double* out_normals, int* out_m_host, int64_t max_cells, void* ws, size_t ws_bytes, void* stream);
+int     buf_knn_normals(const float* pts, int ns, const int* qidx, int nq, const int* cand, int ncand, int knn,
+                        const double* camera_host, int orient, float* normals, unsigned char* deficient, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -346,3 +346,211 @@ void orc_knn(const float* ref, const float* query, int nbatch, int n, int nq, in
     }
     free(bd); free(bi);
 }
+
+
+/* ================================================================================================
+ * open3d 0.13.0 pre-processing (PARITY UNPINNED: restated from open3d's published sources)
+ * ================================================================================================ */
+typedef struct { uint64_t key; int idx; } o3d_kv;
+static int o3d_kv_cmp(const void* a, const void* b)
+{
+    const o3d_kv* x = (const o3d_kv*)a; const o3d_kv* y = (const o3d_kv*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* PointCloud::VoxelDownSample (open3d/geometry/PointCloud.cpp) */
+int orc_o3d_voxel_downsample(const double* pts, const double* normals, int n, double voxel, double* out_pts, double* out_normals)
+{
+    if (voxel <= 0.0) return -1;                       /* "[VoxelDownSample] voxel_size <= 0." */
+    if (n <= 0) return 0;
+    double mn[3] = { pts[0], pts[1], pts[2] }, mx[3] = { pts[0], pts[1], pts[2] };
+    for (int i = 1; i < n; i++)
+        for (int c = 0; c < 3; c++) {
+            double v = pts[3 * (size_t)i + c];
+            if (v < mn[c]) mn[c] = v;
+            if (v > mx[c]) mx[c] = v;
+        }
+    double o[3];
+    uint64_t N[3];
+    for (int c = 0; c < 3; c++) {
+        o[c] = mn[c] - voxel * 0.5;                    /* voxel_min_bound */
+        N[c] = (uint64_t)(int64_t)(floor((mx[c] - o[c]) / voxel) + 1.0);
+    }
+    o3d_kv* kv = (o3d_kv*)malloc(sizeof(o3d_kv) * (size_t)n);
+    if (!kv) return -2;
+    for (int i = 0; i < n; i++) {
+        uint64_t ix = (uint64_t)(int64_t)floor((pts[3 * (size_t)i] - o[0]) / voxel);
+        uint64_t iy = (uint64_t)(int64_t)floor((pts[3 * (size_t)i + 1] - o[1]) / voxel);
+        uint64_t iz = (uint64_t)(int64_t)floor((pts[3 * (size_t)i + 2] - o[2]) / voxel);
+        kv[i].key = ix + N[0] * iy + N[0] * N[1] * iz;
+        kv[i].idx = i;
+    }
+    qsort(kv, (size_t)n, sizeof(o3d_kv), o3d_kv_cmp);
+    int m = 0;
+    for (int a = 0; a < n;) {
+        int b = a;
+        double s[3] = { 0, 0, 0 }, sn[3] = { 0, 0, 0 };
+        while (b < n && kv[b].key == kv[a].key) {      /* AccumulatedPoint::AddPoint, input order */
+            for (int c = 0; c < 3; c++) {
+                s[c] += pts[3 * (size_t)kv[b].idx + c];
+                if (normals) sn[c] += normals[3 * (size_t)kv[b].idx + c];
+            }
+            b++;
+        }
+        for (int c = 0; c < 3; c++) {
+            out_pts[3 * (size_t)m + c] = s[c] / (double)(b - a);
+            if (normals) out_normals[3 * (size_t)m + c] = sn[c] / (double)(b - a);
+        }
+        m++;
+        a = b;
+    }
+    free(kv);
+    return m;
+}
+
+static void o3d_cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* EstimateNormals.cpp ComputeEigenvector0: A symmetric as (a00,a01,a02,a11,a12,a22) */
+static void o3d_evec0(const double* A, double ev, double* out)
+{
+    double r0[3] = { A[0] - ev, A[1], A[2] }, r1[3] = { A[1], A[3] - ev, A[4] }, r2[3] = { A[2], A[4], A[5] - ev };
+    double c[3][3];
+    o3d_cross3(r0, r1, c[0]); o3d_cross3(r0, r2, c[1]); o3d_cross3(r1, r2, c[2]);
+    int best = 0;
+    double dbest = -1.0;
+    for (int i = 0; i < 3; i++) {
+        double d = c[i][0] * c[i][0] + c[i][1] * c[i][1] + c[i][2] * c[i][2];
+        if (d > dbest) { dbest = d; best = i; }
+    }
+    double inv = 1.0 / sqrt(dbest);
+    for (int i = 0; i < 3; i++) out[i] = c[best][i] * inv;
+}
+
+/* ComputeEigenvector1 */
+static void o3d_evec1(const double* A, const double* w, double ev, double* out)
+{
+    double U[3], V[3];
+    if (fabs(w[0]) > fabs(w[1])) {
+        double inv = 1.0 / sqrt(w[0] * w[0] + w[2] * w[2]);
+        U[0] = -w[2] * inv; U[1] = 0.0; U[2] = w[0] * inv;
+    } else {
+        double inv = 1.0 / sqrt(w[1] * w[1] + w[2] * w[2]);
+        U[0] = 0.0; U[1] = w[2] * inv; U[2] = -w[1] * inv;
+    }
+    o3d_cross3(w, U, V);
+    double AU[3], AV[3];
+    AU[0] = A[0] * U[0] + A[1] * U[1] + A[2] * U[2]; AU[1] = A[1] * U[0] + A[3] * U[1] + A[4] * U[2]; AU[2] = A[2] * U[0] + A[4] * U[1] + A[5] * U[2];
+    AV[0] = A[0] * V[0] + A[1] * V[1] + A[2] * V[2]; AV[1] = A[1] * V[0] + A[3] * V[1] + A[4] * V[2]; AV[2] = A[2] * V[0] + A[4] * V[1] + A[5] * V[2];
+    double m00 = U[0] * AU[0] + U[1] * AU[1] + U[2] * AU[2] - ev;
+    double m01 = U[0] * AV[0] + U[1] * AV[1] + U[2] * AV[2];
+    double m11 = V[0] * AV[0] + V[1] * AV[1] + V[2] * AV[2] - ev;
+    double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        if ((a00 > a01 ? a00 : a01) > 0) {
+            if (a00 >= a01) { m01 /= m00; m00 = 1.0 / sqrt(1.0 + m01 * m01); m01 *= m00; }
+            else { m00 /= m01; m01 = 1.0 / sqrt(1.0 + m00 * m00); m00 *= m01; }
+            for (int i = 0; i < 3; i++) out[i] = m01 * U[i] - m00 * V[i];
+        } else
+            for (int i = 0; i < 3; i++) out[i] = U[i];
+    } else {
+        if ((a11 > a01 ? a11 : a01) > 0) {
+            if (a11 >= a01) { m01 /= m11; m11 = 1.0 / sqrt(1.0 + m01 * m01); m01 *= m11; }
+            else { m11 /= m01; m01 = 1.0 / sqrt(1.0 + m11 * m11); m11 *= m01; }
+            for (int i = 0; i < 3; i++) out[i] = m11 * U[i] - m01 * V[i];
+        } else
+            for (int i = 0; i < 3; i++) out[i] = U[i];
+    }
+}
+
+/* FastEigen3x3 (D. Eberly, "A Robust Eigensolver for 3x3 Symmetric Matrices") */
+void orc_o3d_fast_eigen3x3(const double* cov, double* nrm)
+{
+    double A[6], mc = cov[0];
+    for (int i = 1; i < 6; i++) if (cov[i] > mc) mc = cov[i];
+    if (mc == 0.0) { nrm[0] = nrm[1] = nrm[2] = 0.0; return; }
+    for (int i = 0; i < 6; i++) A[i] = cov[i] / mc;
+    double norm = A[1] * A[1] + A[2] * A[2] + A[4] * A[4];
+    if (norm > 0) {
+        double q = (A[0] + A[3] + A[5]) / 3.0;
+        double b00 = A[0] - q, b11 = A[3] - q, b22 = A[5] - q;
+        double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2.0) / 6.0);
+        double c00 = b11 * b22 - A[4] * A[4], c01 = A[1] * b22 - A[4] * A[2], c02 = A[1] * A[4] - b11 * A[2];
+        double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+        double hd = det * 0.5;
+        if (hd < -1.0) hd = -1.0;
+        if (hd > 1.0) hd = 1.0;
+        double angle = acos(hd) / 3.0;
+        double beta2 = cos(angle) * 2.0, beta0 = cos(angle + 2.09439510239319549) * 2.0, beta1 = -(beta0 + beta2);
+        double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+        double v0[3], v1[3], v2[3];
+        if (hd >= 0) {
+            o3d_evec0(A, e2, v2);
+            if (e2 < e0 && e2 < e1) { memcpy(nrm, v2, sizeof v2); return; }
+            o3d_evec1(A, v2, e1, v1);
+            if (e1 < e0 && e1 < e2) { memcpy(nrm, v1, sizeof v1); return; }
+            o3d_cross3(v1, v2, nrm);
+        } else {
+            o3d_evec0(A, e0, v0);
+            if (e0 < e1 && e0 < e2) { memcpy(nrm, v0, sizeof v0); return; }
+            o3d_evec1(A, v0, e1, v1);
+            if (e1 < e0 && e1 < e2) { memcpy(nrm, v1, sizeof v1); return; }
+            o3d_cross3(v0, v1, nrm);
+        }
+    } else {
+        nrm[0] = nrm[1] = nrm[2] = 0.0;
+        if (cov[0] < cov[3] && cov[0] < cov[5]) nrm[0] = 1.0;
+        else if (cov[3] < cov[0] && cov[3] < cov[5]) nrm[1] = 1.0;
+        else nrm[2] = 1.0;
+    }
+}
+
+typedef struct { double d2; int idx; } o3d_dn;
+static int o3d_dn_cmp(const void* a, const void* b)
+{
+    const o3d_dn* x = (const o3d_dn*)a; const o3d_dn* y = (const o3d_dn*)b;
+    if (x->d2 != y->d2) return x->d2 < y->d2 ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+/* EstimateNormals + OrientNormalsTowardsCameraLocation */
+void orc_o3d_estimate_normals(const float* pts, int n, int knn, const double* camera, int orient, float* normals)
+{
+    o3d_dn* dn = (o3d_dn*)malloc(sizeof(o3d_dn) * (size_t)(n > 0 ? n : 1));
+    int k = knn < n ? knn : n;
+    for (int i = 0; i < n; i++) {
+        double q[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
+        for (int j = 0; j < n; j++) {
+            double dx = (double)pts[3 * (size_t)j] - q[0], dy = (double)pts[3 * (size_t)j + 1] - q[1], dz = (double)pts[3 * (size_t)j + 2] - q[2];
+            dn[j].d2 = dx * dx + dy * dy + dz * dz;
+            dn[j].idx = j;
+        }
+        qsort(dn, (size_t)n, sizeof(o3d_dn), o3d_dn_cmp);
+        double nrm[3] = { 0.0, 0.0, 1.0 };
+        if (k >= 3) {                                  /* ComputeCovariance: cumulants over the k neighbours */
+            double cum[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int t = 0; t < k; t++) {
+                const float* p = pts + 3 * (size_t)dn[t].idx;
+                double x = p[0], y = p[1], z = p[2];
+                cum[0] += x; cum[1] += y; cum[2] += z;
+                cum[3] += x * x; cum[4] += x * y; cum[5] += x * z; cum[6] += y * y; cum[7] += y * z; cum[8] += z * z;
+            }
+            for (int t = 0; t < 9; t++) cum[t] /= (double)k;
+            double cov[6] = { cum[3] - cum[0] * cum[0], cum[4] - cum[0] * cum[1], cum[5] - cum[0] * cum[2],
+                              cum[6] - cum[1] * cum[1], cum[7] - cum[1] * cum[2], cum[8] - cum[2] * cum[2] };
+            orc_o3d_fast_eigen3x3(cov, nrm);
+        }
+        if (nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2] == 0.0) { nrm[0] = 0.0; nrm[1] = 0.0; nrm[2] = 1.0; }
+        if (orient) {
+            double r[3] = { camera[0] - q[0], camera[1] - q[1], camera[2] - q[2] };
+            if (nrm[0] * r[0] + nrm[1] * r[1] + nrm[2] * r[2] < 0.0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+        }
+        for (int c = 0; c < 3; c++) normals[3 * (size_t)i + c] = (float)nrm[c];
+    }
+    free(dn);
+}

@@ -49,6 +49,22 @@ void orc_three_nn(const float* unknown, const float* known, int b, int n, int m,
 void orc_knn(const float* ref, const float* query, int b, int n, int q, int d, int k,
              float* dist, int64_t* idx);
 
+/* open3d 0.13.0 PointCloud::VoxelDownSample (open3d/geometry/PointCloud.cpp; pip dependency of the reference,
+ * README.md:28, called at ThreeDMatch/dataset.py:93,104,125,129) -- PARITY UNPINNED (open3d absent from
+ * /root/reference and from this image; restated from its published source).
+ * voxel_min_bound = min - voxel/2, index = floor((p - voxel_min_bound)/voxel), row = fp64 mean of the voxel's points
+ * (and normals, may be NULL) in input order; rows in ascending voxel-key order (open3d: unordered_map order).
+ * pts f64[n,3]; out_pts/out_normals have room for n rows.  Returns the number of rows, <0 on error. */
+int orc_o3d_voxel_downsample(const double* pts, const double* normals, int n, double voxel, double* out_pts, double* out_normals);
+
+/* open3d 0.13.0 EstimateNormals(KDTreeSearchParamKNN(knn)) + OrientNormalsTowardsCameraLocation
+ * (open3d/geometry/EstimateNormals.cpp: ComputeCovariance by cumulants, FastEigen3x3 = Eberly's robust 3x3 symmetric
+ * eigen solver, smallest eigenvector; ThreeDMatch/dataset.py:141-150) -- PARITY UNPINNED, as above.
+ * Brute-force k nearest by (fp64 d2, index), the query point included.  pts f32[n,3] -> normals f32[n,3]. */
+void orc_o3d_estimate_normals(const float* pts, int n, int knn, const double* camera, int orient, float* normals);
+/* the eigen solver alone: cov = (c00,c01,c02,c11,c12,c22) -> eigenvector of the smallest eigenvalue */
+void orc_o3d_fast_eigen3x3(const double* cov, double* normal);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,3 +172,39 @@ def grouping_operation(feat, idx):
     _, m, s = idx.shape
     flat = idx.reshape(b, 1, m * s).astype(np.int64).repeat(c, 1)
     return np.take_along_axis(feat, flat, axis=2).reshape(b, c, m, s)
+
+
+# ---- open3d 0.13.0 pre-processing (parity unpinned; restated from open3d's published sources) ----
+_dp = C.POINTER(C.c_double)
+
+
+def o3d_voxel_down_sample(points, voxel_size, normals=None):
+    """points f64[n,3] -> f64[m,3] voxel means (, mean normals), ascending voxel key."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    n = pts.shape[0]
+    nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+    out = np.zeros((max(n, 1), 3), np.float64)
+    out_n = np.zeros((max(n, 1), 3), np.float64) if nrm is not None else None
+    f = lib().orc_o3d_voxel_downsample
+    f.restype = C.c_int
+    m = f(_p(pts, _dp), None if nrm is None else _p(nrm, _dp), int(n), C.c_double(voxel_size), _p(out, _dp),
+          None if out_n is None else _p(out_n, _dp))
+    if m < 0:
+        raise ValueError("voxel_size <= 0.")
+    return (out[:m], out_n[:m]) if nrm is not None else out[:m]
+
+
+def o3d_estimate_normals(points, knn=30, camera=(0.0, 0.0, 0.0), orient=True):
+    pts = _f32(points)
+    n = pts.shape[0]
+    out = np.zeros((n, 3), np.float32)
+    cam = np.ascontiguousarray(camera, dtype=np.float64)
+    lib().orc_o3d_estimate_normals(_p(pts, _fp), int(n), int(knn), _p(cam, _dp), 1 if orient else 0, _p(out, _fp))
+    return out
+
+
+def o3d_fast_eigen3x3(cov6):
+    cov = np.ascontiguousarray(cov6, dtype=np.float64)
+    out = np.zeros(3, np.float64)
+    lib().orc_o3d_fast_eigen3x3(_p(cov, _dp), _p(out, _dp))
+    return out

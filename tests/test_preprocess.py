@@ -1,0 +1,145 @@
+"""N1 pre-processing (open3d voxel_down_sample / estimate_normals / orient_normals): the oracle restatement against
+independent numpy formulations (CPU), the HIP kernels against the oracle (GPU).  Parity with open3d itself is
+UNPINNED (open3d 0.13.0 is a pip dependency absent from /root/reference and from this image)."""
+import numpy as np
+import pytest
+
+
+def _cloud(seed, n, scale=1.0):
+    rng = np.random.default_rng(seed)
+    # three faces of a box + jitter (the SURVEY 8d synthetic shape), away from the origin
+    face = rng.integers(0, 3, n)
+    p = rng.random((n, 3)) * 2.0
+    p[np.arange(n), face] = 0.0
+    p += rng.normal(0, 0.003, p.shape)
+    return ((p + 0.5) * scale).astype(np.float32)
+
+
+def _np_voxel_down_sample(pts, voxel):
+    pts = np.asarray(pts, np.float64)
+    o = pts.min(0) - voxel * 0.5
+    idx = np.floor((pts - o) / voxel).astype(np.int64)
+    N = np.floor((pts.max(0) - o) / voxel).astype(np.int64) + 1
+    key = idx[:, 0] + N[0] * idx[:, 1] + N[0] * N[1] * idx[:, 2]
+    rows = []
+    for k in np.unique(key):
+        sel = np.nonzero(key == k)[0]
+        s = np.zeros(3)
+        for i in sel:                      # input order, sequential fp64 sum
+            s = s + pts[i]
+        rows.append(s / len(sel))
+    return np.array(rows)
+
+
+def test_oracle_voxel_down_sample_vs_numpy(oracle):
+    pts = _cloud(0, 4000)
+    got = oracle.o3d_voxel_down_sample(pts.astype(np.float64), 0.05)
+    want = _np_voxel_down_sample(pts, 0.05)
+    assert got.shape == want.shape and 500 < got.shape[0] < 4000
+    np.testing.assert_array_equal(got, want)
+    # chained second level on the fp64 means (dataset.py:125) and the mean of normals
+    got2, nrm2 = oracle.o3d_voxel_down_sample(got, 0.12, normals=np.ones_like(got) * [0.0, 0.0, 2.0])
+    np.testing.assert_array_equal(got2, _np_voxel_down_sample(got, 0.12))
+    np.testing.assert_allclose(nrm2, np.tile([0.0, 0.0, 2.0], (got2.shape[0], 1)))
+    with pytest.raises(ValueError):
+        oracle.o3d_voxel_down_sample(got, 0.0)
+    assert oracle.o3d_voxel_down_sample(np.zeros((0, 3)), 0.1).shape == (0, 3)
+
+
+def test_oracle_fast_eigen_vs_eigh(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        a = rng.normal(size=(3, 3)) * rng.choice([1e-3, 1.0, 30.0])
+        c = a @ a.T
+        if rng.random() < 0.2:
+            c = np.diag(np.diag(c))        # the diagonal branch
+        w, v = np.linalg.eigh(c)
+        if (w[1] - w[0]) < 1e-6 * max(w[2], 1e-300):
+            continue
+        n = oracle.o3d_fast_eigen3x3([c[0, 0], c[0, 1], c[0, 2], c[1, 1], c[1, 2], c[2, 2]])
+        assert abs(np.linalg.norm(n) - 1.0) < 1e-9
+        assert abs(abs(n @ v[:, 0]) - 1.0) < 1e-8
+    assert np.array_equal(oracle.o3d_fast_eigen3x3(np.zeros(6)), np.zeros(3))
+    assert np.array_equal(oracle.o3d_fast_eigen3x3([1, 0, 0, 1, 0, 1]), [0, 0, 1])
+
+
+def test_oracle_normals_vs_numpy(oracle):
+    pts = _cloud(2, 600)
+    got = oracle.o3d_estimate_normals(pts, knn=30)
+    p64 = pts.astype(np.float64)
+    for i in range(0, 600, 7):
+        d2 = ((p64 - p64[i]) ** 2).sum(1)
+        nb = np.lexsort((np.arange(600), d2))[:30]
+        c = np.cov(p64[nb].T, bias=True)
+        w, v = np.linalg.eigh(c)
+        n = v[:, 0] if v[:, 0] @ (-p64[i]) >= 0 else -v[:, 0]
+        assert got[i] @ n > 1 - 1e-5, i
+    # fewer than 3 points: identity covariance -> (0,0,1), then oriented towards the camera
+    two = np.array([[0, 0, 1], [0, 1, 2]], np.float32)
+    np.testing.assert_array_equal(oracle.o3d_estimate_normals(two), [[0, 0, -1], [0, 0, -1]])
+    np.testing.assert_array_equal(oracle.o3d_estimate_normals(two, orient=False), [[0, 0, 1], [0, 0, 1]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,voxel,dtype", [(20000, 0.05, np.float32), (20000, 0.013, np.float64), (1, 0.1, np.float32), (7, 5.0, np.float32)])
+def test_hip_voxel_down_sample_vs_oracle(oracle, dev, n, voxel, dtype):
+    import torch
+    from buffer_amd import preprocess
+    pts = _cloud(3, n).astype(dtype)
+    if dtype == np.float64:
+        pts = pts + np.random.default_rng(4).normal(0, 1e-9, pts.shape)
+    nrm = np.random.default_rng(5).normal(size=pts.shape).astype(dtype)
+    got, got_n = preprocess.voxel_down_sample(torch.from_numpy(pts).to(dev), voxel, normals=torch.from_numpy(nrm).to(dev))
+    want, want_n = oracle.o3d_voxel_down_sample(pts.astype(np.float64), voxel, normals=nrm.astype(np.float64))
+    assert got.dtype == torch.float64
+    np.testing.assert_array_equal(got.cpu().numpy(), want)             # fp64 sums in input order: bit-exact
+    np.testing.assert_array_equal(got_n.cpu().numpy(), want_n)
+    # chained level on the fp64 means
+    got2 = preprocess.voxel_down_sample(got, voxel * 1.75)
+    np.testing.assert_array_equal(got2.cpu().numpy(), oracle.o3d_voxel_down_sample(want, voxel * 1.75))
+
+
+@pytest.mark.gpu
+def test_hip_voxel_down_sample_errors(dev):
+    import torch
+    from buffer_amd import preprocess
+    from buffer_amd._lib import BufferHipError
+    with pytest.raises(BufferHipError):
+        preprocess.voxel_down_sample(torch.zeros((4, 3), device=dev), 0.0)
+    with pytest.raises(BufferHipError):
+        preprocess.voxel_down_sample(torch.zeros((4, 3)), 0.1)          # host tensor: no CPU path
+    assert preprocess.voxel_down_sample(torch.zeros((0, 3), device=dev), 0.1).shape == (0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,knn", [(6000, 30), (500, 30), (40, 30), (20, 30), (2, 30), (3000, 10)])
+def test_hip_normals_vs_oracle(oracle, dev, n, knn):
+    import torch
+    from buffer_amd import preprocess
+    pts = _cloud(6, n)
+    if n == 6000:
+        pts[:50] += 40.0                     # a far, sparse cluster: rows that need several radius doublings
+    got = preprocess.estimate_normals(torch.from_numpy(pts).to(dev), knn=knn, camera=(0.1, -0.2, 0.3)).cpu().numpy()
+    want = oracle.o3d_estimate_normals(pts, knn=knn, camera=(0.1, -0.2, 0.3))
+    assert np.all(np.abs(np.linalg.norm(got, axis=1) - 1.0) < 1e-5)
+    dots = (got * want).sum(1)
+    # the same neighbour sets and the same solver: agreement to round-off wherever the two smallest eigenvalues
+    # are separated; allow a handful of ill-conditioned rows (edges of the box) a looser bound
+    assert np.mean(dots > 1 - 1e-6) > 0.995, float(np.mean(dots > 1 - 1e-6))
+    assert np.all(dots > 1 - 1e-3), float(dots.min())
+
+
+@pytest.mark.gpu
+def test_prepare_fragment_feeds_the_pipeline(dev):
+    """raw cloud -> two voxel levels + normals, shaped like ThreeDMatchDataset's test items."""
+    import torch
+    from buffer_amd import preprocess
+    raw = torch.from_numpy(_cloud(8, 60000, scale=1.5)).to(dev)
+    item = preprocess.prepare_fragment(raw, downsample=0.02, voxel_size_0=0.035, seed=1)
+    fds, sds = item['fds_pts'], item['sds_pts']
+    assert fds.dtype == torch.float32 and sds.shape[1] == 6 and 0 < sds.shape[0] < fds.shape[0] <= 60000
+    n = sds[:, 3:]
+    assert torch.all((n.norm(dim=1) - 1).abs() < 1e-5)
+    assert torch.all((n * (-sds[:, :3])).sum(1) >= 0)                   # oriented towards the camera at the origin
+    again = preprocess.prepare_fragment(raw, downsample=0.02, voxel_size_0=0.035, seed=1)
+    assert torch.equal(again['sds_pts'], sds) and torch.equal(again['fds_pts'], fds)

@@ -111,3 +111,23 @@ if which == 'cost':
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 5
     print(f'cost_net 2500 matches: {dt*1e3:.2f} ms  {2500*0.160/dt/1e3:.1f} TFLOP/s')
+if which == 'prep':
+    from buffer_amd import preprocess
+    sample = synth.make_pair(seed=0)
+    raw = torch.from_numpy(np.concatenate([sample['src_fds_pts']] * 12) + np.random.default_rng(0).normal(0, 0.004, (12 * sample['src_fds_pts'].shape[0], 3)).astype(np.float32)).to(dev)
+    sds = torch.from_numpy(sample['src_sds_pts'][:, :3].copy()).to(dev)
+
+    def timeit(f, reps=5):
+        f(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+    dt = timeit(lambda: preprocess.voxel_down_sample(raw, 0.02))
+    m = preprocess.voxel_down_sample(raw, 0.02).shape[0]
+    print(f'voxel_down_sample {raw.shape[0]} -> {m} pts: {dt*1e3:.2f} ms')
+    dt = timeit(lambda: preprocess.estimate_normals(sds))
+    print(f'estimate_normals {sds.shape[0]} pts (knn 30): {dt*1e3:.2f} ms')
+    dt = timeit(lambda: preprocess.prepare_fragment(raw, 0.02, 0.035))
+    print(f'prepare_fragment (2 voxel levels + shuffles + normals): {dt*1e3:.2f} ms')
