@@ -143,3 +143,27 @@ def test_prepare_fragment_feeds_the_pipeline(dev):
     assert torch.all((n * (-sds[:, :3])).sum(1) >= 0)                   # oriented towards the camera at the origin
     again = preprocess.prepare_fragment(raw, downsample=0.02, voxel_size_0=0.035, seed=1)
     assert torch.equal(again['sds_pts'], sds) and torch.equal(again['fds_pts'], fds)
+
+
+@pytest.mark.gpu
+def test_raw_clouds_to_pose(dev):
+    """raw (dense, unvoxelised) fragment pair -> device pre-processing -> BufferPipeline -> the planted pose."""
+    import torch
+    from buffer_amd import preprocess, synth
+    from buffer_amd.pipeline import BufferPipeline
+    s = synth.make_pair(seed=5)
+    rng = np.random.default_rng(5)
+    items = {}
+    for side in ('src', 'tgt'):
+        dense = np.concatenate([s[f'{side}_fds_pts'] + rng.normal(0, 0.004, s[f'{side}_fds_pts'].shape) for _ in range(4)])
+        it = preprocess.prepare_fragment(torch.from_numpy(dense.astype(np.float32)).to(dev), 0.02, 0.035, seed=11)
+        items[f'{side}_fds_pts'] = it['fds_pts'].cpu().numpy()
+        items[f'{side}_sds_pts'] = it['sds_pts'].cpu().numpy()
+    items['relt_pose'] = s['relt_pose']
+    pipe = BufferPipeline(device=dev)
+    pipe.calibrate([items])
+    T = pipe.register(pipe.upload(items)).cpu().numpy().astype(np.float64)
+    gt = s['relt_pose']
+    rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
+    rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+    assert rte < 0.1 and rre < 3.0, (rte, rre)
