@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--keypts', type=int, default=5000, help='keypoints per fragment (BASELINE: ~5k)')
-    ap.add_argument('--pairs-per-step', type=int, default=16, help='pairs registered per GPU and step')
+    ap.add_argument('--pairs-per-step', type=int, default=32, help='pairs registered per GPU and step')
     ap.add_argument('--mode', choices=['batch', 'threads'], default='batch',
                     help='batch: the pairs of a step share one set of stacked launches; threads: one stream per pair')
     ap.add_argument('--streams', type=int, default=1,
