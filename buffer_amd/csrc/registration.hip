@@ -237,11 +237,11 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
 // One lane per hypothesis: 3 distinct correspondences from the candidate list, edge-length checker,
 // Kabsch, distance checker, then fitness (inlier count) and sum of squared inlier distances over
 // all candidates.  key = (count << 32) | ~bits(mean squared error): larger is better.
-__global__ void __launch_bounds__(256) k_ransac(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
+__global__ void __launch_bounds__(WAVE) k_ransac(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
                                               int ncorr, int nhyp, unsigned long long seed, float max_dist, float edge_sim,
                                               unsigned long long* __restrict__ keys, float* __restrict__ Ts)
 {
-    int h = blockIdx.x * 256 + threadIdx.x;
+    int h = blockIdx.x * WAVE + threadIdx.x;       // one wavefront per workgroup: 4096 hypotheses spread over 64 CUs
     if (h >= nhyp) return;
     unsigned long long key = 0;
     float T[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
@@ -347,7 +347,7 @@ extern "C" int buf_ransac_kabsch(const float* src, const float* tgt, const int* 
         BUF_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)nhyp, s));
     } else {
         BUF_REQUIRE(src && tgt && corr, BUF_EINVAL, "buf_ransac_kabsch: null argument");
-        k_ransac<<<cdiv(nhyp, 256), 256, 0, s>>>(src, tgt, corr, ncorr, nhyp, seed, max_dist, edge_similarity, keys, Ts);
+        k_ransac<<<cdiv(nhyp, WAVE), WAVE, 0, s>>>(src, tgt, corr, ncorr, nhyp, seed, max_dist, edge_similarity, keys, Ts);
     }
     k_ransac_pick<<<1, 1024, 0, s>>>(keys, Ts, nhyp, T_out, info_out);
     BUF_LAUNCH_CHECK();

@@ -265,3 +265,93 @@ extern "C" int buf_vn_std(const float* x, const float* z, int n, int c, float* o
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// InstanceNorm1d over contiguous row segments (models/point_learner.py:131,133: the score heads normalise over
+// the stacked src+tgt points OF ONE PAIR; a batch of pairs = one segment per pair).  Two-pass statistics
+// (mean, then biased variance of the deviations) without atomics: every segment is cut into SEG_SPLITS chunks,
+// per-chunk partial sums are combined in a fixed order, so the result does not depend on scheduling.
+#define SEG_SPLITS 64
+
+// partial[seg][split][ch] = sum over the chunk's rows of (x - mean)^(SQ ? 2 : 1); blockDim = c * rows_per_iter
+template <bool SQ>
+__global__ void __launch_bounds__(256) k_seg_partial(const float* __restrict__ x, const int* __restrict__ seg_off, int c,
+                                                   const float* __restrict__ mean, float* __restrict__ partial)
+{
+    __shared__ float sh[256];
+    const int seg = blockIdx.x, split = blockIdx.y;
+    const int lo = seg_off[seg], hi = seg_off[seg + 1];
+    const int chunk = (hi - lo + SEG_SPLITS - 1) / SEG_SPLITS;
+    const int r0 = lo + split * chunk, r1 = min(r0 + chunk, hi);
+    const int rpi = blockDim.x / c, ch = threadIdx.x % c, rr = threadIdx.x / c;
+    const float mu = SQ ? mean[seg * c + ch] : 0.f;
+    float acc = 0.f;
+    for (int r = r0 + rr; r < r1; r += rpi) {
+        float v = x[(size_t)r * c + ch] - mu;
+        acc += SQ ? v * v : v;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < c) {
+        float t = 0.f;
+        for (int k = 0; k < rpi; k++) t += sh[k * c + threadIdx.x];
+        partial[((size_t)seg * SEG_SPLITS + split) * c + threadIdx.x] = t;
+    }
+}
+
+__global__ void k_seg_final(const float* __restrict__ partial, const int* __restrict__ seg_off, int nseg, int c, float* __restrict__ out)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseg * c) return;
+    int seg = t / c, ch = t % c;
+    float s = 0.f;
+    for (int k = 0; k < SEG_SPLITS; k++) s += partial[((size_t)seg * SEG_SPLITS + k) * c + ch];
+    int cnt = seg_off[seg + 1] - seg_off[seg];
+    out[t] = cnt > 0 ? s / (float)cnt : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_seg_apply(const float* __restrict__ x, const int* __restrict__ seg_off, int nseg, int c, long long total,
+                                                 const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                 float* __restrict__ out)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    int row = (int)(t / c), ch = (int)(t % c);
+    int seg = find_elem(seg_off, nseg, row);
+    out[t] = (x[t] - mean[seg * c + ch]) / sqrtf(var[seg * c + ch] + eps);
+}
+
+extern "C" size_t buf_segment_instance_norm_ws_bytes(int nseg, int c)
+{
+    if (nseg <= 0 || c <= 0) return 256;
+    return 256 + sizeof(int) * ((size_t)nseg + 1) + sizeof(float) * (size_t)nseg * c * (SEG_SPLITS + 2) + 256;
+}
+
+// x f32[n,c] (rows of segment s contiguous, lens_host[s] rows each) -> out f32[n,c] = (x - mean_s) / sqrt(var_s + eps)
+extern "C" int buf_segment_instance_norm(const float* x, int n, int c, const int* lens_host, int nseg, float eps, float* out,
+                                         void* ws, size_t ws_bytes, void* stream)
+{
+    BUF_REQUIRE(n >= 0 && c > 0 && c <= 256 && nseg > 0, BUF_EINVAL, "buf_segment_instance_norm: n=%d c=%d nseg=%d", n, c, nseg);
+    BUF_REQUIRE(lens_host && ws, BUF_EINVAL, "buf_segment_instance_norm: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver w(ws, ws_bytes);
+    int* off = w.take<int>((size_t)nseg + 1);
+    float* partial = w.take<float>((size_t)nseg * c * SEG_SPLITS);
+    float* mean = w.take<float>((size_t)nseg * c);
+    float* var = w.take<float>((size_t)nseg * c);
+    BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_segment_instance_norm: workspace %zu < %zu", ws_bytes, w.used());
+    int rc = upload_offsets(off, lens_host, nseg, n, "buf_segment_instance_norm", s);
+    if (rc) return rc;
+    if (n == 0) return BUF_OK;
+    BUF_REQUIRE(x && out, BUF_EINVAL, "buf_segment_instance_norm: null argument");
+    const int threads = c * (256 / c);
+    dim3 grid(nseg, SEG_SPLITS);
+    k_seg_partial<false><<<grid, threads, 0, s>>>(x, off, c, nullptr, partial);
+    k_seg_final<<<cdiv(nseg * c, 64), 64, 0, s>>>(partial, off, nseg, c, mean);
+    k_seg_partial<true><<<grid, threads, 0, s>>>(x, off, c, mean, partial);
+    k_seg_final<<<cdiv(nseg * c, 64), 64, 0, s>>>(partial, off, nseg, c, var);
+    long long total = (long long)n * c;
+    k_seg_apply<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(x, off, nseg, c, total, mean, var, eps, out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

@@ -342,6 +342,21 @@ def patch_voxelize(patches, axis, des_r, centres, azi_cs, voxel_r, nsample, mlp_
     return x, R, ra, pn
 
 
+def segment_instance_norm(x, seg_lengths, eps=1e-5):
+    """InstanceNorm1d (biased variance) over contiguous row segments: x f32[n,c], seg_lengths int[nseg] (host) -> f32[n,c]."""
+    L = _lib.lib()
+    x = _dev(x, torch.float32, "segment_instance_norm")
+    n, c = int(x.shape[0]), int(x.shape[1])
+    lens = _host_i32(seg_lengths)
+    nseg = int(lens.shape[0])
+    out = torch.empty_like(x)
+    nbytes = L.buf_segment_instance_norm_ws_bytes(nseg, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(L.buf_segment_instance_norm(_ptr(x), n, c, _hptr(lens), nseg, float(eps), _ptr(out), _ptr(ws), nbytes, _stream()),
+          "buf_segment_instance_norm")
+    return out
+
+
 # ----------------------------------------------------------------------------- pose recovery
 def hypotheses_score(ind, ss_kpts, tt_kpts, ss_R, tt_R, azi_n=20, inlier_th=1 / 3):
     L = _lib.lib()

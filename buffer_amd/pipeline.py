@@ -92,10 +92,7 @@ class BufferPipeline:
         feats = torch.cat([i['features'] for i in inps]) if B > 1 else inps[0]['features']
         pyr = pyramid.build_pyramid(pts, lens, self.limits, cfg)
         pair_rows = lens.reshape(B, 2).sum(1)
-        seg = None
-        if B > 1:
-            ids = torch.repeat_interleave(torch.arange(B, device=dev), torch.from_numpy(pair_rows.astype(np.int64)).to(dev))
-            seg = (ids, torch.from_numpy(pair_rows.astype(np.float32)).to(dev))
+        seg = pair_rows.astype(np.int32) if B > 1 else None      # InstanceNorm segments of the score heads: one per pair
         axis, eps, bottle, skips, _ = self.point.efcnn(pyr, feats, seg)
         score = self.point.detnet(pyr, bottle, skips, seg)
         pts0 = pyr['points'][0]

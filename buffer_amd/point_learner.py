@@ -21,16 +21,8 @@ class _ScoreHead:
     @staticmethod
     def _inorm(h, seg=None):
         # InstanceNorm1d over the stacked (src+tgt) point axis OF ONE PAIR, biased variance, eps 1e-5 (:131,133).
-        # seg = (pair id per row int64[N], rows per pair f32[B]) when several pairs are stacked in one batch.
-        if seg is None:
-            m = h.mean(0, keepdim=True)
-            v = h.var(0, unbiased=False, keepdim=True)
-            return (h - m) / torch.sqrt(v + 1e-5)
-        ids, cnt = seg
-        m = torch.zeros((cnt.shape[0], h.shape[1]), dtype=h.dtype, device=h.device).index_add_(0, ids, h) / cnt[:, None]
-        d = h - m[ids]
-        v = torch.zeros_like(m).index_add_(0, ids, d * d) / cnt[:, None]
-        return d / torch.sqrt(v[ids] + 1e-5)
+        # seg = rows per pair (host int array [B]) when several pairs are stacked in one batch; one pair = one segment.
+        return ops.segment_instance_norm(h, [h.shape[0]] if seg is None else seg)
 
     def __call__(self, x, seg=None):
         z = ops.vn_pointwise(self.vn1, x)

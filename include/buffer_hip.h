@@ -181,6 +181,12 @@ int     buf_vn_pointwise(const float* a, const int* ind_a, int ind_stride, int n
                          const float* bn_shift, float slope, const float* residual, float* out, void* stream);
 /* max_pool (models/KPConv/blocks.py:104-121): out[i,f] = max_k feats_pad[idx[i,k], f], zero shadow row. */
 int     buf_gather_max(const float* feats, const int* idx, int nq, int ns, int k, int width, float* out, void* stream);
+/* InstanceNorm1d (biased variance, no affine) over contiguous row segments: the score heads of
+ * models/point_learner.py:128-136,163-171 normalise over the stacked points of ONE pair; lens_host[s] rows per
+ * segment (HOST int[nseg], sum = n).  x f32[n,c] -> out f32[n,c].  Deterministic (no atomics). */
+size_t  buf_segment_instance_norm_ws_bytes(int nseg, int c);
+int     buf_segment_instance_norm(const float* x, int n, int c, const int* lens_host, int nseg, float eps, float* out,
+                                  void* ws, size_t ws_bytes, void* stream);
 /* VNStdFeature tail (vn_layers.py:213-219): x f32[n,3c], z f32[n,9] -> f32[n,3c] invariant scalars. */
 int     buf_vn_std(const float* x, const float* z, int n, int c, float* out, void* stream);
 

@@ -128,3 +128,25 @@ def test_compact_greater(dev):
     x = torch.ones(1000)
     assert torch.equal(ops.compact_greater(x.to(dev), 0.0).cpu().long(), torch.arange(1000))
     assert ops.compact_greater(x.to(dev), 2.0).numel() == 0
+
+
+def test_segment_instance_norm_vs_torch(dev):
+    """InstanceNorm1d over contiguous row segments (point_learner.py:131,133) == torch per-segment statistics;
+    deterministic run to run; empty and single-row segments."""
+    import torch
+    from buffer_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(0)
+    lens = [1000, 1, 0, 4567, 333]
+    x = (torch.randn((sum(lens), 30), generator=g) * 3 + 1.5).to(dev)
+    got = ops.segment_instance_norm(x, lens)
+    lo = 0
+    for n in lens:
+        if n:
+            seg = x[lo:lo + n]
+            want = (seg - seg.mean(0, keepdim=True)) / torch.sqrt(seg.var(0, unbiased=False, keepdim=True) + 1e-5)
+            np.testing.assert_allclose(got[lo:lo + n].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
+        lo += n
+    assert torch.equal(got, ops.segment_instance_norm(x, lens))
+    assert ops.segment_instance_norm(x[:0], [0]).shape == (0, 30)
+    with pytest.raises(Exception):
+        ops.segment_instance_norm(x, [5])                      # lengths do not sum to n
