@@ -30,6 +30,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CYL_EXP
 #define CYL_EXP 0
 #endif
+// -DCYL_PRIO=1: raise the wave priority around MFMA blocks; =2: static priority by workgroup parity (experiments)
+#ifndef CYL_PRIO
+#define CYL_PRIO 0
+#endif
+#if CYL_PRIO == 1
+#define CYL_PRIO_HI __builtin_amdgcn_s_setprio(2);
+#define CYL_PRIO_LO __builtin_amdgcn_s_setprio(0);
+#else
+#define CYL_PRIO_HI
+#define CYL_PRIO_LO
+#endif
 #if CYL_EXP & 1
 #define CYL_EXP_A(x) (1.0f + (float)(g_ + p + t))
 #else
@@ -108,12 +119,12 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
             __builtin_amdgcn_sched_barrier(0);
             CYL_LOAD(a1, b1, g + 1)
             __builtin_amdgcn_sched_barrier(0);
-            CYL_MMA(a0, b0)
+            CYL_PRIO_HI CYL_MMA(a0, b0) CYL_PRIO_LO
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < groups) {
                 CYL_LOAD(a0, b0, g + 2)
                 __builtin_amdgcn_sched_barrier(0);
-                CYL_MMA(a1, b1)
+                CYL_PRIO_HI CYL_MMA(a1, b1) CYL_PRIO_LO
             }
         }
 #undef CYL_LOAD
@@ -172,6 +183,9 @@ __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restri
     float* buf0 = lds;
     const int patch = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);     // wave-uniform: tile ranges branch on it
+#if CYL_PRIO == 2
+    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2);
+#endif
     {   // input: [16,3,7,20] = 48 folded channels x 140 positions, contiguous
         const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)patch * P.cin[0] * CN_POS);
         for (int i = threadIdx.x; i < P.cin[0] * (CN_POS / 4); i += CN_THREADS) {
