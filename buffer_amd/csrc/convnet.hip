@@ -41,6 +41,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CYL_PRIO_HI
 #define CYL_PRIO_LO
 #endif
+// CYL_SCHED: how the next group's operand loads are placed against the MFMA block of the current group.
+// 0: in front of it (sched_barrier), 1: compiler's choice, 2 (default, fastest measured at two workgroups per CU):
+// woven into it -- after every CYL_SG_M MFMAs up to CYL_SG_V VALU/SALU and CYL_SG_L memory instructions.
+#ifndef CYL_SCHED
+#define CYL_SCHED 2
+#endif
+#if CYL_SCHED == 0
+#define CYL_SCHED_MID __builtin_amdgcn_sched_barrier(0);
+#define CYL_SCHED_TAIL
+#elif CYL_SCHED == 1
+#define CYL_SCHED_MID
+#define CYL_SCHED_TAIL
+#else
+#ifndef CYL_SG_M
+#define CYL_SG_M 2
+#define CYL_SG_V 6
+#define CYL_SG_L 2
+#endif
+#define CYL_SCHED_MID
+// per MFMA: up to 2 VALU/SALU, then one memory instruction, woven between the matrix instructions
+#define CYL_SCHED_TAIL                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < CN_PF * MT * NT; i_++) {                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, CYL_SG_M, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x006, CYL_SG_V, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x120, CYL_SG_L, 0);                       \
+    }
+#endif
 #if CYL_EXP & 1
 #define CYL_EXP_A(x) (1.0f + (float)(g_ + p + t))
 #else
@@ -118,13 +145,15 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         for (int g = 0; g < groups; g += 2) {
             __builtin_amdgcn_sched_barrier(0);
             CYL_LOAD(a1, b1, g + 1)
-            __builtin_amdgcn_sched_barrier(0);
+            CYL_SCHED_MID
             CYL_PRIO_HI CYL_MMA(a0, b0) CYL_PRIO_LO
+            CYL_SCHED_TAIL
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < groups) {
                 CYL_LOAD(a0, b0, g + 2)
-                __builtin_amdgcn_sched_barrier(0);
+                CYL_SCHED_MID
                 CYL_PRIO_HI CYL_MMA(a1, b1) CYL_PRIO_LO
+                CYL_SCHED_TAIL
             }
         }
 #undef CYL_LOAD
