@@ -20,6 +20,24 @@
 #endif
 
 typedef float cvx4 __attribute__((ext_vector_type(4)));
+
+// Placement of a group's operand loads against the previous group's MFMAs: CV_SCHED 0 = loads in front of the MFMA
+// block (sched_barrier), 2 = woven into it (after every 2 MFMAs up to 6 VALU/SALU and 2 memory instructions).
+#ifndef CV_SCHED
+#define CV_SCHED 0     // measured: 4.38 ms (0) vs 4.49 ms (2) per 2500 matches -- one wavefront per SIMD here
+#endif
+#if CV_SCHED == 0
+#define CV_SCHED_MID __builtin_amdgcn_sched_barrier(0);
+#define CV_SCHED_TAIL(NMFMA)
+#else
+#define CV_SCHED_MID
+#define CV_SCHED_TAIL(NMFMA)                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < ((NMFMA) + 1) / 2; i_++) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x120, 2, 0);                              \
+    }
+#endif
 typedef const __attribute__((address_space(1))) float* cv_gptr;
 
 struct CostNetParams {
@@ -136,7 +154,7 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
     for (int g = 0; g < TOTAL; g++) {
         __builtin_amdgcn_sched_barrier(0);
         if (g + D - 1 < TOTAL) CVS_LOAD((g + D - 1) % D, g + D - 1)
-        __builtin_amdgcn_sched_barrier(0);
+        CV_SCHED_MID
 #pragma unroll
         for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -144,6 +162,7 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
 #pragma unroll
                 for (int u = 0; u < NT; u++)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % D][p][t], b[g % D][p][u], acc[t][u], 0, 0, 0);
+        CV_SCHED_TAIL(4 * MT * NT)
     }
 #undef CVS_LOAD
 }
@@ -241,7 +260,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
             __builtin_amdgcn_sched_barrier(0);
             if (cg + 1 < GPT) CVC_LOAD((cg + 1) & 1, cur, wcur, cg + 1)
             else              CVC_LOAD((cg + 1) & 1, nxt, wnxt, 0)
-            __builtin_amdgcn_sched_barrier(0);
+            CV_SCHED_MID
 #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -249,6 +268,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
 #pragma unroll
                     for (int u = 0; u < NT; u++)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg & 1][p][t], b[cg & 1][p][u], acc[t][u], 0, 0, 0);
+            CV_SCHED_TAIL(4 * MT * NT)
         }
 #pragma unroll
         for (int t = 0; t < MT; t++) cur[t] = nxt[t];
