@@ -24,6 +24,7 @@
 #define CN_THREADS 256
 #define CN_PF 4               // k-steps per software-pipeline group
 #define CN_BUF (CN_MAXC * CN_STR)                 // one activation buffer
+#define CN_TAB 160                                // tap-table row: 10 tiles of 16 output positions (the 5/4 split reaches tile 9)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // timing experiments only (-DCYL_EXP=1: no LDS fragment loads, 2: no weight loads, 3: neither); default = real loads
@@ -96,21 +97,18 @@ struct CylNetParams {
 // unconditional: a prefetch past the end of a tap is clamped to the tap's last group.
 template <int MT, int NT>
 __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* __restrict__ out_lds, float* __restrict__ out_glb,
-                                          const float* __restrict__ wt, const float* __restrict__ bias, int cin, int cout,
-                                          int relu, int mt0, int mt_cnt, int nt0)
+                                          const unsigned short* __restrict__ postab, const float* __restrict__ wt,
+                                          const float* __restrict__ bias, int cin, int cout, int relu, int mt0, int mt_cnt, int nt0)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const int li = lane & 15, lk = lane >> 4;
+    // accumulators start at the bias of their output channel (C/D layout: column = lane & 15): no bias pass afterwards
     f32x4 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+    for (int u = 0; u < NT; u++) {
+        const float bv = bias[(nt0 + u) * 16 + li];
 #pragma unroll
-        for (int u = 0; u < NT; u++) acc[t][u] = (f32x4){ 0.f, 0.f, 0.f, 0.f };
-    int ey[MT], ax[MT];
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-        int m = (mt0 + t) * 16 + li;
-        ey[t] = m / 20; ax[t] = m % 20;
+        for (int t = 0; t < MT; t++) acc[t][u] = (f32x4){ bv, bv, bv, bv };
     }
     const int groups = cin >> 4;                     // groups of CN_PF (=4) k-steps per kernel tap
     const float* wrow = wt + (size_t)lk * cout + nt0 * 16 + li;
@@ -162,15 +160,10 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
     using std::integral_constant;
 #pragma unroll 1
     for (int s = 0; s < 9; s++) {
-        const int ky = s / 3 - 1, kx = s % 3 - 1;
+        const int ky = s / 3 - 1;
         int io[MT];                                                     // lane's position in its channel row, per tile
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            int y = ey[t] + ky, x = ax[t] + kx;
-            x = x < 0 ? x + 20 : (x >= 20 ? x - 20 : x);
-            const bool ok = y >= 0 && y < 7 && t < mt_cnt;
-            io[t] = ok ? y * 20 + x : CN_POS;                           // pad column 140 of every channel row holds 0
-        }
+        for (int t = 0; t < MT; t++) io[t] = postab[s * CN_TAB + (mt0 + t) * 16 + li];      // tiles past mt_cnt: zero column
         const float* ws = wrow + (size_t)s * cin * cout;
         // M-tiles whose 16 positions all read the zero elevation padding under this tap contribute exactly 0 and are
         // skipped: tile 0 (positions 0..15, elevation row 0) for ky = -1, tile 8 (128..143: row 6 + the 4 padding
@@ -186,30 +179,41 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
     // The layer's output overwrites its input IN PLACE (one 72 KB LDS buffer per workgroup, so two workgroups
     // fit a CU and one computes while the other loads/stores): every wavefront has finished reading `in` here.
     __syncthreads();
-    // epilogue: bias (+ReLU); C/D layout: col = lane & 15 (n), rows (lane >> 4)*4 + r (m)
+    // epilogue: ReLU + store; C/D layout: col = lane & 15 (n), rows (lane >> 4)*4 + r (m).  Only the last M-tile has
+    // rows past position 139 (its lanes with lk == 3); the branches below are wave-uniform except that one.
+    const bool last_rows_ok = lk * 4 + 128 < CN_POS;
 #pragma unroll
     for (int u = 0; u < NT; u++) {
         const int n = (nt0 + u) * 16 + li;
-        const float bv = bias[n];
 #pragma unroll
         for (int t = 0; t < MT; t++) {
+            if (t >= mt_cnt) continue;
             const int m = (mt0 + t) * 16 + lk * 4;
-            if (t < mt_cnt && m < CN_POS) {
-                f32x4 v = acc[t][u];
-                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                // two typed stores (global_store / ds_write), not one flat store through a selected pointer
-                if (out_glb) *reinterpret_cast<f32x4*>(out_glb + (size_t)n * CN_POS + m) = v;
-                else         *reinterpret_cast<f32x4*>(out_lds + n * CN_STR + m) = v;
-            }
+            f32x4 v = acc[t][u];
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (mt0 + t == CN_MT - 1 && !last_rows_ok) continue;
+            // two typed stores (global_store / ds_write), not one flat store through a selected pointer
+            if (out_glb) *reinterpret_cast<f32x4*>(out_glb + (size_t)n * CN_POS + m) = v;
+            else         *reinterpret_cast<f32x4*>(out_lds + n * CN_STR + m) = v;
         }
     }
 }
 
 __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restrict__ x, CylNetParams P, float* __restrict__ y)
 {
-    extern __shared__ float lds[];                   // [128][144] fp32 (140 positions + bank padding)
+    extern __shared__ float lds[];                   // [128][144] fp32 (140 positions + bank padding), then the tap table
     float* buf0 = lds;
+    // postab[tap][m]: position (within a channel row) that output position m reads under kernel tap (ky,kx): circular
+    // azimuth, the zero column 140 for the zero elevation padding and for the tile padding m >= 140.  Built once per
+    // workgroup; a tap then costs one ds_read_u16 per M-tile instead of ~12 VALU.
+    unsigned short* postab = reinterpret_cast<unsigned short*>(lds + CN_BUF);
+    for (int i = threadIdx.x; i < 9 * CN_TAB; i += CN_THREADS) {
+        const int s = i / CN_TAB, m = i - s * CN_TAB;
+        const int ky = s / 3 - 1, kx = s % 3 - 1;
+        int y = m / 20 + ky, x = m % 20 + kx;
+        x = x < 0 ? x + 20 : (x >= 20 ? x - 20 : x);
+        postab[i] = (unsigned short)((m < CN_POS && y >= 0 && y < 7) ? y * 20 + x : CN_POS);
+    }
     const int patch = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);     // wave-uniform: tile ranges branch on it
 #if CYL_PRIO == 2
@@ -233,11 +237,11 @@ __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restri
     for (int l = 0; l < CN_LAYERS; l++) {
         const int cin = P.cin[l], cout = P.cout[l];
         float* glb = l == CN_LAYERS - 1 ? y + (size_t)patch * cout * CN_POS : nullptr;
-        if (cout == 128)      cyl_layer<CN_MT, 2>(in, out, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], 0, CN_MT, 2 * w);
-        else if (cout == 64)  cyl_layer<CN_MT, 1>(in, out, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], 0, CN_MT, w);
+        if (cout == 128)      cyl_layer<CN_MT, 2>(in, out, glb, postab, P.wt[l], P.bias[l], cin, cout, P.relu[l], 0, CN_MT, 2 * w);
+        else if (cout == 64)  cyl_layer<CN_MT, 1>(in, out, glb, postab, P.wt[l], P.bias[l], cin, cout, P.relu[l], 0, CN_MT, w);
         else {                // cout == 32: two wavefronts share an N-tile and split the M-tiles 5 / 4
             const int half = w & 1;
-            cyl_layer<5, 1>(in, out, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], half * 5, half ? 4 : 5, w >> 1);
+            cyl_layer<5, 1>(in, out, glb, postab, P.wt[l], P.bias[l], cin, cout, P.relu[l], half * 5, half ? 4 : 5, w >> 1);
         }
         __syncthreads();
     }
@@ -259,7 +263,7 @@ extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* cons
                     BUF_EINVAL, "buf_cylindrical_net: layer %d has unsupported widths %d -> %d", l, P.cin[l], P.cout[l]);
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net: layer %d width mismatch", l);
     }
-    size_t lds = sizeof(float) * CN_BUF;
+    size_t lds = sizeof(float) * CN_BUF + sizeof(unsigned short) * 9 * CN_TAB;
     static bool attr_set = false;
     if (!attr_set) {
         BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cyl_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
