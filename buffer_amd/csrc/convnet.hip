@@ -85,6 +85,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CYL_EXP_B(x) (x)
 #endif
 
+// -DCYL_PROF: cycle accounting of one wavefront (workgroup 300, wave 0) into g_cyl_prof, read back by
+// buf_debug_cyl_prof (development aid; not in the header): [0] tap loops, [1] MFMAs issued, [2] barrier before the
+// epilogue, [3] epilogue, [4] barrier after the layer, [5] whole kernel, [6] tap set-up (table reads, dispatch).
+#ifdef CYL_PROF
+__device__ unsigned long long g_cyl_prof[8];
+#define PROF_T() __builtin_readcyclecounter()
+#define PROF_ADD(i, dt) if (blockIdx.x == 300 && threadIdx.x == 0) g_cyl_prof[i] += (dt);
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(i, dt)
+#endif
 struct CylNetParams {
     const float* wt[CN_LAYERS];     // [9*Cin][Cout] row-major, BN folded
     const float* bias[CN_LAYERS];   // [Cout]
@@ -160,6 +171,7 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
     using std::integral_constant;
 #pragma unroll 1
     for (int s = 0; s < 9; s++) {
+        unsigned long long tp6 = PROF_T();
         const int ky = s / 3 - 1;
         int io[MT];                                                     // lane's position in its channel row, per tile
 #pragma unroll
@@ -171,14 +183,21 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         // drops its unused fifth tile.
         const bool skip_first = ky < 0 && mt0 == 0;
         const int t1 = mt_cnt - ((ky > 0 && mt0 + mt_cnt == CN_MT) ? 1 : 0);
+        unsigned long long tp0 = PROF_T();
+        PROF_ADD(6, tp0 - tp6)
         if (skip_first) run_tap(integral_constant<int, 1>{}, integral_constant<int, MT>{}, io, ws);
         else if (t1 == MT) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT>{}, io, ws);
         else if (t1 == MT - 1) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT - 1>{}, io, ws);
         else if constexpr (MT == 5) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT - 2>{}, io, ws);
+        PROF_ADD(0, PROF_T() - tp0)
+        PROF_ADD(1, (unsigned long long)(groups * CN_PF * NT * (t1 - (skip_first ? 1 : 0))))
     }
     // The layer's output overwrites its input IN PLACE (one 72 KB LDS buffer per workgroup, so two workgroups
     // fit a CU and one computes while the other loads/stores): every wavefront has finished reading `in` here.
+    unsigned long long tp1 = PROF_T();
     __syncthreads();
+    PROF_ADD(2, PROF_T() - tp1)
+    tp1 = PROF_T();
     // epilogue: ReLU + store; C/D layout: col = lane & 15 (n), rows (lane >> 4)*4 + r (m).  Only the last M-tile has
     // rows past position 139 (its lanes with lk == 3); the branches below are wave-uniform except that one.
     const bool last_rows_ok = lk * 4 + 128 < CN_POS;
@@ -197,6 +216,7 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
             else         *reinterpret_cast<f32x4*>(out_lds + n * CN_STR + m) = v;
         }
     }
+    PROF_ADD(3, PROF_T() - tp1)
 }
 
 __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restrict__ x, CylNetParams P, float* __restrict__ y)
@@ -216,6 +236,7 @@ __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restri
     }
     const int patch = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);     // wave-uniform: tile ranges branch on it
+    unsigned long long tk0 = PROF_T();
 #if CYL_PRIO == 2
     if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2);
 #endif
@@ -243,9 +264,16 @@ __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restri
             const int half = w & 1;
             cyl_layer<5, 1>(in, out, glb, postab, P.wt[l], P.bias[l], cin, cout, P.relu[l], half * 5, half ? 4 : 5, w >> 1);
         }
+        unsigned long long tb = PROF_T();
         __syncthreads();
+        PROF_ADD(4, PROF_T() - tb)
     }
+    PROF_ADD(5, PROF_T() - tk0)
 }
+
+#ifdef CYL_PROF
+extern "C" int buf_debug_cyl_prof(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cyl_prof), sizeof(g_cyl_prof)); }
+#endif
 
 // x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140].  wt/bias: DEVICE pointers per layer, passed in host arrays.
 extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
