@@ -72,7 +72,7 @@ _SIGNATURES = {
     "buf_knn_normals": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "buf_segment_instance_norm_ws_bytes": (_sz, [_i, _i]),
     "buf_segment_instance_norm": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _vp, _sz, _vp]),
-    "buf_descriptor_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_descriptor_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "buf_cost_volume_net": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "buf_hypotheses_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_ransac_ws_bytes": (_sz, [_i]),

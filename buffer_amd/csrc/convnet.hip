@@ -111,7 +111,10 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
                                           const unsigned short* __restrict__ postab, const float* __restrict__ wt,
                                           const float* __restrict__ bias, int cin, int cout, int relu, int mt0, int mt_cnt, int nt0)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
+    int lane = threadIdx.x & (WAVE - 1);
+    // keep every lane-derived offset of this layer inside the layer: hoisted out of the layer loop (for all three
+    // instantiations at once) they outlive 256 VGPRs and are spilled to scratch, 32 KB of HBM traffic per patch
+    asm volatile("" : "+v"(lane));
     const int li = lane & 15, lk = lane >> 4;
     // accumulators start at the bias of their output channel (C/D layout: column = lane & 15): no bias pass afterwards
     f32x4 acc[MT][NT];
@@ -319,37 +322,38 @@ extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* cons
 #define DH_C 32
 #define DH_HID 16
 
-struct DescHeadParams {
-    float w0[DH_HID][DH_C];   // pool_layer.0 with pool_layer.1 (BatchNorm) folded
-    float b0[DH_HID];
-    float w3[DH_HID];         // pool_layer.3 with pool_layer.4 folded
-    float b3;
-};
+#define DH_NPARAM (DH_HID * DH_C + DH_HID + DH_HID + 1)
+// params (DEVICE, DH_NPARAM floats): w0[16][32] (pool_layer.0 with pool_layer.1 BatchNorm folded), b0[16],
+// w3[16] (pool_layer.3 with pool_layer.4 folded), b3
 
-__global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restrict__ y, DescHeadParams H,
+__global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restrict__ y, const float* __restrict__ params,
                                                        float* __restrict__ desc, float* __restrict__ equi)
 {
     __shared__ float ys[DH_C * CN_POS];
     __shared__ float wgt[CN_POS], nrm[CN_POS], fs[DH_C];
+    __shared__ float hp[DH_NPARAM + 3];
     const int patch = blockIdx.x, tid = threadIdx.x;
     const f32x4* src = reinterpret_cast<const f32x4*>(y + (size_t)patch * DH_C * CN_POS);
     for (int i = tid; i < DH_C * CN_POS / 4; i += DH_THREADS) reinterpret_cast<f32x4*>(ys)[i] = src[i];
+    for (int i = tid; i < DH_NPARAM; i += DH_THREADS) hp[i] = params[i];
     __syncthreads();
+    const float* w0 = hp;
+    const float* b0 = hp + DH_HID * DH_C;
+    const float* w3 = b0 + DH_HID;
     if (tid < CN_POS) {
         float h[DH_HID];
 #pragma unroll
-        for (int j = 0; j < DH_HID; j++) h[j] = H.b0[j];
+        for (int j = 0; j < DH_HID; j++) h[j] = b0[j];
         float ss = 0.f;
-#pragma unroll
         for (int c = 0; c < DH_C; c++) {
             const float v = ys[c * CN_POS + tid];
             ss += v * v;
 #pragma unroll
-            for (int j = 0; j < DH_HID; j++) h[j] += H.w0[j][c] * v;
+            for (int j = 0; j < DH_HID; j++) h[j] += w0[j * DH_C + c] * v;        // LDS broadcast reads
         }
-        float a = H.b3;
+        float a = w3[DH_HID];                                                     // b3
 #pragma unroll
-        for (int j = 0; j < DH_HID; j++) a += H.w3[j] * fmaxf(h[j], 0.f);
+        for (int j = 0; j < DH_HID; j++) a += w3[j] * fmaxf(h[j], 0.f);
         wgt[tid] = fmaxf(a, 0.f);
         nrm[tid] = fmaxf(sqrtf(ss), 1e-12f);                     // F.normalize: x / max(||x||, eps)
     }
@@ -374,17 +378,13 @@ __global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restric
     }
 }
 
-// y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].  w0 [16][32], b0 [16], w3 [16], b3 [1]: HOST arrays (BN folded).
-extern "C" int buf_descriptor_head(const float* y, int npatch, const float* w0_host, const float* b0_host,
-                                   const float* w3_host, const float* b3_host, float* desc, float* equi, void* stream)
+// y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].  params: DEVICE f32[545] = w0 [16][32], b0 [16], w3 [16], b3 (BN folded).
+extern "C" int buf_descriptor_head(const float* y, int npatch, const float* params, float* desc, float* equi, void* stream)
 {
     BUF_REQUIRE(npatch >= 0, BUF_EINVAL, "buf_descriptor_head: npatch=%d", npatch);
     if (npatch == 0) return BUF_OK;
-    BUF_REQUIRE(y && w0_host && b0_host && w3_host && b3_host && desc && equi, BUF_EINVAL, "buf_descriptor_head: null argument");
-    DescHeadParams H;
-    memcpy(H.w0, w0_host, sizeof(H.w0)); memcpy(H.b0, b0_host, sizeof(H.b0));
-    memcpy(H.w3, w3_host, sizeof(H.w3)); H.b3 = b3_host[0];
-    k_desc_head<<<npatch, DH_THREADS, 0, (hipStream_t)stream>>>(y, H, desc, equi);
+    BUF_REQUIRE(y && params && desc && equi, BUF_EINVAL, "buf_descriptor_head: null argument");
+    k_desc_head<<<npatch, DH_THREADS, 0, (hipStream_t)stream>>>(y, params, desc, equi);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

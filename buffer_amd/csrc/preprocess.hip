@@ -296,17 +296,18 @@ __global__ void __launch_bounds__(64) k_knn_normals(const float* __restrict__ pt
     if (row >= nq) return;
     const int qi = qidx ? qidx[row] : row;
     const double qx = pts[3 * (size_t)qi], qy = pts[3 * (size_t)qi + 1], qz = pts[3 * (size_t)qi + 2];
-    double d2[NRM_MAXC];
-    int id[NRM_MAXC];
+    // candidate distances / ids live in LDS columns (one per lane): 48 fp64 + 48 int per lane would not fit registers
+    __shared__ double d2s[NRM_MAXC][64];
+    __shared__ int ids[NRM_MAXC][64];
+    const int ln = threadIdx.x;
     int nvalid = 0;
-#pragma unroll
-    for (int j = 0; j < NRM_MAXC; j++) {
-        int c = j < ncand ? cand[(size_t)row * ncand + j] : ns;
-        bool ok = c >= 0 && c < ns;
-        id[j] = ok ? c : 0x7fffffff;
+    for (int j = 0; j < ncand; j++) {
+        const int c = cand[(size_t)row * ncand + j];
+        const bool ok = c >= 0 && c < ns;
         double dx = 0.0, dy = 0.0, dz = 0.0;
         if (ok) { dx = (double)pts[3 * (size_t)c] - qx; dy = (double)pts[3 * (size_t)c + 1] - qy; dz = (double)pts[3 * (size_t)c + 2] - qz; }
-        d2[j] = ok ? dx * dx + dy * dy + dz * dz : 1e300;
+        ids[j][ln] = ok ? c : 0x7fffffff;
+        d2s[j][ln] = ok ? dx * dx + dy * dy + dz * dz : 1e300;
         nvalid += ok ? 1 : 0;
     }
     // a short list holds the whole search ball and must reach min(knn, ns) points; a full one holds the ncand nearest
@@ -315,13 +316,17 @@ __global__ void __launch_bounds__(64) k_knn_normals(const float* __restrict__ pt
     deficient[row] = 0;
     double cum[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int taken = 0;
-#pragma unroll
-    for (int j = 0; j < NRM_MAXC; j++) {
+    for (int j = 0; j < ncand; j++) {
+        const double dj = d2s[j][ln];
+        const int ij = ids[j][ln];
+        if (ij == 0x7fffffff) continue;
         int rank = 0;
-#pragma unroll
-        for (int t = 0; t < NRM_MAXC; t++) rank += (d2[t] < d2[j] || (d2[t] == d2[j] && id[t] < id[j])) ? 1 : 0;
-        if (id[j] != 0x7fffffff && rank < need) {
-            const size_t c = (size_t)id[j];
+        for (int t = 0; t < ncand; t++) {
+            const double dt = d2s[t][ln];
+            rank += (dt < dj || (dt == dj && ids[t][ln] < ij)) ? 1 : 0;
+        }
+        if (rank < need) {
+            const size_t c = (size_t)ij;
             const double x = pts[3 * c], y = pts[3 * c + 1], z = pts[3 * c + 2];
             cum[0] += x; cum[1] += y; cum[2] += z;
             cum[3] += x * x; cum[4] += x * y; cum[5] += x * z; cum[6] += y * y; cum[7] += y * z; cum[8] += z * z;

@@ -435,10 +435,10 @@ class CylindricalNet:
 class DescriptorHead:
     """Attention pooling + normalisation head (patch_embedder.py:66-72,81-84) for csrc/convnet.hip k_desc_head."""
 
-    def __init__(self, w0, b0, w3, b3):
-        """w0 [16,32], b0 [16], w3 [16], b3 [1]: np.float32, BatchNorms folded"""
-        f = lambda a, shape: np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(shape))
-        self.w0, self.b0, self.w3, self.b3 = f(w0, (16, 32)), f(b0, (16,)), f(w3, (16,)), f(b3, (1,))
+    def __init__(self, w0, b0, w3, b3, device):
+        """w0 [16,32], b0 [16], w3 [16], b3 [1]: np.float32, BatchNorms folded -> one device parameter block"""
+        f = lambda a, n: np.asarray(a, dtype=np.float32).reshape(n)
+        self.params = torch.from_numpy(np.concatenate([f(w0, 512), f(b0, 16), f(w3, 16), f(b3, 1)])).to(device)
 
     def __call__(self, y):
         """y f32[P,32,7,20] -> desc f32[P,32], equi f32[P,32,7,20]"""
@@ -448,9 +448,7 @@ class DescriptorHead:
         assert y.dtype == torch.float32 and y.numel() == P * 32 * 140
         desc = torch.empty((P, 32), dtype=torch.float32, device=y.device)
         equi = torch.empty((P, 32, 7, 20), dtype=torch.float32, device=y.device)
-        hp = lambda a: a.ctypes.data_as(C.c_void_p)
-        check(L.buf_descriptor_head(_ptr(y), P, hp(self.w0), hp(self.b0), hp(self.w3), hp(self.b3), _ptr(desc), _ptr(equi),
-                                    _stream()), "buf_descriptor_head")
+        check(L.buf_descriptor_head(_ptr(y), P, _ptr(self.params), _ptr(desc), _ptr(equi), _stream()), "buf_descriptor_head")
         return desc, equi
 
 

@@ -71,7 +71,7 @@ class PatchEmbedder:
         w3, b3 = _fold_bn(W[f'{q}.3.weight'], W[f'{q}.3.bias'], W[f'{q}.4.running_mean'], W[f'{q}.4.running_var'],
                           W[f'{q}.4.weight'], W[f'{q}.4.bias'])
         self.pool = [(t(w0), t(b0)), (t(w3), t(b3))]
-        self.fused_head = ops.DescriptorHead(w0, b0, w3, b3)
+        self.fused_head = ops.DescriptorHead(w0, b0, w3, b3, device)
 
     @staticmethod
     def _pad(x):

@@ -221,9 +221,8 @@ int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_h
 /* A11 (head)  attention pooling + normalisation (models/patch_embedder.py:66-72,81-84): pool_layer
  * (Conv2d 1x1 32->16 + BN + ReLU, Conv2d 1x1 16->1 + BN + ReLU), desc = normalize(mean(y * w)),
  * equi = normalize(y, channel).  y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].
- * w0 [16][32], b0 [16], w3 [16], b3 [1]: HOST arrays with the BatchNorms folded. */
-int     buf_descriptor_head(const float* y, int npatch, const float* w0_host, const float* b0_host,
-                            const float* w3_host, const float* b3_host, float* desc, float* equi, void* stream);
+ * params: DEVICE f32[545] = w0 [16][32], b0 [16], w3 [16], b3 [1] with the BatchNorms folded. */
+int     buf_descriptor_head(const float* y, int npatch, const float* params, float* desc, float* equi, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A13  CostVolume + CostNet (models/BUFFER.py:37-66, models/patchnet.py:88-147) fused on fp32 MFMA: the
