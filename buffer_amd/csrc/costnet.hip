@@ -15,6 +15,8 @@
 #define CV_THREADS 256
 #define CV_BUF 18432              // floats per ping-pong buffer (128 ch x 144 positions)
 #define CV_LAYERS 10
+#define CV_RS 72                  // LDS row strides of the layer-0 row buffer R and of the shift-row ring D: 72 and 304 floats
+#define CV_DS 304                 // (= 8 and 16 mod 32 banks) spread the four channel rows of an A-fragment read over all banks
 #ifndef CV_EXP
 #define CV_EXP 0     // timing experiments only: 1 = no layer-0 GEMM, 2 = no layer-1 GEMM, 4 = no layers 2..9, 8 = no cost rows
 #endif
@@ -177,31 +179,41 @@ struct L0Loader {
         const int tap = g >> 1, cg = g & 1;
         const int dn = tap / 9, r = tap - dn * 9, dk = r / 3, dl = r - dk * 3;
 #pragma unroll
-        for (int p = 0; p < 4; p++) a[p][0] = row[dn][(cg * 4 + p) * 1200 + dk * 20 + dl];
+        for (int p = 0; p < 4; p++) a[p][0] = row[dn][(cg * 4 + p) * 4 * CV_DS + dk * 20 + dl];
     }
 };
 
-// one shift row of the cost volume into its ring slot (all threads of the workgroup)
+// one shift row of the cost volume into its ring slot (all threads of the workgroup): 8 threads per channel walk the
+// channel's 100 (k,l) entries with stride 8, the circular shift is one add and one wrap per entry
 __device__ __forceinline__ void cost_row(float* __restrict__ D, const float* __restrict__ S, const float* __restrict__ T, int n)
 {
-    const int slot = n % 3;
-    for (int i = threadIdx.x; i < 3200; i += CV_THREADS) {
-        const int c = i / 100, r = i - c * 100, k = r / 20, l = r - k * 20;
-        int sh = l - n;
-        sh = sh < 0 ? sh + 20 : sh;
-        D[c * 300 + slot * 100 + r] = S[c * 100 + k * 20 + sh] - T[c * 100 + r];
+    const int c = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const float* Sc = S + c * 100;
+    const float* Tc = T + c * 100;
+    float* Dc = D + c * CV_DS + (n % 3) * 100;
+    const int nn = n % 20;
+    int k20 = 0, l = sub;                                 // r = k20 + l
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+        if (k20 + l < 100) {
+            int sh = l - nn;
+            sh = sh < 0 ? sh + 20 : sh;
+            Dc[k20 + l] = Sc[k20 + sh] - Tc[k20 + l];
+        }
+        l += 8;
+        if (l >= 20) { l -= 20; k20 += 20; }
     }
 }
 
 // layer 1 contribution of one layer-0 row: A[m=l''][tap=(dk,dl), c] = R[c][dk*18 + l''+dl];  K = tap*32 + c (per dn)
 struct L1Loader {
-    const float* base;                                   // R + lk*64 + l''
+    const float* base;                                   // R + lk*CV_RS + l''
     __device__ __forceinline__ void load(float (&a)[4][1], int g) const
     {
         const int tap = g >> 1, cg = g & 1;
         const int dk = tap / 3, dl = tap - dk * 3;
 #pragma unroll
-        for (int p = 0; p < 4; p++) a[p][0] = base[(cg * 4 + p) * 256 + dk * 18 + dl];
+        for (int p = 0; p < 4; p++) a[p][0] = base[(cg * 4 + p) * 4 * CV_RS + dk * 18 + dl];
     }
 };
 
@@ -210,11 +222,14 @@ struct L1Loader {
 // weight offset is an immediate on one per-tile base register, so a group of 4 k-steps issues only its loads
 // and MFMAs (the generic runtime-indexed form spent more issue cycles on addresses than on MFMAs).
 // Operands of group g+1 (possibly the first group of the next tap) are loaded while group g multiplies.
-template <int MT, int NT, int CIN, int COUT, int WIN, int KW>
+// PSI / PSO: channel-row strides (floats) of the input / output maps in LDS, >= the map size and = 8 or 16 mod 32 so
+// that the four channel rows of an A-fragment read fall on disjoint bank halves (a stride = 0 mod 32 is a 4-way conflict).
+template <int MT, int NT, int CIN, int COUT, int WIN, int KW, int PSI, int PSO>
 __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wt,
                                               const float* __restrict__ bias, int nt0, bool relu)
 {
-    constexpr int WOUT = WIN - KW + 1, P = WOUT * WOUT, PLANE = WIN * WIN, GPT = CIN / 16, TAPS = KW * KW;
+    constexpr int WOUT = WIN - KW + 1, P = WOUT * WOUT, GPT = CIN / 16, TAPS = KW * KW;
+    static_assert(PSI >= WIN * WIN && PSO >= P && PSO % 4 == 0, "row strides");
     static_assert(GPT % 2 == 0, "two pipeline slots alternate per channel group");
     const int lane = threadIdx.x & (WAVE - 1), li = lane & 15, lk = lane >> 4;
     const float* pa[MT];                 // lane's A element of tile t at tap (0,0), channel lk
@@ -222,14 +237,16 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
     for (int t = 0; t < MT; t++) {
         int m = t * 16 + li;
         m = m < P ? m : P - 1;           // padding rows of the last tile recompute position P-1 (never stored)
-        pa[t] = in + lk * PLANE + (m / WOUT) * WIN + (m % WOUT);
+        pa[t] = in + lk * PSI + (m / WOUT) * WIN + (m % WOUT);
     }
     const float* wl = wt + (size_t)lk * COUT + nt0 * 16 + li;
-    cvx4 acc[MT][NT];
+    cvx4 acc[MT][NT];                    // start at the bias of the output channel (C/D layout: column = lane & 15)
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+    for (int u = 0; u < NT; u++) {
+        const float bv = bias[(nt0 + u) * 16 + li];
 #pragma unroll
-        for (int u = 0; u < NT; u++) acc[t][u] = (cvx4){ 0.f, 0.f, 0.f, 0.f };
+        for (int t = 0; t < MT; t++) acc[t][u] = (cvx4){ bv, bv, bv, bv };
+    }
     float a[2][4][MT], b[2][4][NT];
 #define CVC_LOAD(SLOT, PTRS, WTAP, CG)                                                                    \
     {                                                                                                     \
@@ -239,7 +256,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
             _Pragma("unroll") for (int u = 0; u < NT; u++) b[SLOT][p][u] = wg_[p * 4 * COUT + u * 16];    \
         }                                                                                                 \
         _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
-            _Pragma("unroll") for (int t = 0; t < MT; t++) a[SLOT][p][t] = PTRS[t][((CG) * 4 + p) * 4 * PLANE]; \
+            _Pragma("unroll") for (int t = 0; t < MT; t++) a[SLOT][p][t] = PTRS[t][((CG) * 4 + p) * 4 * PSI]; \
         }                                                                                                 \
     }
     const float* cur[MT];
@@ -275,19 +292,24 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
         wcur = wnxt;
     }
 #undef CVC_LOAD
+    // epilogue: ReLU + store.  The four rows a lane holds of a tile (m = 16t + 4lk + r) are all inside or all outside
+    // the map whenever P is a multiple of 4: one 16-byte store; the 1x1 map of the last layer stores row 0 only.
 #pragma unroll
     for (int u = 0; u < NT; u++) {
         const int n = (nt0 + u) * 16 + li;
-        const float bv = bias[n];
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+        for (int t = 0; t < MT; t++) {
+            const int m = t * 16 + lk * 4;
+            cvx4 v = acc[t][u];
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if constexpr (P % 4 == 0) {
+                if (m < P) *reinterpret_cast<cvx4*>(out + n * PSO + m) = v;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int m = t * 16 + lk * 4 + r;
-                float v = acc[t][u][r] + bv;
-                if (relu) v = fmaxf(v, 0.f);
-                if (m < P) out[n * P + m] = v;
+                for (int r = 0; r < 4; r++)
+                    if (m + r < P) out[n * PSO + m + r] = v[r];
             }
+        }
     }
 }
 
@@ -299,8 +321,8 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     float* bufB = lds + CV_BUF;              // phase A: S, T and the layer-0 row buffer live here
     float* S = bufB;
     float* T = bufB + 3200;
-    float* R = bufB + 6400;                  // [32][64]
-    float* D = bufB + 8448;                  // [32][3][100] ring of cost-volume shift rows (ends at 18048 <= CV_BUF)
+    float* R = bufB + 6400;                  // [32][CV_RS]: row stride 72 -> the 4 channel rows of a fragment read hit disjoint bank halves
+    float* D = bufB + 6400 + 32 * CV_RS;     // [32][CV_DS] (3 x 100 used): ring of cost-volume shift rows; ends exactly at CV_BUF
     const int match = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE, li = lane & 15, lk = lane >> 4;
     {
@@ -320,6 +342,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     // layer 1: wave w owns N-tile w (16 of the 64 output channels), one M-tile = the 16 l'' of row n''.
     cvx4 win0 = (cvx4){ 0.f, 0.f, 0.f, 0.f }, win1 = win0, win2 = win0;      // rows n', n'-1, n'-2
     const float b1v = P.bias[1][w * 16 + li];
+    const float b0v[2] = { P.bias[0][li], P.bias[0][16 + li] };
     int m0 = w * 16 + li;
     m0 = m0 < 54 ? m0 : 53;
 #pragma unroll 1
@@ -329,24 +352,21 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         {
             L0Loader L;
 #pragma unroll
-            for (int dn = 0; dn < 3; dn++) L.row[dn] = D + lk * 300 + ((nrow + dn) % 3) * 100 + (m0 / 18) * 20 + (m0 % 18);
-            cvx4 acc[1][2] = { { (cvx4){ 0.f, 0.f, 0.f, 0.f }, (cvx4){ 0.f, 0.f, 0.f, 0.f } } };
+            for (int dn = 0; dn < 3; dn++) L.row[dn] = D + lk * CV_DS + ((nrow + dn) % 3) * 100 + (m0 / 18) * 20 + (m0 % 18);
+            cvx4 acc[1][2] = { { (cvx4){ b0v[0], b0v[0], b0v[0], b0v[0] }, (cvx4){ b0v[1], b0v[1], b0v[1], b0v[1] } } };   // bias first
             if (!(CV_EXP & 1)) cv_gemm_static<1, 2, 4, 54>(acc, L, P.wt[0] + (size_t)lk * 32 + li, 32);
+            // R rows are 64 wide, layer 1 reads columns 0..53 only: the four rows of a lane go out as one 16-byte store
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int n = u * 16 + li;
-                const float bv = P.bias[0][n];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int m = w * 16 + lk * 4 + r;
-                    if (m < 54) R[n * 64 + m] = fmaxf(acc[0][u][r] + bv, 0.f);
-                }
+                cvx4 v = acc[0][u];
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<cvx4*>(R + (u * 16 + li) * CV_RS + w * 16 + lk * 4) = v;
             }
         }
         __syncthreads();
         if (!(CV_EXP & 2)) {
             L1Loader L;
-            L.base = R + lk * 64 + li;
+            L.base = R + lk * CV_RS + li;
             const float* w1 = P.wt[1] + (size_t)lk * 64 + w * 16 + li;
             cvx4 a[1][1];
             if (nrow <= 15) { a[0][0] = win0; cv_gemm_static<1, 1, 4, 18>(a, L, w1, 64); win0 = a[0][0]; }                         // dn = 0
@@ -356,7 +376,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         if (nrow >= 2) {                     // row n'' = nrow-2 is complete
             const int n2 = nrow - 2;
 #pragma unroll
-            for (int r = 0; r < 4; r++) bufA[(w * 16 + li) * 256 + n2 * 16 + lk * 4 + r] = fmaxf(win2[r] + b1v, 0.f);
+            for (int r = 0; r < 4; r++) bufA[(w * 16 + li) * 264 + n2 * 16 + lk * 4 + r] = fmaxf(win2[r] + b1v, 0.f);
         }
         win2 = win1; win1 = win0; win0 = (cvx4){ 0.f, 0.f, 0.f, 0.f };
         __syncthreads();                     // R is rewritten by the next row
@@ -364,24 +384,24 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
 
     // ---- phase B: layers 2..9, ping-pong bufA <-> bufB ---------------------------------------------------
     if (CV_EXP & 4) return;
-    cv_conv_layer<13, 1, 64, 64, 16, 3>(bufA, bufB, P.wt[2], P.bias[2], w, true);            // 16x16 -> 14x14
+    cv_conv_layer<13, 1, 64, 64, 16, 3, 264, 200>(bufA, bufB, P.wt[2], P.bias[2], w, true);            // 16x16 -> 14x14
     __syncthreads();
-    cv_conv_layer<9, 2, 64, 128, 14, 3>(bufB, bufA, P.wt[3], P.bias[3], 2 * w, true);        // -> 12x12
+    cv_conv_layer<9, 2, 64, 128, 14, 3, 200, 144>(bufB, bufA, P.wt[3], P.bias[3], 2 * w, true);        // -> 12x12
     __syncthreads();
-    cv_conv_layer<7, 2, 128, 128, 12, 3>(bufA, bufB, P.wt[4], P.bias[4], 2 * w, true);       // -> 10x10
+    cv_conv_layer<7, 2, 128, 128, 12, 3, 144, 104>(bufA, bufB, P.wt[4], P.bias[4], 2 * w, true);       // -> 10x10
     __syncthreads();
-    cv_conv_layer<4, 1, 128, 64, 10, 3>(bufB, bufA, P.wt[5], P.bias[5], w, true);            // -> 8x8
+    cv_conv_layer<4, 1, 128, 64, 10, 3, 104, 72>(bufB, bufA, P.wt[5], P.bias[5], w, true);            // -> 8x8
     __syncthreads();
-    cv_conv_layer<3, 1, 64, 64, 8, 3>(bufA, bufB, P.wt[6], P.bias[6], w, true);              // -> 6x6
+    cv_conv_layer<3, 1, 64, 64, 8, 3, 72, 40>(bufA, bufB, P.wt[6], P.bias[6], w, true);              // -> 6x6
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 64, 32, 6, 3>(bufB, bufA, P.wt[7], P.bias[7], w, true);   // -> 4x4
+    if (w < 2) cv_conv_layer<1, 1, 64, 32, 6, 3, 40, 16>(bufB, bufA, P.wt[7], P.bias[7], w, true);   // -> 4x4
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 32, 32, 4, 3>(bufA, bufB, P.wt[8], P.bias[8], w, true);   // -> 2x2
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 4, 3, 16, 4>(bufA, bufB, P.wt[8], P.bias[8], w, true);   // -> 2x2
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2>(bufB, bufA, P.wt[9], P.bias[9], w, false);  // -> 1x1, 20 (+12 zero) logits
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2, 4, 4>(bufB, bufA, P.wt[9], P.bias[9], w, false);  // -> 1x1, 20 (+12 zero) logits
     __syncthreads();
     if (w == 0) {                            // softmax over the 20 logits, expected index (BUFFER.py:63-65)
-        float v = lane < 20 ? bufA[lane] : -3.4e38f;
+        float v = lane < 20 ? bufA[lane * 4] : -3.4e38f;           // row stride 4 of the last map
         float mx = v;
         for (int d = WAVE / 2; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, WAVE));
         float e = lane < 20 ? expf(v - mx) : 0.f;
