@@ -167,3 +167,28 @@ def test_raw_clouds_to_pose(dev):
     rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
     rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
     assert rte < 0.1 and rre < 3.0, (rte, rre)
+
+
+@pytest.mark.gpu
+def test_prepare_fragment_kitti_scale(oracle, dev):
+    """KITTI constants (KITTI/dataset.py:123-178: 0.05 m and 0.30 m voxels) on a LiDAR-shaped scan of ~160 m extent:
+    sparse far rings need several radius growths in the k-NN search; voxel means == oracle bit for bit."""
+    import torch
+    from buffer_amd import preprocess, synth
+    s = synth.make_kitti_pair(seed=2)
+    raw = np.ascontiguousarray(s['src_fds_pts'][:, :3], dtype=np.float32)
+    assert raw.shape[0] > 30000 and np.ptp(raw[:, 0]) > 60
+    it = preprocess.prepare_fragment(torch.from_numpy(raw).to(dev), 0.05, 0.30, seed=4)
+    fds, sds = it['fds_pts'], it['sds_pts']
+    want_fds = oracle.o3d_voxel_down_sample(raw.astype(np.float64), 0.05)
+    want_sds = oracle.o3d_voxel_down_sample(want_fds, 0.30)
+    assert fds.shape[0] == want_fds.shape[0] and sds.shape[0] == want_sds.shape[0]
+    # rows are shuffled by prepare_fragment: compare as sorted sets of f32 rows
+    key = lambda a: a[np.lexsort(a.T[::-1])]
+    np.testing.assert_array_equal(key(fds.cpu().numpy()), key(want_fds.astype(np.float32)))
+    np.testing.assert_array_equal(key(sds[:, :3].cpu().numpy()), key(want_sds.astype(np.float32)))
+    n = sds[:, 3:]
+    assert torch.all((n.norm(dim=1) - 1).abs() < 1e-5) and torch.all((n * (-sds[:, :3])).sum(1) >= 0)
+    want_n = oracle.o3d_estimate_normals(sds[:, :3].cpu().numpy(), knn=30)
+    dots = (n.cpu().numpy() * want_n).sum(1)
+    assert np.mean(dots > 1 - 1e-6) > 0.99 and np.all(dots > 1 - 1e-3), (float(np.mean(dots > 1 - 1e-6)), float(dots.min()))
