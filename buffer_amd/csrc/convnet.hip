@@ -97,7 +97,7 @@ __device__ unsigned long long g_cyl_prof[8];
 #define PROF_ADD(i, dt)
 #endif
 struct CylNetParams {
-    const float* wt[CN_LAYERS];     // [9*Cin][Cout] row-major, BN folded
+    const float* wt[CN_LAYERS];     // [9*Cin][Cout], BN folded, in the MFMA B-operand tiling (blocks [K/16][Cout/16] of [lk][li][p])
     const float* bias[CN_LAYERS];   // [Cout]
     int cin[CN_LAYERS], cout[CN_LAYERS], relu[CN_LAYERS];
 };
@@ -125,7 +125,8 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         for (int t = 0; t < MT; t++) acc[t][u] = (f32x4){ bv, bv, bv, bv };
     }
     const int groups = cin >> 4;                     // groups of CN_PF (=4) k-steps per kernel tap
-    const float* wrow = wt + (size_t)lk * cout + nt0 * 16 + li;
+    const int ntot = cout >> 4;                      // N-tiles of the layer
+    const float* wrow = wt + ((size_t)nt0 * 64 + lane) * 4;      // lane's 16 bytes of block (group 0, N-tile nt0)
     const float* ib = in + lk * CN_STR;              // lane's channel row of k-step 0
     // One kernel tap over the wavefront's M-tiles [T0, T1) (compile-time bounds): ping-pong register sets;
     // sched_barriers pin "issue loads of the next group" in front of "MFMAs of the current group" (the compiler
@@ -136,9 +137,10 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
 #define CYL_LOAD(A, B, G)                                                                              \
     {                                                                                                  \
         const int g_ = (G) < groups ? (G) : groups - 1;   /* prefetch past the tap re-reads its last group */ \
-        const float* wn_ = ws + (size_t)g_ * CN_PF * 4 * cout;                                         \
-        _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
-            _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = CYL_EXP_B(wn_[(size_t)p * 4 * cout + u * 16]); \
+        const float* wn_ = ws + (size_t)g_ * ntot * 256;      /* MFMA-tiled weights: one 16-byte load per N-tile */ \
+        _Pragma("unroll") for (int u = 0; u < NT; u++) {                                               \
+            const f32x4 bv_ = *reinterpret_cast<const f32x4*>(wn_ + u * 256);                          \
+            _Pragma("unroll") for (int p = 0; p < CN_PF; p++) B[p][u] = CYL_EXP_B(bv_[p]);             \
         }                                                                                              \
         _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
             _Pragma("unroll") for (int t = T0; t < T1; t++) A[p][t] = CYL_EXP_A(ib[io[t] + (g_ * CN_PF + p) * 4 * CN_STR]); \
@@ -179,7 +181,7 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         int io[MT];                                                     // lane's position in its channel row, per tile
 #pragma unroll
         for (int t = 0; t < MT; t++) io[t] = postab[s * CN_TAB + (mt0 + t) * 16 + li];      // tiles past mt_cnt: zero column
-        const float* ws = wrow + (size_t)s * cin * cout;
+        const float* ws = wrow + (size_t)s * groups * ntot * 256;
         // M-tiles whose 16 positions all read the zero elevation padding under this tap contribute exactly 0 and are
         // skipped: tile 0 (positions 0..15, elevation row 0) for ky = -1, tile 8 (128..143: row 6 + the 4 padding
         // positions) for ky = +1 -- 6 of 81 (tap, tile) pairs; a 4-tile wavefront of the 32-channel layers also

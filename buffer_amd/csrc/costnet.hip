@@ -9,7 +9,7 @@
 // produced one shift-row (n') at a time into an 8 KB LDS row buffer and immediately consumed by layer 1,
 // whose three live output rows are accumulator tiles in registers (sliding window over n'), so the
 // 124 KB layer-0 activation never exists either.  Layers 2..9 ping-pong between two 72 KB LDS buffers.
-// All GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32), weights ([K][Cout], BN folded) stream from L2.
+// All GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32), weights ([K][Cout] MFMA-tiled, BN folded) stream from L2.
 #include "common.h"
 
 #define CV_THREADS 256
@@ -26,127 +26,49 @@ typedef float cvx4 __attribute__((ext_vector_type(4)));
 // Placement of a group's operand loads against the previous group's MFMAs: CV_SCHED 0 = loads in front of the MFMA
 // block (sched_barrier), 2 = woven into it (after every 2 MFMAs up to 6 VALU/SALU and 2 memory instructions).
 #ifndef CV_SCHED
-#define CV_SCHED 0     // measured: 4.38 ms (0) vs 4.49 ms (2) per 2500 matches -- one wavefront per SIMD here
+#define CV_SCHED 2
 #endif
 #if CV_SCHED == 0
 #define CV_SCHED_MID __builtin_amdgcn_sched_barrier(0);
-#define CV_SCHED_TAIL(NMFMA)
+#define CV_SCHED_TAIL(NMFMA, NMEM)
 #else
 #define CV_SCHED_MID
-#define CV_SCHED_TAIL(NMFMA)                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < ((NMFMA) + 1) / 2; i_++) {                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              \
-        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);                              \
-        __builtin_amdgcn_sched_group_barrier(0x120, 2, 0);                              \
+// after every MFMA: up to 4 VALU/SALU and the group's memory instructions spread evenly (NMEM over NMFMA, rounded up)
+#define CV_SCHED_TAIL(NMFMA, NMEM)                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA); i_++) {                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x120, ((NMEM) + (NMFMA) - 1) / (NMFMA), 0); \
     }
 #endif
-typedef const __attribute__((address_space(1))) float* cv_gptr;
+typedef const __attribute__((address_space(1))) cvx4* cv_gptr;     // global (not flat) 16-byte weight loads
 
 struct CostNetParams {
-    const float* wt[CV_LAYERS];    // [K][Cout] row-major; K ordering documented per layer below; >= 16 spare rows not required
+    const float* wt[CV_LAYERS];    // [K][Cout] in the MFMA tiling described at cv_gemm_static; K ordering per layer below
     const float* bias[CV_LAYERS];
 };
 
-// ---- generic pipelined tile GEMM: acc[t][u] += sum over `total` groups of 4 k-steps -------------------------
+// ---- tile GEMM: acc[t][u] += sum over groups of 4 k-steps ---------------------------------------------------------
 // Loader::load(a, g): fills a[p][t] (p = k-step inside the group, t = M-tile) for group g.
-// wl = wt + lk*cout + nt0*16 + li (lane's B element of k-step 0); rows advance by 4*cout per k-step.
-template <int MT, int NT, typename Loader>
-__device__ __forceinline__ void cv_gemm(cvx4 (&acc)[MT][NT], Loader& L, const float* __restrict__ wl, int cout, int total)
-{
-    float a0[4][MT], b0[4][NT], a1[4][MT], b1[4][NT];
-#define CV_LOAD(A, B, G)                                                                                  \
-    {                                                                                                     \
-        const int g_ = (G) < total ? (G) : total - 1;                                                     \
-        const float* wn_ = wl + (size_t)g_ * 16 * cout;                                                   \
-        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
-            _Pragma("unroll") for (int u = 0; u < NT; u++) B[p][u] = wn_[(size_t)p * 4 * cout + u * 16];  \
-        }                                                                                                 \
-        L.load(A, g_);                                                                                    \
-    }
-#define CV_MMA(A, B)                                                                                      \
-    _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                       \
-        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
-            _Pragma("unroll") for (int u = 0; u < NT; u++)                                                \
-                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[p][t], B[p][u], acc[t][u], 0, 0, 0);   \
-        }                                                                                                 \
-    }
-    CV_LOAD(a0, b0, 0)
-#pragma unroll 1
-    for (int g = 0; g < total; g += 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        CV_LOAD(a1, b1, g + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        CV_MMA(a0, b0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < total) {
-            CV_LOAD(a0, b0, g + 2)
-            __builtin_amdgcn_sched_barrier(0);
-            CV_MMA(a1, b1)
-        }
-    }
-#undef CV_LOAD
-#undef CV_MMA
-}
-
-// Same GEMM for small tiles (MT*NT <= 4 MFMAs per k-step): a group of 4 k-steps is then only 128-512 MFMA cycles,
-// less than an L2 round trip for the weight loads, so operands are prefetched D-1 groups ahead through a
-// register ring of depth D (fully unrolled, static indices).
-template <int MT, int NT, int D, typename Loader>
-__device__ __forceinline__ void cv_gemm_deep(cvx4 (&acc)[MT][NT], Loader& L, const float* __restrict__ wl, int cout, int total)
-{
-    float a[D][4][MT], b[D][4][NT];
-#define CVD_LOAD(SLOT, G)                                                                                 \
-    {                                                                                                     \
-        const int g_ = (G) < total ? (G) : total - 1;                                                     \
-        const float* wn_ = wl + (size_t)g_ * 16 * cout;                                                   \
-        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
-            _Pragma("unroll") for (int u = 0; u < NT; u++) b[SLOT][p][u] = wn_[(size_t)p * 4 * cout + u * 16]; \
-        }                                                                                                 \
-        L.load(a[SLOT], g_);                                                                              \
-    }
-#define CVD_MMA(SLOT)                                                                                     \
-    _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                       \
-        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
-            _Pragma("unroll") for (int u = 0; u < NT; u++)                                                \
-                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SLOT][p][t], b[SLOT][p][u], acc[t][u], 0, 0, 0); \
-        }                                                                                                 \
-    }
-#pragma unroll
-    for (int i = 0; i < D - 1; i++) CVD_LOAD(i, i)
-    const int main_groups = total - total % D;
-#pragma unroll 1
-    for (int g = 0; g < main_groups; g += D) {
-#pragma unroll
-        for (int i = 0; i < D; i++) {
-            __builtin_amdgcn_sched_barrier(0);
-            CVD_LOAD((i + D - 1) % D, g + i + D - 1)
-            __builtin_amdgcn_sched_barrier(0);
-            CVD_MMA(i)
-        }
-    }
-    // tail: groups main_groups .. total-1 are already in slots 0 .. D-2
-#pragma unroll
-    for (int i = 0; i < D - 1; i++)
-        if (main_groups + i < total) CVD_MMA(i)
-#undef CVD_LOAD
-#undef CVD_MMA
-}
-
+// Weights come TILED for the MFMA B operand: block (group g of 16 K-rows, N-tile n) = 256 floats laid out
+// [lane = lk*16 + li][p], so the four B values a lane needs for the four k-steps of a group are ONE 16-byte load and a
+// wavefront reads 1 KB contiguously (W[(16g + 4p + lk)][16n + li]); blocks ordered [g][n].  wl = tiled + (nt0*64 + lane)*4.
 // Fully unrolled variant for a compile-time group count: every tap/channel-group index, LDS offset and weight
 // offset folds to an immediate, so a group costs no address arithmetic at all (the operand loads of the small
 // layer-0/1 tiles otherwise take as many issue cycles as their 4-8 MFMAs).
 template <int MT, int NT, int D, int TOTAL, typename Loader>
-__device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, const float* __restrict__ wl, int cout)
+__device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, const float* __restrict__ wl, int ntot)
 {
     float a[D][4][MT], b[D][4][NT];
 #define CVS_LOAD(SLOT, G)                                                                                 \
     {                                                                                                     \
         /* one address per group, pinned here (not hoisted out of the caller's loop) and typed as global  \
            memory so that the loads stay global_load (in-order vmcnt), not flat_load */                   \
-        cv_gptr wg_ = (cv_gptr)(wl + (G) * 16 * cout);                                                    \
+        cv_gptr wg_ = (cv_gptr)(wl + (size_t)(G) * ntot * 256);                                           \
         asm volatile("" : "+v"(wg_));                                                                     \
-        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
-            _Pragma("unroll") for (int u = 0; u < NT; u++) b[SLOT][p][u] = wg_[p * 4 * cout + u * 16];    \
+        _Pragma("unroll") for (int u = 0; u < NT; u++) {                                                  \
+            const cvx4 bv_ = wg_[u * 64];                                                                 \
+            _Pragma("unroll") for (int p = 0; p < 4; p++) b[SLOT][p][u] = bv_[p];                         \
         }                                                                                                 \
         L.load(a[SLOT], (G));                                                                             \
     }
@@ -164,7 +86,7 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
 #pragma unroll
                 for (int u = 0; u < NT; u++)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % D][p][t], b[g % D][p][u], acc[t][u], 0, 0, 0);
-        CV_SCHED_TAIL(4 * MT * NT)
+        CV_SCHED_TAIL(4 * MT * NT, 4 * (MT + NT))
     }
 #undef CVS_LOAD
 }
@@ -239,7 +161,8 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
         m = m < P ? m : P - 1;           // padding rows of the last tile recompute position P-1 (never stored)
         pa[t] = in + lk * PSI + (m / WOUT) * WIN + (m % WOUT);
     }
-    const float* wl = wt + (size_t)lk * COUT + nt0 * 16 + li;
+    constexpr int NTOT = COUT / 16;
+    const float* wl = wt + ((size_t)nt0 * 64 + lane) * 4;
     cvx4 acc[MT][NT];                    // start at the bias of the output channel (C/D layout: column = lane & 15)
 #pragma unroll
     for (int u = 0; u < NT; u++) {
@@ -250,10 +173,11 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
     float a[2][4][MT], b[2][4][NT];
 #define CVC_LOAD(SLOT, PTRS, WTAP, CG)                                                                    \
     {                                                                                                     \
-        cv_gptr wg_ = (cv_gptr)((WTAP) + (CG) * 16 * COUT);                                               \
+        cv_gptr wg_ = (cv_gptr)((WTAP) + (size_t)(CG) * NTOT * 256);                                      \
         asm volatile("" : "+v"(wg_));                                                                     \
-        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
-            _Pragma("unroll") for (int u = 0; u < NT; u++) b[SLOT][p][u] = wg_[p * 4 * COUT + u * 16];    \
+        _Pragma("unroll") for (int u = 0; u < NT; u++) {                                                  \
+            const cvx4 bv_ = wg_[u * 64];                                                                 \
+            _Pragma("unroll") for (int p = 0; p < 4; p++) b[SLOT][p][u] = bv_[p];                         \
         }                                                                                                 \
         _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
             _Pragma("unroll") for (int t = 0; t < MT; t++) a[SLOT][p][t] = PTRS[t][((CG) * 4 + p) * 4 * PSI]; \
@@ -271,7 +195,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
         const int offn = (tn / KW) * WIN + (tn % KW);
 #pragma unroll
         for (int t = 0; t < MT; t++) nxt[t] = pa[t] + offn;
-        const float* wnxt = wl + (size_t)tn * CIN * COUT;
+        const float* wnxt = wl + (size_t)tn * GPT * NTOT * 256;
 #pragma unroll
         for (int cg = 0; cg < GPT; cg++) {
             __builtin_amdgcn_sched_barrier(0);
@@ -285,7 +209,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
 #pragma unroll
                     for (int u = 0; u < NT; u++)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg & 1][p][t], b[cg & 1][p][u], acc[t][u], 0, 0, 0);
-            CV_SCHED_TAIL(4 * MT * NT)
+            CV_SCHED_TAIL(4 * MT * NT, 4 * (MT + NT))
         }
 #pragma unroll
         for (int t = 0; t < MT; t++) cur[t] = nxt[t];
@@ -354,7 +278,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
 #pragma unroll
             for (int dn = 0; dn < 3; dn++) L.row[dn] = D + lk * CV_DS + ((nrow + dn) % 3) * 100 + (m0 / 18) * 20 + (m0 % 18);
             cvx4 acc[1][2] = { { (cvx4){ b0v[0], b0v[0], b0v[0], b0v[0] }, (cvx4){ b0v[1], b0v[1], b0v[1], b0v[1] } } };   // bias first
-            if (!(CV_EXP & 1)) cv_gemm_static<1, 2, 4, 54>(acc, L, P.wt[0] + (size_t)lk * 32 + li, 32);
+            if (!(CV_EXP & 1)) cv_gemm_static<1, 2, 4, 54>(acc, L, P.wt[0] + (size_t)lane * 4, 2);
             // R rows are 64 wide, layer 1 reads columns 0..53 only: the four rows of a lane go out as one 16-byte store
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -367,11 +291,11 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         if (!(CV_EXP & 2)) {
             L1Loader L;
             L.base = R + lk * CV_RS + li;
-            const float* w1 = P.wt[1] + (size_t)lk * 64 + w * 16 + li;
+            const float* w1 = P.wt[1] + ((size_t)w * 64 + lane) * 4;      // N-tile w of 4; a dn slab = 18 groups
             cvx4 a[1][1];
-            if (nrow <= 15) { a[0][0] = win0; cv_gemm_static<1, 1, 4, 18>(a, L, w1, 64); win0 = a[0][0]; }                         // dn = 0
-            if (nrow >= 1 && nrow <= 16) { a[0][0] = win1; cv_gemm_static<1, 1, 4, 18>(a, L, w1 + (size_t)288 * 64, 64); win1 = a[0][0]; }   // dn = 1
-            if (nrow >= 2) { a[0][0] = win2; cv_gemm_static<1, 1, 4, 18>(a, L, w1 + (size_t)576 * 64, 64); win2 = a[0][0]; }       // dn = 2
+            if (nrow <= 15) { a[0][0] = win0; cv_gemm_static<1, 1, 4, 18>(a, L, w1, 4); win0 = a[0][0]; }                         // dn = 0
+            if (nrow >= 1 && nrow <= 16) { a[0][0] = win1; cv_gemm_static<1, 1, 4, 18>(a, L, w1 + (size_t)18 * 4 * 256, 4); win1 = a[0][0]; }   // dn = 1
+            if (nrow >= 2) { a[0][0] = win2; cv_gemm_static<1, 1, 4, 18>(a, L, w1 + (size_t)36 * 4 * 256, 4); win2 = a[0][0]; }       // dn = 2
         }
         if (nrow >= 2) {                     // row n'' = nrow-2 is complete
             const int n2 = nrow - 2;

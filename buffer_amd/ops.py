@@ -401,8 +401,17 @@ def post_refine(T_init, src, tgt, thr=0.10, iters=20):
 
 
 # ----------------------------------------------------------------------------- fused descriptor CNN
+def mfma_tile_weights(wt):
+    """[K, Cout] (K, Cout multiples of 16) -> the B-operand tiling of the fused MFMA kernels: blocks [K/16][Cout/16] of
+    256 floats laid out [lk][li][p] = wt[16g + 4p + lk][16n + li], so that a lane's four k-steps are one 16-byte load."""
+    K, cout = wt.shape
+    assert K % 16 == 0 and cout % 16 == 0
+    t = wt.reshape(K // 16, 4, 4, cout // 16, 16)            # [g, p, lk, n, li]
+    return np.ascontiguousarray(np.transpose(t, (0, 3, 2, 4, 1)), dtype=np.float32).reshape(-1)   # [g, n, lk, li, p]
+
+
 class CylindricalNet:
-    """Device weights of Cylindrical_Net re-laid for csrc/convnet.hip: per layer Wt[(ky*3+kx)*Cin + c][Cout]."""
+    """Device weights of Cylindrical_Net re-laid for csrc/convnet.hip: per layer Wt[(ky*3+kx)*Cin + c][Cout], MFMA-tiled."""
 
     def __init__(self, layers, device):
         """layers: list of 8 (w [Cout,Cin,3,3] np.float32 with BN folded, b [Cout], relu)"""
@@ -410,8 +419,7 @@ class CylindricalNet:
         for w, b, relu in layers:
             cout, cin = w.shape[0], w.shape[1]
             wt = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)).reshape(9 * cin, cout), dtype=np.float32)
-            wt = np.concatenate([wt, np.zeros((32, cout), np.float32)])       # spare rows for the pipelined over-read
-            self.wt.append(torch.from_numpy(wt).to(device))
+            self.wt.append(torch.from_numpy(mfma_tile_weights(wt)).to(device))
             self.bias.append(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(device))
             self.cin.append(cin); self.cout.append(cout); self.relu.append(1 if relu else 0)
         n = len(layers)
@@ -453,7 +461,7 @@ class DescriptorHead:
 
 
 class CostVolumeNet:
-    """Device weights of CostNet re-laid for csrc/costnet.hip: per layer Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout]."""
+    """Device weights of CostNet re-laid for csrc/costnet.hip: per layer Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout], MFMA-tiled."""
 
     def __init__(self, layers, device):
         """layers: 10 x (w [Cout,Cin,KD,KH,KW] np.float32 with BN folded, b [Cout])"""
@@ -466,7 +474,7 @@ class CostVolumeNet:
             if i == 9:                                    # 20 logits -> two full 16-column tiles
                 wt = np.concatenate([wt, np.zeros((wt.shape[0], 32 - cout), np.float32)], 1)
                 b = np.concatenate([b, np.zeros(32 - cout, np.float32)])
-            self.wt.append(torch.from_numpy(np.ascontiguousarray(wt, dtype=np.float32)).to(device))
+            self.wt.append(torch.from_numpy(mfma_tile_weights(np.ascontiguousarray(wt, dtype=np.float32))).to(device))
             self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
         self._wp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.wt])
         self._bp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.bias])

@@ -212,9 +212,10 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
  * A11 (dense)  Cylindrical_Net (models/patchnet.py:15-85) fused: Conv3d(16->64,3^3) + 7 x Conv2d 3x3 with the
  * reference's circular-azimuth / zero-elevation padding, BN folded, ReLU, on fp32 MFMA; activations stay in LDS.
  * x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140] (= [np,32,7,20]).
- * wt_host[l] / bias_host[l]: HOST arrays of 8 DEVICE pointers: weights [9*Cin][Cout] row-major with
- * k = (ky*3+kx)*Cin + c (layer 0: c = c16*3 + depth) FOLLOWED BY 32 READABLE ROWS (zeros; the software
- * pipeline over-reads one group), biases [Cout]; widths in cin_host/cout_host. */
+ * wt_host[l] / bias_host[l]: HOST arrays of 8 DEVICE pointers: weights W[9*Cin][Cout] with
+ * k = (ky*3+kx)*Cin + c (layer 0: c = c16*3 + depth) in the MFMA B-operand tiling (blocks [K/16][Cout/16] of 256
+ * floats, block (g, n) = [lk][li][p] = W[16g + 4p + lk][16n + li]; see buf_cost_volume_net), biases [Cout]; widths in
+ * cin_host/cout_host. */
 int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                             const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
 
@@ -228,8 +229,10 @@ int     buf_descriptor_head(const float* y, int npatch, const float* params, flo
  * A13  CostVolume + CostNet (models/BUFFER.py:37-66, models/patchnet.py:88-147) fused on fp32 MFMA: the
  * [m,32,20,5,20] cost tensor is never built.  s_eq,t_eq f32[m,32,5,20] (elevation rows 1..ele_n-2 of the
  * equivariant maps) -> ind f32[m] (expected azimuth shift).  wt_host/bias_host: HOST arrays of 10 DEVICE
- * pointers, BN folded; weights [K][Cout] row-major with K = ((dn*KH + dk)*KW + dl)*Cin + c; the last
- * layer (20 outputs) is zero-padded to 32 columns / biases. */
+ * pointers, BN folded; weights W[K][Cout] with K = ((dn*KH + dk)*KW + dl)*Cin + c, the last layer (20 outputs)
+ * zero-padded to 32 columns / biases, stored in the MFMA B-operand tiling: blocks [K/16][Cout/16] of 256 floats,
+ * block (g, n) laid out [lk 0..3][li 0..15][p 0..3] = W[16g + 4p + lk][16n + li]
+ * (buffer_amd.ops.mfma_tile_weights is the host-side re-layout). */
 int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
                             const float* const* bias_host, float* ind_out, void* stream);
 

@@ -34,6 +34,24 @@ __global__ void __launch_bounds__(256, 2) k_peak(float* out, int iters, float a0
     }
 }
 
+// dependent-issue rate: NACC independent accumulators used round-robin (NACC = 1: every MFMA waits for the previous one)
+template <int NACC>
+__global__ void __launch_bounds__(256, 1) k_chain(float* out, int iters, float a0, float b0)
+{
+    float a = a0 + threadIdx.x * 1e-3f, b = b0 - threadIdx.x * 1e-3f;
+    f4 acc[NACC];
+    for (int i = 0; i < NACC; i++) acc[i] = (f4){ 0, 0, 0, 0 };
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 16 / NACC; r++)
+#pragma unroll
+            for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 // 16x16x4 MFMAs with the operand traffic of the conv kernel woven in: per 2 MFMAs one ds_read2st64_b32 whose
 // results feed later MFMAs, plus address VALU; 72 MFMAs per "group" like <MT=9,NT=2>.
 __global__ void __launch_bounds__(256, 2) k_mix(float* out, int iters, int stride, int rnd)
@@ -95,6 +113,20 @@ int main()
             double flop = (double)blocks * 4 * iters * 32768.0;
             printf("mfma_f32_%s: %.2f ms  %.1f TFLOP/s\n", shape == 16 ? "16x16x4" : "32x32x2", ms, flop / ms / 1e9);
         }
+    }
+    for (int nacc = 1; nacc <= 8; nacc *= 2) {
+        const int it3 = 20000, blocks1 = 256;        // one workgroup of 4 wavefronts per CU: one wavefront per SIMD
+        hipEventRecord(e0);
+        if (nacc == 1) k_chain<1><<<blocks1, 256>>>(out, it3, 1.0f, 0.5f);
+        else if (nacc == 2) k_chain<2><<<blocks1, 256>>>(out, it3, 1.0f, 0.5f);
+        else if (nacc == 4) k_chain<4><<<blocks1, 256>>>(out, it3, 1.0f, 0.5f);
+        else k_chain<8><<<blocks1, 256>>>(out, it3, 1.0f, 0.5f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double flop = (double)blocks1 * 4 * it3 * 16 * 2048.0;
+        printf("one wavefront per SIMD, %d independent accumulators: %.2f ms  %.1f TFLOP/s\n", nacc, ms, flop / ms / 1e9);
     }
     hipFuncSetAttribute((const void*)k_mix, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
     for (int rep = 0; rep < 6; rep++) {
