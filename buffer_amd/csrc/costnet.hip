@@ -8,15 +8,21 @@
 // built: layer 0's A operand is formed on the fly as S[c][k][(l-n) mod 20] - T[c][k][l].  Layer 0 is
 // produced one shift-row (n') at a time into an 8 KB LDS row buffer and immediately consumed by layer 1,
 // whose three live output rows are accumulator tiles in registers (sliding window over n'), so the
-// 124 KB layer-0 activation never exists either.  Layers 2..9 ping-pong between two 72 KB LDS buffers.
+// 124 KB layer-0 activation never exists either.  Layers 2..9 ping-pong between two 75 KB LDS buffers.
 // All GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32), weights ([K][Cout] MFMA-tiled, BN folded) stream from L2.
+//
+// Every LDS map is POSITION-major, [position][channels + 4]: the four k-steps of a 16-channel group that a lane feeds
+// to the MFMA A operand (channels 16g + 4lk + 0..3 at its position) are one 16-byte ds_read_b128, and the +4 padding
+// (row stride = 4 mod 32 banks) keeps eight neighbouring positions on distinct bank quads.  With one wavefront per SIMD
+// the number of memory instructions per MFMA, not their bytes, sets the MFMA duty: 1 LDS + 1-2 global loads per group.
 #include "common.h"
 
 #define CV_THREADS 256
-#define CV_BUF 18432              // floats per ping-pong buffer (128 ch x 144 positions)
+#define CV_BUF 19200              // floats per ping-pong buffer (largest map: 144 positions x (128 + 4) channels = 19008)
 #define CV_LAYERS 10
-#define CV_RS 72                  // LDS row strides of the layer-0 row buffer R and of the shift-row ring D: 72 and 304 floats
-#define CV_DS 304                 // (= 8 and 16 mod 32 banks) spread the four channel rows of an A-fragment read over all banks
+#define CV_C32 36                 // position-row strides (floats) of maps with 32 / 64 / 128 channels
+#define CV_C64 68
+#define CV_C128 132
 #ifndef CV_EXP
 #define CV_EXP 0     // timing experiments only: 1 = no layer-0 GEMM, 2 = no layer-1 GEMM, 4 = no layers 2..9, 8 = no cost rows
 #endif
@@ -52,7 +58,8 @@ struct CostNetParams {
 // Loader::load(a, g): fills a[p][t] (p = k-step inside the group, t = M-tile) for group g.
 // Weights come TILED for the MFMA B operand: block (group g of 16 K-rows, N-tile n) = 256 floats laid out
 // [lane = lk*16 + li][p], so the four B values a lane needs for the four k-steps of a group are ONE 16-byte load and a
-// wavefront reads 1 KB contiguously (W[(16g + 4p + lk)][16n + li]); blocks ordered [g][n].  wl = tiled + (nt0*64 + lane)*4.
+// wavefront reads 1 KB contiguously; blocks ordered [g][n].  wl = tiled + (nt0*64 + lane)*4.  K-row of (g, p, lk) is
+// 16g + 4lk + p: k-step p of a group takes channel 4lk + p from every lane quarter, matching the A loads above.
 // Fully unrolled variant for a compile-time group count: every tap/channel-group index, LDS offset and weight
 // offset folds to an immediate, so a group costs no address arithmetic at all (the operand loads of the small
 // layer-0/1 tiles otherwise take as many issue cycles as their 4-8 MFMAs).
@@ -86,22 +93,23 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
 #pragma unroll
                 for (int u = 0; u < NT; u++)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % D][p][t], b[g % D][p][u], acc[t][u], 0, 0, 0);
-        CV_SCHED_TAIL(4 * MT * NT, 4 * (MT + NT))
+        CV_SCHED_TAIL(4 * MT * NT, MT + NT)
     }
 #undef CVS_LOAD
 }
 
 // layer 0: A[m=(k',l')][tap=(dn,dk,dl), c] = cost[c][n'+dn][k'+dk][l'+dl];  K = tap*32 + c.
 // The three shift rows n', n'+1, n'+2 of the cost volume (cost[c][n][k][l] = S[c][k][(l-n) mod 20] - T[c][k][l])
-// live in a 3-slot ring D[c][n mod 3][5][20], so a fragment is ONE LDS read (no arithmetic between load and MFMA).
+// live in a 3-slot ring D[n mod 3][5*20][32+4], so the fragments of a group are ONE LDS read (no arithmetic before the MFMA).
 struct L0Loader {
-    const float* row[3];                                 // lane's element of shift row n'+dn: D + lk*300 + slot*100 + k'*20 + l'
+    const float* row[3];                                 // lane's 4 channels of shift row n'+dn: D + slot*3600 + (k'*20 + l')*36 + lk*4
     __device__ __forceinline__ void load(float (&a)[4][1], int g) const
     {
         const int tap = g >> 1, cg = g & 1;
         const int dn = tap / 9, r = tap - dn * 9, dk = r / 3, dl = r - dk * 3;
+        const cvx4 v = *reinterpret_cast<const cvx4*>(row[dn] + (dk * 20 + dl) * CV_C32 + cg * 16);
 #pragma unroll
-        for (int p = 0; p < 4; p++) a[p][0] = row[dn][(cg * 4 + p) * 4 * CV_DS + dk * 20 + dl];
+        for (int p = 0; p < 4; p++) a[p][0] = v[p];
     }
 };
 
@@ -112,7 +120,7 @@ __device__ __forceinline__ void cost_row(float* __restrict__ D, const float* __r
     const int c = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const float* Sc = S + c * 100;
     const float* Tc = T + c * 100;
-    float* Dc = D + c * CV_DS + (n % 3) * 100;
+    float* Dc = D + (n % 3) * (100 * CV_C32) + c;
     const int nn = n % 20;
     int k20 = 0, l = sub;                                 // r = k20 + l
 #pragma unroll
@@ -120,48 +128,46 @@ __device__ __forceinline__ void cost_row(float* __restrict__ D, const float* __r
         if (k20 + l < 100) {
             int sh = l - nn;
             sh = sh < 0 ? sh + 20 : sh;
-            Dc[k20 + l] = Sc[k20 + sh] - Tc[k20 + l];
+            Dc[(k20 + l) * CV_C32] = Sc[k20 + sh] - Tc[k20 + l];
         }
         l += 8;
         if (l >= 20) { l -= 20; k20 += 20; }
     }
 }
 
-// layer 1 contribution of one layer-0 row: A[m=l''][tap=(dk,dl), c] = R[c][dk*18 + l''+dl];  K = tap*32 + c (per dn)
+// layer 1 contribution of one layer-0 row: A[m=l''][tap=(dk,dl), c] = R[dk*18 + l''+dl][c];  K = tap*32 + c (per dn)
 struct L1Loader {
-    const float* base;                                   // R + lk*CV_RS + l''
+    const float* base;                                   // R + l''*36 + lk*4
     __device__ __forceinline__ void load(float (&a)[4][1], int g) const
     {
         const int tap = g >> 1, cg = g & 1;
         const int dk = tap / 3, dl = tap - dk * 3;
+        const cvx4 v = *reinterpret_cast<const cvx4*>(base + (dk * 18 + dl) * CV_C32 + cg * 16);
 #pragma unroll
-        for (int p = 0; p < 4; p++) a[p][0] = base[(cg * 4 + p) * 4 * CV_RS + dk * 18 + dl];
+        for (int p = 0; p < 4; p++) a[p][0] = v[p];
     }
 };
 
-// layers 2..9: valid (KW x KW) convolution over an LDS-resident [CIN][WIN*WIN] map;  K = (dn*KW + dl)*CIN + c.
+// layers 2..9: valid (KW x KW) convolution over an LDS-resident [WIN*WIN][CIN+4] map;  K = (dn*KW + dl)*CIN + c.
 // The tap loop is a runtime loop, the CIN/16 channel groups of a tap are unrolled: inside a tap every LDS and
 // weight offset is an immediate on one per-tile base register, so a group of 4 k-steps issues only its loads
-// and MFMAs (the generic runtime-indexed form spent more issue cycles on addresses than on MFMAs).
+// (one ds_read_b128 per M-tile, one global_load_dwordx4 per N-tile) and its MFMAs.
 // Operands of group g+1 (possibly the first group of the next tap) are loaded while group g multiplies.
-// PSI / PSO: channel-row strides (floats) of the input / output maps in LDS, >= the map size and = 8 or 16 mod 32 so
-// that the four channel rows of an A-fragment read fall on disjoint bank halves (a stride = 0 mod 32 is a 4-way conflict).
-template <int MT, int NT, int CIN, int COUT, int WIN, int KW, int PSI, int PSO>
+template <int MT, int NT, int CIN, int COUT, int WIN, int KW>
 __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wt,
                                               const float* __restrict__ bias, int nt0, bool relu)
 {
-    constexpr int WOUT = WIN - KW + 1, P = WOUT * WOUT, GPT = CIN / 16, TAPS = KW * KW;
-    static_assert(PSI >= WIN * WIN && PSO >= P && PSO % 4 == 0, "row strides");
+    constexpr int WOUT = WIN - KW + 1, P = WOUT * WOUT, GPT = CIN / 16, TAPS = KW * KW, NTOT = COUT / 16;
+    constexpr int CSI = CIN + 4, CSO = COUT + 4;                        // position-row strides of the two maps
     static_assert(GPT % 2 == 0, "two pipeline slots alternate per channel group");
     const int lane = threadIdx.x & (WAVE - 1), li = lane & 15, lk = lane >> 4;
-    const float* pa[MT];                 // lane's A element of tile t at tap (0,0), channel lk
+    const float* pa[MT];                 // lane's 4 channels (4lk..4lk+3 of group 0) of tile t at tap (0,0)
 #pragma unroll
     for (int t = 0; t < MT; t++) {
         int m = t * 16 + li;
         m = m < P ? m : P - 1;           // padding rows of the last tile recompute position P-1 (never stored)
-        pa[t] = in + lk * PSI + (m / WOUT) * WIN + (m % WOUT);
+        pa[t] = in + ((m / WOUT) * WIN + (m % WOUT)) * CSI + lk * 4;
     }
-    constexpr int NTOT = COUT / 16;
     const float* wl = wt + ((size_t)nt0 * 64 + lane) * 4;
     cvx4 acc[MT][NT];                    // start at the bias of the output channel (C/D layout: column = lane & 15)
 #pragma unroll
@@ -179,8 +185,9 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
             const cvx4 bv_ = wg_[u * 64];                                                                 \
             _Pragma("unroll") for (int p = 0; p < 4; p++) b[SLOT][p][u] = bv_[p];                         \
         }                                                                                                 \
-        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                                   \
-            _Pragma("unroll") for (int t = 0; t < MT; t++) a[SLOT][p][t] = PTRS[t][((CG) * 4 + p) * 4 * PSI]; \
+        _Pragma("unroll") for (int t = 0; t < MT; t++) {                                                  \
+            const cvx4 av_ = *reinterpret_cast<const cvx4*>(PTRS[t] + (CG) * 16);                         \
+            _Pragma("unroll") for (int p = 0; p < 4; p++) a[SLOT][p][t] = av_[p];                         \
         }                                                                                                 \
     }
     const float* cur[MT];
@@ -192,7 +199,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; tap++) {
         const int tn = tap + 1 < TAPS ? tap + 1 : tap;       // the last tap prefetches itself again (unused)
-        const int offn = (tn / KW) * WIN + (tn % KW);
+        const int offn = ((tn / KW) * WIN + (tn % KW)) * CSI;
 #pragma unroll
         for (int t = 0; t < MT; t++) nxt[t] = pa[t] + offn;
         const float* wnxt = wl + (size_t)tn * GPT * NTOT * 256;
@@ -209,31 +216,26 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
 #pragma unroll
                     for (int u = 0; u < NT; u++)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cg & 1][p][t], b[cg & 1][p][u], acc[t][u], 0, 0, 0);
-            CV_SCHED_TAIL(4 * MT * NT, 4 * (MT + NT))
+            CV_SCHED_TAIL(4 * MT * NT, MT + NT)
         }
 #pragma unroll
         for (int t = 0; t < MT; t++) cur[t] = nxt[t];
         wcur = wnxt;
     }
 #undef CVC_LOAD
-    // epilogue: ReLU + store.  The four rows a lane holds of a tile (m = 16t + 4lk + r) are all inside or all outside
-    // the map whenever P is a multiple of 4: one 16-byte store; the 1x1 map of the last layer stores row 0 only.
+    // epilogue: ReLU + store; C/D layout: a lane holds channel n at the four positions m = 16t + 4lk + r
 #pragma unroll
     for (int u = 0; u < NT; u++) {
         const int n = (nt0 + u) * 16 + li;
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const int m = t * 16 + lk * 4;
-            cvx4 v = acc[t][u];
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if constexpr (P % 4 == 0) {
-                if (m < P) *reinterpret_cast<cvx4*>(out + n * PSO + m) = v;
-            } else {
+        for (int t = 0; t < MT; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (m + r < P) out[n * PSO + m + r] = v[r];
+            for (int r = 0; r < 4; r++) {
+                const int m = t * 16 + lk * 4 + r;
+                float v = acc[t][u][r];
+                if (relu) v = fmaxf(v, 0.f);
+                if (m < P) out[m * CSO + n] = v;
             }
-        }
     }
 }
 
@@ -245,8 +247,8 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     float* bufB = lds + CV_BUF;              // phase A: S, T and the layer-0 row buffer live here
     float* S = bufB;
     float* T = bufB + 3200;
-    float* R = bufB + 6400;                  // [32][CV_RS]: row stride 72 -> the 4 channel rows of a fragment read hit disjoint bank halves
-    float* D = bufB + 6400 + 32 * CV_RS;     // [32][CV_DS] (3 x 100 used): ring of cost-volume shift rows; ends exactly at CV_BUF
+    float* R = bufB + 6400;                  // [54][36]: layer-0 output row (3 x 18 positions x 32 channels)
+    float* D = R + 54 * CV_C32;              // [3][100][36]: ring of cost-volume shift rows; ends at 19144 <= CV_BUF
     const int match = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE, li = lane & 15, lk = lane >> 4;
     {
@@ -276,21 +278,22 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         {
             L0Loader L;
 #pragma unroll
-            for (int dn = 0; dn < 3; dn++) L.row[dn] = D + lk * CV_DS + ((nrow + dn) % 3) * 100 + (m0 / 18) * 20 + (m0 % 18);
+            for (int dn = 0; dn < 3; dn++) L.row[dn] = D + ((nrow + dn) % 3) * (100 * CV_C32) + ((m0 / 18) * 20 + (m0 % 18)) * CV_C32 + lk * 4;
             cvx4 acc[1][2] = { { (cvx4){ b0v[0], b0v[0], b0v[0], b0v[0] }, (cvx4){ b0v[1], b0v[1], b0v[1], b0v[1] } } };   // bias first
             if (!(CV_EXP & 1)) cv_gemm_static<1, 2, 4, 54>(acc, L, P.wt[0] + (size_t)lane * 4, 2);
-            // R rows are 64 wide, layer 1 reads columns 0..53 only: the four rows of a lane go out as one 16-byte store
+            // C/D layout: lane holds channel n = 16u + li at the four positions m = 16w + 4lk + r
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                cvx4 v = acc[0][u];
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                *reinterpret_cast<cvx4*>(R + (u * 16 + li) * CV_RS + w * 16 + lk * 4) = v;
-            }
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = w * 16 + lk * 4 + r;
+                    if (m < 54) R[m * CV_C32 + u * 16 + li] = fmaxf(acc[0][u][r], 0.f);
+                }
         }
         __syncthreads();
         if (!(CV_EXP & 2)) {
             L1Loader L;
-            L.base = R + lk * CV_RS + li;
+            L.base = R + li * CV_C32 + lk * 4;
             const float* w1 = P.wt[1] + ((size_t)w * 64 + lane) * 4;      // N-tile w of 4; a dn slab = 18 groups
             cvx4 a[1][1];
             if (nrow <= 15) { a[0][0] = win0; cv_gemm_static<1, 1, 4, 18>(a, L, w1, 4); win0 = a[0][0]; }                         // dn = 0
@@ -300,7 +303,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         if (nrow >= 2) {                     // row n'' = nrow-2 is complete
             const int n2 = nrow - 2;
 #pragma unroll
-            for (int r = 0; r < 4; r++) bufA[(w * 16 + li) * 264 + n2 * 16 + lk * 4 + r] = fmaxf(win2[r] + b1v, 0.f);
+            for (int r = 0; r < 4; r++) bufA[(n2 * 16 + lk * 4 + r) * CV_C64 + w * 16 + li] = fmaxf(win2[r] + b1v, 0.f);
         }
         win2 = win1; win1 = win0; win0 = (cvx4){ 0.f, 0.f, 0.f, 0.f };
         __syncthreads();                     // R is rewritten by the next row
@@ -308,24 +311,24 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
 
     // ---- phase B: layers 2..9, ping-pong bufA <-> bufB ---------------------------------------------------
     if (CV_EXP & 4) return;
-    cv_conv_layer<13, 1, 64, 64, 16, 3, 264, 200>(bufA, bufB, P.wt[2], P.bias[2], w, true);            // 16x16 -> 14x14
+    cv_conv_layer<13, 1, 64, 64, 16, 3>(bufA, bufB, P.wt[2], P.bias[2], w, true);            // 16x16 -> 14x14
     __syncthreads();
-    cv_conv_layer<9, 2, 64, 128, 14, 3, 200, 144>(bufB, bufA, P.wt[3], P.bias[3], 2 * w, true);        // -> 12x12
+    cv_conv_layer<9, 2, 64, 128, 14, 3>(bufB, bufA, P.wt[3], P.bias[3], 2 * w, true);        // -> 12x12
     __syncthreads();
-    cv_conv_layer<7, 2, 128, 128, 12, 3, 144, 104>(bufA, bufB, P.wt[4], P.bias[4], 2 * w, true);       // -> 10x10
+    cv_conv_layer<7, 2, 128, 128, 12, 3>(bufA, bufB, P.wt[4], P.bias[4], 2 * w, true);       // -> 10x10
     __syncthreads();
-    cv_conv_layer<4, 1, 128, 64, 10, 3, 104, 72>(bufB, bufA, P.wt[5], P.bias[5], w, true);            // -> 8x8
+    cv_conv_layer<4, 1, 128, 64, 10, 3>(bufB, bufA, P.wt[5], P.bias[5], w, true);            // -> 8x8
     __syncthreads();
-    cv_conv_layer<3, 1, 64, 64, 8, 3, 72, 40>(bufA, bufB, P.wt[6], P.bias[6], w, true);              // -> 6x6
+    cv_conv_layer<3, 1, 64, 64, 8, 3>(bufA, bufB, P.wt[6], P.bias[6], w, true);              // -> 6x6
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 64, 32, 6, 3, 40, 16>(bufB, bufA, P.wt[7], P.bias[7], w, true);   // -> 4x4
+    if (w < 2) cv_conv_layer<1, 1, 64, 32, 6, 3>(bufB, bufA, P.wt[7], P.bias[7], w, true);   // -> 4x4
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 32, 32, 4, 3, 16, 4>(bufA, bufB, P.wt[8], P.bias[8], w, true);   // -> 2x2
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 4, 3>(bufA, bufB, P.wt[8], P.bias[8], w, true);   // -> 2x2
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2, 4, 4>(bufB, bufA, P.wt[9], P.bias[9], w, false);  // -> 1x1, 20 (+12 zero) logits
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2>(bufB, bufA, P.wt[9], P.bias[9], w, false);  // -> 1x1, 20 (+12 zero) logits
     __syncthreads();
     if (w == 0) {                            // softmax over the 20 logits, expected index (BUFFER.py:63-65)
-        float v = lane < 20 ? bufA[lane * 4] : -3.4e38f;           // row stride 4 of the last map
+        float v = lane < 20 ? bufA[lane] : -3.4e38f;               // the 1x1 map: position 0, channels 0..19
         float mx = v;
         for (int d = WAVE / 2; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, WAVE));
         float e = lane < 20 ? expf(v - mx) : 0.f;

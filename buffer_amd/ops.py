@@ -401,13 +401,16 @@ def post_refine(T_init, src, tgt, thr=0.10, iters=20):
 
 
 # ----------------------------------------------------------------------------- fused descriptor CNN
-def mfma_tile_weights(wt):
+def mfma_tile_weights(wt, lk_major=False):
     """[K, Cout] (K, Cout multiples of 16) -> the B-operand tiling of the fused MFMA kernels: blocks [K/16][Cout/16] of
-    256 floats laid out [lk][li][p] = wt[16g + 4p + lk][16n + li], so that a lane's four k-steps are one 16-byte load."""
+    256 floats laid out [lk][li][p], so that a lane's four k-steps are one 16-byte load.  K-row of (g, p, lk):
+    16g + 4p + lk (k-step p takes channels 4p..4p+3: csrc/convnet.hip), or with lk_major 16g + 4lk + p (k-step p takes
+    channel 4lk + p of every lane quarter, the order of csrc/costnet.hip's 16-byte A-fragment loads)."""
     K, cout = wt.shape
     assert K % 16 == 0 and cout % 16 == 0
-    t = wt.reshape(K // 16, 4, 4, cout // 16, 16)            # [g, p, lk, n, li]
-    return np.ascontiguousarray(np.transpose(t, (0, 3, 2, 4, 1)), dtype=np.float32).reshape(-1)   # [g, n, lk, li, p]
+    t = wt.reshape(K // 16, 4, 4, cout // 16, 16)            # [g, p, lk, n, li]  or  [g, lk, p, n, li]
+    perm = (0, 3, 1, 4, 2) if lk_major else (0, 3, 2, 4, 1)
+    return np.ascontiguousarray(np.transpose(t, perm), dtype=np.float32).reshape(-1)              # [g, n, lk, li, p]
 
 
 class CylindricalNet:
@@ -474,7 +477,7 @@ class CostVolumeNet:
             if i == 9:                                    # 20 logits -> two full 16-column tiles
                 wt = np.concatenate([wt, np.zeros((wt.shape[0], 32 - cout), np.float32)], 1)
                 b = np.concatenate([b, np.zeros(32 - cout, np.float32)])
-            self.wt.append(torch.from_numpy(mfma_tile_weights(np.ascontiguousarray(wt, dtype=np.float32))).to(device))
+            self.wt.append(torch.from_numpy(mfma_tile_weights(np.ascontiguousarray(wt, dtype=np.float32), lk_major=True)).to(device))
             self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
         self._wp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.wt])
         self._bp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.bias])

@@ -214,7 +214,7 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
  * x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140] (= [np,32,7,20]).
  * wt_host[l] / bias_host[l]: HOST arrays of 8 DEVICE pointers: weights W[9*Cin][Cout] with
  * k = (ky*3+kx)*Cin + c (layer 0: c = c16*3 + depth) in the MFMA B-operand tiling (blocks [K/16][Cout/16] of 256
- * floats, block (g, n) = [lk][li][p] = W[16g + 4p + lk][16n + li]; see buf_cost_volume_net), biases [Cout]; widths in
+ * floats, block (g, n) = [lk][li][p] = W[16g + 4p + lk][16n + li]; ops.mfma_tile_weights), biases [Cout]; widths in
  * cin_host/cout_host. */
 int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                             const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
@@ -231,8 +231,8 @@ int     buf_descriptor_head(const float* y, int npatch, const float* params, flo
  * equivariant maps) -> ind f32[m] (expected azimuth shift).  wt_host/bias_host: HOST arrays of 10 DEVICE
  * pointers, BN folded; weights W[K][Cout] with K = ((dn*KH + dk)*KW + dl)*Cin + c, the last layer (20 outputs)
  * zero-padded to 32 columns / biases, stored in the MFMA B-operand tiling: blocks [K/16][Cout/16] of 256 floats,
- * block (g, n) laid out [lk 0..3][li 0..15][p 0..3] = W[16g + 4p + lk][16n + li]
- * (buffer_amd.ops.mfma_tile_weights is the host-side re-layout). */
+ * block (g, n) laid out [lk 0..3][li 0..15][p 0..3] = W[16g + 4lk + p][16n + li]
+ * (buffer_amd.ops.mfma_tile_weights(w, lk_major=True) is the host-side re-layout). */
 int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
                             const float* const* bias_host, float* ind_out, void* stream);
 
