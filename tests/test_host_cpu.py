@@ -151,3 +151,17 @@ def test_shard_indices_cover_everything():
         for w in (1, 2, 8):
             got = sorted(sum((bd.shard_indices(n, r, w) for r in range(w)), []))
             assert got == list(range(n))
+
+
+def test_mfma_tile_weights_layout():
+    """ops.mfma_tile_weights: block (g, n) of 256 floats = [lk][li][p] with K-row 16g + 4p + lk (conv net) or
+    16g + 4lk + p (cost net, lk_major) and column 16n + li -- the contract stated in include/buffer_hip.h."""
+    import numpy as np
+    from buffer_amd.ops import mfma_tile_weights
+    K, C = 48, 32
+    w = np.arange(K * C, dtype=np.float32).reshape(K, C)
+    for lk_major in (False, True):
+        t = mfma_tile_weights(w, lk_major=lk_major).reshape(K // 16, C // 16, 4, 16, 4)
+        for g, n, lk, li, p in [(0, 0, 0, 0, 0), (2, 1, 3, 15, 2), (1, 0, 2, 7, 3), (2, 1, 0, 9, 1)]:
+            k = 16 * g + (4 * lk + p if lk_major else 4 * p + lk)
+            assert t[g, n, lk, li, p] == w[k, 16 * n + li]
