@@ -310,6 +310,53 @@ def main():
         print('F6 skipped:', repr(e))
 
 
+def make_kitti_fixture():
+    """F7 `kitti_tiny.npz`: the KITTI branch of the reference (KITTI/config.py constants, released KITTI weights, the
+    R = I alignment of patch_embedder.py:143-147) on a small ring-pattern LiDAR pair: pyramid tables, EFCNN / DetNet
+    outputs and the descriptors of 48 FPS keypoints."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg, model, _ = load_reference_model('KITTI', '06050001')
+    from KITTI import dataloader as dlk
+    sample = synth.make_kitti_pair(9, beams=24, az_steps=700)
+    limits = dlk.calibrate_neighbors([sample], cfg, dlk.collate_fn_descriptor)
+    batch = dlk.collate_fn_descriptor([sample], cfg, limits)
+    out = {'limits': np.asarray(limits, np.int32)}
+    for l in range(3):
+        out[f'points_{l}'] = batch['points'][l].numpy()
+        out[f'neighbors_{l}'] = batch['neighbors'][l].numpy().astype(np.int32)
+        out[f'pools_{l}'] = batch['pools'][l].numpy().astype(np.int32)
+        out[f'upsamples_{l}'] = batch['upsamples'][l].numpy().astype(np.int32)
+        out[f'lengths_{l}'] = batch['stack_lengths'][l].numpy().astype(np.int32)
+    with torch.no_grad():
+        axis, eps, branch = model.Ref(batch)
+        bottle = branch['bottle_feature']
+        score = model.Keypt(batch, {'bottle_feature': bottle, 'skip_feature': list(branch['skip_feature'])})
+    out.update(features=batch['features'].numpy(), axis=axis.numpy(), eps=eps.numpy(), score=score.numpy())
+    n_src = int(batch['stack_lengths'][0][0])
+    src_pts = batch['src_pcd']
+    src_axis = F.normalize(axis[:n_src], p=2, dim=1)
+    mask = (torch.sum(-src_axis * src_pts, dim=1) < 0).float().unsqueeze(1)
+    src_axis = src_axis * (1 - mask) - src_axis * mask
+    fps_idx = torch.from_numpy(cpu.fps(src_pts[None].numpy(), 48)).long()[0]
+    kpts, kaxis = src_pts[fps_idx], src_axis[fps_idx]
+    raw = batch['src_pcd_raw']
+    perm = np.random.RandomState(7).permutation(raw.shape[0])
+    orig_choice = np.random.choice
+    np.random.choice = lambda n, size=None, replace=True: perm           # pin select_patches' shuffle
+    with torch.no_grad():
+        d = model.Desc(raw[None], kpts[None], kaxis[None])
+    np.random.choice = orig_choice
+    out.update(raw=raw.numpy(), kpts=kpts.numpy(), kaxis=kaxis.numpy(), perm=perm.astype(np.int64),
+               patches=d['patches'].numpy(), R=d['R'].numpy(), rand_axis=d['rand_axis'].numpy(), desc=d['desc'].numpy(),
+               equi=d['equi'].numpy())
+    np.savez_compressed(os.path.join(GOLD, 'kitti_tiny.npz'), **out)
+    print('F7 kitti: layers', [p.shape[0] for p in batch['points']], 'limits', limits, 'desc', d['desc'].shape,
+          'R==I', bool((d['R'] == torch.eye(3)).all()))
+    sys.modules.pop('KITTI.config', None)
+
+
 def make_rr_fixture():
     src = open(f'{REF}/ThreeDMatch/test.py').read()
     # only the function definitions above `if __name__` are needed; exec them in a module namespace
@@ -367,6 +414,13 @@ def make_rr_fixture():
                         infos=np.asarray(infos))
     print('F6 evaluate_registration ->', flat)
 
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'kitti':       # only F7 (leaves F1-F6 untouched)
+    cpu.build(ref=True)
+    install_stubs()
+    os.makedirs(GOLD, exist_ok=True)
+    make_kitti_fixture()
+    sys.exit(0)
 
 if __name__ == '__main__':
     main()

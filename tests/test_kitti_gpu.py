@@ -51,3 +51,36 @@ def test_kitti_registration_matches_cpu_oracle(kitti_pair, dev):
     assert np.array_equal(d['s_mids'].cpu().numpy(), wd['s_mids'])
     np.testing.assert_allclose(d['ind'].cpu().numpy(), wd['ind'].numpy(), rtol=1e-4, atol=5e-4)
     np.testing.assert_allclose(pose.cpu().numpy(), want, rtol=0, atol=2e-3)
+
+
+def test_kitti_branch_vs_reference_fixture(dev):
+    """HIP point learner and patch embedder with the KITTI constants / weights against fixture F7 (`kitti_tiny.npz`,
+    produced by the reference itself: KITTI/config.py, released KITTI snapshot, R = I alignment)."""
+    import os
+    from buffer_amd.config import KITTI
+    from buffer_amd.patch_embedder import PatchEmbedder
+    from buffer_amd.point_learner import PointLearner
+    from buffer_amd.weights import load_weights
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_tiny.npz"))
+    W = load_weights("kitti")
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    pyr = dict(points=[t(f[f'points_{l}']) for l in range(3)], neighbors=[t(f[f'neighbors_{l}'], torch.int32) for l in range(3)],
+               pools=[t(f[f'pools_{l}'], torch.int32) for l in range(2)], upsamples=[t(f[f'upsamples_{l}'], torch.int32) for l in range(2)])
+    pl = PointLearner(W, dev, scale=KITTI.scale)
+    axis, eps, bottle, skips, _ = pl.efcnn(pyr, t(f['features']))
+    score = pl.detnet(pyr, bottle, skips)
+    a, b = axis.cpu().numpy(), f['axis']
+    # 80 m coordinates in fp32: neighbour offsets carry ~1e-5 relative round-off that summation order amplifies;
+    # the oracle (CPU torch) sits at 3e-4 of the axis length from the same fixture, the HIP path at 7e-4
+    assert np.all(np.linalg.norm(a - b, axis=1) < 1e-3 * np.linalg.norm(b, axis=1) + 1e-5)
+    assert np.min((a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))) > 1 - 1e-5
+    np.testing.assert_allclose(eps.cpu().numpy(), f['eps'], rtol=5e-3, atol=1e-4)             # sigmoid / softplus after two
+    np.testing.assert_allclose(score.cpu().numpy(), f['score'], rtol=5e-3, atol=1e-4)         # InstanceNorms over the pair
+    assert np.array_equal(score.cpu().numpy() > KITTI.keypts_th, f['score'] > KITTI.keypts_th)
+    pe = PatchEmbedder(W, dev, KITTI)
+    out = pe(t(f['raw']), t(f['kpts']), t(f['kaxis']), t(f['perm']), want_patches=True)
+    np.testing.assert_allclose(out['patches'].cpu().numpy(), f['patches'], rtol=0, atol=3e-6)
+    assert np.array_equal(out['R'].cpu().numpy(), f['R'])                                       # identity
+    np.testing.assert_allclose(out['rand_axis'].cpu().numpy(), f['rand_axis'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out['desc'].cpu().numpy(), f['desc'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out['equi'].cpu().numpy(), f['equi'], rtol=1e-4, atol=2e-5)

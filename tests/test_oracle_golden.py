@@ -150,3 +150,32 @@ def test_matching_and_pose_match_reference(W):
     assert np.array_equal(inl.numpy(), f['inlier_ind'])
     refined = T.post_refinement(torch.from_numpy(f['init_pose']), ss[None], tt[None])
     np.testing.assert_allclose(refined.numpy(), f['refined_pose'], rtol=0, atol=1e-5)
+
+
+def test_kitti_branch_matches_reference():
+    """Fixture F7 (KITTI constants and weights, R = I alignment): the oracle's EFCNN / DetNet on the reference's own
+    pyramid tables and its descriptors with dataset='KITTI' against what the reference itself produced."""
+    from buffer_amd.config import KITTI
+    from buffer_amd.weights import load_weights
+    Wk = {k: torch.from_numpy(v) for k, v in load_weights("kitti").items()}
+    f = load("kitti_tiny.npz")
+    batch = _ref_batch(f)
+    batch['features'] = torch.from_numpy(f['features'])
+    with torch.no_grad():
+        axis, eps, bottle, skips = T.efcnn_forward(batch, Wk, scale=KITTI.scale)[:4]
+        score = T.detnet_forward(batch, bottle, skips, Wk)
+        out = T.desc_forward(torch.from_numpy(f['raw']), torch.from_numpy(f['kpts']), torch.from_numpy(f['kaxis']),
+                             torch.from_numpy(f['perm']), Wk, des_r=KITTI.des_r, dataset='KITTI')
+    # KITTI coordinates reach 80 m: neighbour offsets carry fp32 round-off of the order 1e-5 relative, which the
+    # summation order of a different backend turns into ~1e-4 of the axis length on a handful of points
+    a, b = axis.numpy(), f['axis']
+    assert np.all(np.linalg.norm(a - b, axis=1) < 5e-4 * np.linalg.norm(b, axis=1) + 1e-5)
+    np.testing.assert_allclose(eps.numpy(), f['eps'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(score.numpy(), f['score'], rtol=5e-3, atol=1e-4)       # softplus after two InstanceNorms
+    assert np.array_equal(score.numpy() > KITTI.keypts_th, f['score'] > KITTI.keypts_th)
+    assert np.array_equal(f['R'], np.tile(np.eye(3, dtype=np.float32), (f['R'].shape[0], 1, 1)))
+    np.testing.assert_allclose(out['patches'].numpy(), f['patches'], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(out['R'].numpy(), f['R'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out['rand_axis'].numpy(), f['rand_axis'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out['desc'].numpy(), f['desc'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out['equi'].numpy(), f['equi'], rtol=1e-4, atol=1e-5)
