@@ -70,6 +70,7 @@ _SIGNATURES = {
     "buf_voxel_downsample_ws_bytes": (_sz, [_i, _i64]),
     "buf_voxel_downsample": (_i, [_vp, _vp, _i, _i, C.c_double, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "buf_knn_normals": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "buf_row_linear": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "buf_segment_instance_norm_ws_bytes": (_sz, [_i, _i]),
     "buf_segment_instance_norm": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     "buf_descriptor_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),

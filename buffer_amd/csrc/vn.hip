@@ -355,3 +355,43 @@ extern "C" int buf_segment_instance_norm(const float* x, int n, int c, const int
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Conv1d(kernel 1) of the score heads (models/point_learner.py:128-136,163-171): out[i] = W x[i] + b with
+// cin <= 32, cout <= 32.  One lane per row, weights broadcast from LDS; activation: 0 none, 1 sigmoid, 2 softplus.
+#define ROWLIN_MAX 32
+__global__ void __launch_bounds__(256) k_row_linear(const float* __restrict__ x, int n, int cin, int cout, const float* __restrict__ w,
+                                                  const float* __restrict__ b, int act, float* __restrict__ out)
+{
+    __shared__ float ws[ROWLIN_MAX * ROWLIN_MAX + ROWLIN_MAX];
+    for (int i = threadIdx.x; i < cout * cin; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < cout; i += 256) ws[ROWLIN_MAX * ROWLIN_MAX + i] = b[i];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    float xv[ROWLIN_MAX];
+#pragma unroll
+    for (int c = 0; c < ROWLIN_MAX; c++) xv[c] = c < cin ? x[(size_t)row * cin + c] : 0.f;
+    for (int o = 0; o < cout; o++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < ROWLIN_MAX; c++) acc += c < cin ? ws[o * cin + c] * xv[c] : 0.f;   // ascending c, like a dot product
+        acc += ws[ROWLIN_MAX * ROWLIN_MAX + o];
+        if (act == 1) acc = 1.f / (1.f + expf(-acc));
+        else if (act == 2) acc = acc > 20.f ? acc : log1pf(expf(acc));                        // F.softplus (threshold 20)
+        out[(size_t)row * cout + o] = acc;
+    }
+}
+
+extern "C" int buf_row_linear(const float* x, int n, int cin, int cout, const float* w, const float* b, int activation, float* out,
+                              void* stream)
+{
+    BUF_REQUIRE(n >= 0 && cin > 0 && cin <= ROWLIN_MAX && cout > 0 && cout <= ROWLIN_MAX, BUF_EINVAL,
+                "buf_row_linear: n=%d cin=%d cout=%d (widths up to %d)", n, cin, cout, ROWLIN_MAX);
+    BUF_REQUIRE(activation >= 0 && activation <= 2, BUF_EINVAL, "buf_row_linear: activation %d", activation);
+    if (n == 0) return BUF_OK;
+    BUF_REQUIRE(x && w && b && out, BUF_EINVAL, "buf_row_linear: null argument");
+    k_row_linear<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, cin, cout, w, b, activation, out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

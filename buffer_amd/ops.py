@@ -342,6 +342,19 @@ def patch_voxelize(patches, axis, des_r, centres, azi_cs, voxel_r, nsample, mlp_
     return x, R, ra, pn
 
 
+def row_linear(x, w, b, activation=None):
+    """Conv1d(kernel 1) of the score heads: x f32[n,cin] @ w[cout,cin].T + b, then None | 'sigmoid' | 'softplus'."""
+    L = _lib.lib()
+    x = _dev(x, torch.float32, "row_linear")
+    n, cin = int(x.shape[0]), int(x.shape[1])
+    cout = int(w.shape[0])
+    out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    act = {None: 0, 'sigmoid': 1, 'softplus': 2}[activation]
+    check(L.buf_row_linear(_ptr(x), n, cin, cout, _ptr(w.contiguous()), _ptr(b.contiguous()), act, _ptr(out), _stream()),
+          "buf_row_linear")
+    return out
+
+
 def segment_instance_norm(x, seg_lengths, eps=1e-5):
     """InstanceNorm1d (biased variance) over contiguous row segments: x f32[n,c], seg_lengths int[nseg] (host) -> f32[n,c]."""
     L = _lib.lib()

@@ -14,7 +14,7 @@ class _ScoreHead:
         self.vn2 = ops.VnLayer(W, f'{p}.0.vn2', device, slope=0.0)
         self.lin = ops.VnLayer(W, f'{p}.0.vn_lin', device, linear_only=True)
         t = lambda k: torch.as_tensor(W[k], dtype=torch.float32, device=device)
-        self.w = [t(f'{p}.{i}.weight')[:, :, 0] for i in (1, 3, 5)]
+        self.w = [t(f'{p}.{i}.weight')[:, :, 0].contiguous() for i in (1, 3, 5)]
         self.b = [t(f'{p}.{i}.bias') for i in (1, 3, 5)]
         self.final = final
 
@@ -29,10 +29,9 @@ class _ScoreHead:
         z = ops.vn_pointwise(self.vn2, z)
         z = ops.vn_pointwise(self.lin, z)                          # [N, 9]
         h = ops.vn_std(x, z)                                       # [N, 30]
-        h = self._inorm(h @ self.w[0].t() + self.b[0], seg)
-        h = self._inorm(h @ self.w[1].t() + self.b[1], seg)
-        h = h @ self.w[2].t() + self.b[2]
-        return torch.sigmoid(h) if self.final == 'sigmoid' else F.softplus(h)
+        h = self._inorm(ops.row_linear(h, self.w[0], self.b[0]), seg)
+        h = self._inorm(ops.row_linear(h, self.w[1], self.b[1]), seg)
+        return ops.row_linear(h, self.w[2], self.b[2], self.final)
 
 
 class _Decoder:

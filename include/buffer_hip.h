@@ -181,6 +181,10 @@ int     buf_vn_pointwise(const float* a, const int* ind_a, int ind_stride, int n
                          const float* bn_shift, float slope, const float* residual, float* out, void* stream);
 /* max_pool (models/KPConv/blocks.py:104-121): out[i,f] = max_k feats_pad[idx[i,k], f], zero shadow row. */
 int     buf_gather_max(const float* feats, const int* idx, int nq, int ns, int k, int width, float* out, void* stream);
+/* Conv1d(kernel 1) of the score heads (models/point_learner.py:128-136,163-171): out[i] = W x[i] + b, x f32[n,cin],
+ * W f32[cout,cin], b f32[cout] (device), cin, cout <= 32; activation 0 none, 1 sigmoid, 2 softplus. */
+int     buf_row_linear(const float* x, int n, int cin, int cout, const float* w, const float* b, int activation, float* out,
+                       void* stream);
 /* InstanceNorm1d (biased variance, no affine) over contiguous row segments: the score heads of
  * models/point_learner.py:128-136,163-171 normalise over the stacked points of ONE pair; lens_host[s] rows per
  * segment (HOST int[nseg], sum = n).  x f32[n,c] -> out f32[n,c].  Deterministic (no atomics). */

@@ -150,3 +150,22 @@ def test_segment_instance_norm_vs_torch(dev):
     assert ops.segment_instance_norm(x[:0], [0]).shape == (0, 30)
     with pytest.raises(Exception):
         ops.segment_instance_norm(x, [5])                      # lengths do not sum to n
+
+
+def test_row_linear_vs_torch(dev):
+    """Conv1d(kernel 1) of the score heads (point_learner.py:128-136) + its final activations == torch."""
+    import torch
+    import torch.nn.functional as F
+    from buffer_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(2)
+    for cin, cout in ((30, 20), (20, 10), (10, 1), (32, 32)):
+        x = (torch.randn((1237, cin), generator=g) * 4).to(dev)
+        w = torch.randn((cout, cin), generator=g).to(dev)
+        b = torch.randn((cout,), generator=g).to(dev)
+        want = x @ w.t() + b
+        np.testing.assert_allclose(ops.row_linear(x, w, b).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(ops.row_linear(x, w, b, 'sigmoid').cpu().numpy(), torch.sigmoid(want).cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ops.row_linear(x, w, b, 'softplus').cpu().numpy(), F.softplus(want).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert ops.row_linear(x[:0], w, b).shape == (0, 32)
+    with pytest.raises(Exception):
+        ops.row_linear(torch.zeros((4, 33), device=dev), torch.zeros((2, 33), device=dev), torch.zeros((2,), device=dev))
