@@ -237,14 +237,22 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
 // One lane per hypothesis: 3 distinct correspondences from the candidate list, edge-length checker,
 // Kabsch, distance checker, then fitness (inlier count) and sum of squared inlier distances over
 // all candidates.  key = (count << 32) | ~bits(mean squared error): larger is better.
+// ncorr_dev (nullable): the candidate count lives on the device (buf_ransac_kabsch_masked: no host round trip); fewer
+// than 3 candidates leave every key 0, which k_ransac_pick turns into the identity (open3d's result in that case).
 __global__ void __launch_bounds__(WAVE) k_ransac(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
-                                              int ncorr, int nhyp, unsigned long long seed, float max_dist, float edge_sim,
-                                              unsigned long long* __restrict__ keys, float* __restrict__ Ts)
+                                              int ncorr, const int* __restrict__ ncorr_dev, int nhyp, unsigned long long seed,
+                                              float max_dist, float edge_sim, unsigned long long* __restrict__ keys, float* __restrict__ Ts)
 {
     int h = blockIdx.x * WAVE + threadIdx.x;       // one wavefront per workgroup: 4096 hypotheses spread over 64 CUs
     if (h >= nhyp) return;
+    if (ncorr_dev) ncorr = *ncorr_dev;
     unsigned long long key = 0;
     float T[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    if (ncorr < 3) {
+        keys[h] = 0;
+        for (int k = 0; k < 12; k++) Ts[12 * (size_t)h + k] = T[k];
+        return;
+    }
     int i0 = (int)(splitmix64(seed + 3ull * h) % (unsigned long long)ncorr);
     int i1 = (int)(splitmix64(seed + 3ull * h + 1) % (unsigned long long)(ncorr - 1));
     int i2 = (int)(splitmix64(seed + 3ull * h + 2) % (unsigned long long)(ncorr - 2));
@@ -347,8 +355,48 @@ extern "C" int buf_ransac_kabsch(const float* src, const float* tgt, const int* 
         BUF_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)nhyp, s));
     } else {
         BUF_REQUIRE(src && tgt && corr, BUF_EINVAL, "buf_ransac_kabsch: null argument");
-        k_ransac<<<cdiv(nhyp, WAVE), WAVE, 0, s>>>(src, tgt, corr, ncorr, nhyp, seed, max_dist, edge_similarity, keys, Ts);
+        k_ransac<<<cdiv(nhyp, WAVE), WAVE, 0, s>>>(src, tgt, corr, ncorr, nullptr, nhyp, seed, max_dist, edge_similarity, keys, Ts);
     }
+    k_ransac_pick<<<1, 1024, 0, s>>>(keys, Ts, nhyp, T_out, info_out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+// ascending indices of the set bytes of mask[0..m) and their count: one wavefront, ballot + popcount per 64 entries
+__global__ void __launch_bounds__(WAVE) k_mask_compact(const unsigned char* __restrict__ mask, int m, int* __restrict__ idx,
+                                                    int* __restrict__ count)
+{
+    const int lane = threadIdx.x;
+    int cnt = 0;
+    for (int base = 0; base < m; base += WAVE) {
+        const int i = base + lane;
+        const bool hit = i < m && mask[i] != 0;
+        const unsigned long long b = __ballot(hit);
+        if (hit) idx[cnt + lane_prefix(b, lane)] = i;
+        cnt += __popcll(b);
+    }
+    if (lane == 0) *count = cnt;
+}
+
+extern "C" size_t buf_ransac_masked_ws_bytes(int m, int nhyp) { return buf_ransac_ws_bytes(nhyp) + sizeof(int) * ((size_t)(m > 0 ? m : 0) + 64); }
+
+// buf_ransac_kabsch on the correspondences selected by mask uint8[m] (e.g. best_mask of buf_hypotheses_score): the
+// index list and its length stay on the device, so a whole pose recovery is enqueued without a host round trip.
+extern "C" int buf_ransac_kabsch_masked(const float* src, const float* tgt, const unsigned char* mask, int m, int nhyp,
+                                        unsigned long long seed, float max_dist, float edge_similarity, float* T_out,
+                                        int* info_out, void* ws, size_t ws_bytes, void* stream)
+{
+    BUF_REQUIRE(nhyp > 0 && m >= 0, BUF_EINVAL, "buf_ransac_kabsch_masked: m=%d nhyp=%d", m, nhyp);
+    BUF_REQUIRE(T_out && ws && (m == 0 || (src && tgt && mask)), BUF_EINVAL, "buf_ransac_kabsch_masked: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver w(ws, ws_bytes);
+    unsigned long long* keys = w.take<unsigned long long>((size_t)nhyp);
+    float* Ts = w.take<float>(12 * (size_t)nhyp);
+    int* count = w.take<int>(1);
+    int* idx = w.take<int>((size_t)(m > 0 ? m : 1));
+    BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_ransac_kabsch_masked: workspace %zu < %zu", ws_bytes, w.used());
+    k_mask_compact<<<1, WAVE, 0, s>>>(mask, m, idx, count);
+    k_ransac<<<cdiv(nhyp, WAVE), WAVE, 0, s>>>(src, tgt, idx, 0, count, nhyp, seed, max_dist, edge_similarity, keys, Ts);
     k_ransac_pick<<<1, 1024, 0, s>>>(keys, Ts, nhyp, T_out, info_out);
     BUF_LAUNCH_CHECK();
     return BUF_OK;

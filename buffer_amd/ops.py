@@ -402,6 +402,23 @@ def ransac_kabsch(src, tgt, corr, nhyp=4096, seed=0, max_dist=0.10, edge_similar
     return T, info
 
 
+def ransac_kabsch_masked(src, tgt, mask, nhyp=4096, seed=0, max_dist=0.10, edge_similarity=0.8):
+    """ransac_kabsch on the correspondences with mask != 0 (uint8[m]); nothing returns to the host.
+    -> (T f32[4,4], info int32[2])."""
+    L = _lib.lib()
+    dev = src.device
+    mask = _dev(mask, torch.uint8, "ransac_kabsch_masked")
+    m = int(mask.shape[0])
+    T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+    info = torch.zeros((2,), dtype=torch.int32, device=dev)
+    nbytes = L.buf_ransac_masked_ws_bytes(m, int(nhyp))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(L.buf_ransac_kabsch_masked(_ptr(src.contiguous()), _ptr(tgt.contiguous()), _ptr(mask), m, int(nhyp), int(seed),
+                                     float(max_dist), float(edge_similarity), _ptr(T), _ptr(info), _ptr(ws), nbytes, _stream()),
+          "buf_ransac_kabsch_masked")
+    return T, info
+
+
 def post_refine(T_init, src, tgt, thr=0.10, iters=20):
     L = _lib.lib()
     dev = src.device

@@ -59,8 +59,9 @@ def recover_pose(ind, ss_kpts, tt_kpts, ss_R, tt_R, cfg, seed=0):
     """BUFFER.py:295-333: hypotheses, all-vs-all scoring, RANSAC on the winner's inliers, refinement.
     -> (pose f32[4,4] device, dict of diagnostics)."""
     R, t, num, best, mask = ops.hypotheses_score(ind, ss_kpts, tt_kpts, ss_R, tt_R, cfg.azi_n, cfg.inlier_th)
-    inlier_ind = torch.nonzero(mask).flatten().int()
-    T, info = ops.ransac_kabsch(ss_kpts, tt_kpts, inlier_ind, cfg.ransac_hypotheses, seed, cfg.dist_th, cfg.similar_th)
+    # the winner's inlier list stays on the device (mask -> index list inside the RANSAC entry point): the whole
+    # recovery is enqueued without a host round trip
+    T, info = ops.ransac_kabsch_masked(ss_kpts, tt_kpts, mask, cfg.ransac_hypotheses, seed, cfg.dist_th, cfg.similar_th)
     if cfg.pose_refine:
         T, rinfo = ops.post_refine(T, ss_kpts, tt_kpts, cfg.refine_threshold, 20)
-    return T, dict(inlier_num=num, best=best, inlier_ind=inlier_ind, ransac_info=info, R_hyp=R, t_hyp=t)
+    return T, dict(inlier_num=num, best=best, inlier_mask=mask, ransac_info=info, R_hyp=R, t_hyp=t)

@@ -253,6 +253,12 @@ size_t  buf_ransac_ws_bytes(int nhyp);
 int     buf_ransac_kabsch(const float* src, const float* tgt, const int* corr, int ncorr, int nhyp,
                           unsigned long long seed, float max_dist, float edge_similarity, float* T_out,
                           int* info_out, void* ws, size_t ws_bytes, void* stream);
+/* The same on the correspondences selected by mask uint8[m] (best_mask of buf_hypotheses_score): index list and count
+ * stay on the device, so a pose recovery is enqueued without a host round trip.  ws: buf_ransac_masked_ws_bytes(m, nhyp). */
+size_t  buf_ransac_masked_ws_bytes(int m, int nhyp);
+int     buf_ransac_kabsch_masked(const float* src, const float* tgt, const unsigned char* mask, int m, int nhyp,
+                                 unsigned long long seed, float max_dist, float edge_similarity, float* T_out,
+                                 int* info_out, void* ws, size_t ws_bytes, void* stream);
 /* A16  post_refinement (models/BUFFER.py:382-418,424-464): <= iters rounds of weighted Kabsch in one launch.
  * T_init,T_out f32[4,4]; src,tgt f32[m,3]; info_out (nullable) int32[2] = {last inlier count, rounds run}. */
 int     buf_post_refine(const float* T_init, const float* src, const float* tgt, int m, float inlier_threshold,
