@@ -330,6 +330,8 @@ extern "C" int buf_ball_query(const float* xyz, const float* new_xyz, int b, int
 //   slot j >= hits       -> the keypoint   (reference: padding slots equal the first hit -> masked)
 //   slot nsample-1       -> the keypoint, always
 //   no hit at all        -> slot 0 = point 0 of the cloud (the zero-initialised index row)
+struct __attribute__((packed, aligned(4))) Pt3 { float x, y, z; };     // 12-byte point, dword aligned
+
 __global__ void __launch_bounds__(BQ_WAVES * WAVE) k_select_patches(const float* __restrict__ pts, const float* __restrict__ kpts,
                                                                   int n, int m, float r2, int nsample,
                                                                   float* __restrict__ patches)
@@ -345,13 +347,14 @@ __global__ void __launch_bounds__(BQ_WAVES * WAVE) k_select_patches(const float*
         bool hit = false;
         float x = 0, y = 0, z = 0;
         if (k < n) {
-            x = pts[3 * (size_t)k]; y = pts[3 * (size_t)k + 1]; z = pts[3 * (size_t)k + 2];
+            const Pt3 p = *reinterpret_cast<const Pt3*>(pts + 3 * (size_t)k);      // one global_load_dwordx3
+            x = p.x; y = p.y; z = p.z;
             hit = sqdist3(qx, qy, qz, x, y, z) < r2;
         }
         unsigned long long mask = __ballot(hit);
         if (mask) {
             int slot = cnt + lane_prefix(mask, lane);
-            if (hit && slot < nsample - 1) { row[3 * slot] = x; row[3 * slot + 1] = y; row[3 * slot + 2] = z; }
+            if (hit && slot < nsample - 1) { Pt3 o; o.x = x; o.y = y; o.z = z; *reinterpret_cast<Pt3*>(row + 3 * slot) = o; }
             cnt += __popcll(mask);
         }
     }
