@@ -102,3 +102,37 @@ def test_c_abi_error_codes(dev):
     rc = L.buf_vn_gather_block(None, None, None, None, 10, 10, 4, 2, 4, 3, 1.0, None, None, None, None, 0.2, None, s)
     assert rc == -1 and b"mode" in L.buf_last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("npts,rad_n,azi_n,ele_n,nsample", [(200, 3, 20, 7, 10), (512, 2, 8, 4, 4), (777, 3, 20, 7, 16), (33, 1, 4, 2, 1)])
+def test_voxelize_other_shapes_vs_oracle(dev, npts, rad_n, azi_n, ele_n, nsample):
+    """Fused voxelisation with other patch sizes / voxel grids / sample counts than the 3DMatch constants (hit masks not a
+    multiple of 32 points, centres not 420, nsample up to 16): == oracle SPT + point MLP; KITTI-style R = I as well."""
+    import torch
+    from buffer_amd import ops
+    from buffer_amd.weights import load_weights
+    from oracle import torch_ref as T
+    W = load_weights("3dmatch")
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    g = torch.Generator(device='cpu').manual_seed(npts)
+    P = 29
+    patches = (torch.rand((P, npts, 3), generator=g) * 2 - 1) * 0.25 + torch.tensor([1.0, -2.0, 0.5])
+    patches[:, -1] = torch.tensor([1.0, -2.0, 0.5])                       # keypoint in the last slot
+    patches[3, :5] = patches[3, -1]                                        # points on the centre: hit many balls, incl. point 0
+    axis = torch.nn.functional.normalize(torch.randn((P, 3), generator=g), dim=1)
+    centres = T.voxel_centres(rad_n, azi_n, ele_n)
+    ang = -torch.arange(azi_n, dtype=torch.float64) * 2 * np.pi / azi_n
+    azi_cs = torch.stack([torch.cos(ang), torch.sin(ang)], 1).float()
+    s = Wt['Desc.pnt_layer.1.weight'] / torch.sqrt(Wt['Desc.pnt_layer.1.running_var'] + 1e-5)
+    t = Wt['Desc.pnt_layer.1.bias'] - Wt['Desc.pnt_layer.1.running_mean'] * s
+    for ax, dataset in ((axis, '3DMatch'), (None, 'KITTI')):
+        x, R, ra, pn = ops.patch_voxelize(patches.to(dev), None if ax is None else ax.to(dev), 0.3, centres.to(dev), azi_cs.to(dev),
+                                          0.8 / rad_n, nsample, W['Desc.pnt_layer.0.weight'].reshape(16, 3), W['Desc.pnt_layer.0.bias'],
+                                          s.numpy(), t.numpy(), azi_n, True)
+        with torch.no_grad():
+            al, rand_axis, Rw = T.axis_align(patches, axis, dataset)
+            inv = T.spt(al / 0.3, rad_n, azi_n, ele_n, 0.8, nsample)
+            want = T.point_mlp_max(inv, Wt).reshape(P, 16, -1)
+        np.testing.assert_allclose(pn.cpu().numpy(), (al / 0.3).numpy(), rtol=0, atol=3e-6)
+        np.testing.assert_allclose(R.cpu().numpy(), Rw.numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
