@@ -136,3 +136,32 @@ def test_voxelize_other_shapes_vs_oracle(dev, npts, rad_n, azi_n, ele_n, nsample
         np.testing.assert_allclose(pn.cpu().numpy(), (al / 0.3).numpy(), rtol=0, atol=3e-6)
         np.testing.assert_allclose(R.cpu().numpy(), Rw.numpy(), rtol=0, atol=2e-6)
         np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 600])
+def test_fused_cnns_small_and_odd_batches(dev, n):
+    """k_cyl_net / k_desc_head / k_cost_net with 0, 1, 3 and a non-round number of workgroups == library convolutions."""
+    import torch
+    from buffer_amd import registration
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    from buffer_amd.weights import load_weights
+    W = load_weights("3dmatch")
+    pe = PatchEmbedder(W, dev, THREEDMATCH)
+    cv = registration.CostVolume(W, dev)
+    g = torch.Generator(device='cpu').manual_seed(10 + n)
+    x = torch.rand((n, 16, 420), generator=g).to(dev)
+    y = pe.fused(x)
+    assert y.shape == (n, 32, 7, 20)
+    d, e = pe.head(y)
+    assert d.shape == (n, 32) and e.shape == (n, 32, 7, 20)
+    a = torch.nn.functional.normalize(torch.rand((n, 32, 5, 20), generator=g), dim=1).to(dev)
+    b = torch.nn.functional.normalize(torch.rand((n, 32, 5, 20), generator=g), dim=1).to(dev)
+    ind = cv(a, b, fused=True)
+    assert ind.shape == (n,)
+    if n:
+        want = pe.conv_net(x.view(-1, 16, 3, 7, 20))
+        assert (y - want).abs().max().item() < 2e-5 * max(want.abs().max().item(), 1.0)
+        wd, we = pe.head_library(y)
+        np.testing.assert_allclose(d.cpu().numpy(), wd.cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ind.cpu().numpy(), cv(a, b, fused=False).cpu().numpy(), rtol=1e-4, atol=2e-4)
