@@ -50,6 +50,12 @@ struct WsCarver {
     size_t used() const { return align_up(off, 256); }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: the grant is remembered per
+// (kernel, device), so a process that drives several GPUs raises the limit on each of them.
+#define BUF_MAX_DEVICES 64
+struct LdsGrant { size_t bytes[BUF_MAX_DEVICES]; };
+int grant_dynamic_lds(const void* kernel, size_t bytes, LdsGrant& g);
+
 // In-place exclusive scan of int32 data[n] on `stream`; tmp must hold scan_tmp_ints() ints.
 size_t scan_tmp_ints();
 int exclusive_scan_i32(int* data, long long n, int* tmp, int* total_out, hipStream_t stream);

@@ -27,75 +27,16 @@
 #define CN_TAB 160                                // tap-table row: 10 tiles of 16 output positions (the 5/4 split reaches tile 9)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// timing experiments only (-DCYL_EXP=1: no LDS fragment loads, 2: no weight loads, 3: neither); default = real loads
-#ifndef CYL_EXP
-#define CYL_EXP 0
-#endif
-// -DCYL_PRIO=1: raise the wave priority around MFMA blocks; =2: static priority by workgroup parity (experiments)
-#ifndef CYL_PRIO
-#define CYL_PRIO 0
-#endif
-#if CYL_PRIO == 1
-#define CYL_PRIO_HI __builtin_amdgcn_s_setprio(2);
-#define CYL_PRIO_LO __builtin_amdgcn_s_setprio(0);
-#else
-#define CYL_PRIO_HI
-#define CYL_PRIO_LO
-#endif
-// CYL_SCHED: how the next group's operand loads are placed against the MFMA block of the current group.
-// 0: in front of it (sched_barrier), 1: compiler's choice, 2 (default, fastest measured at two workgroups per CU):
-// woven into it -- after every CYL_SG_M MFMAs up to CYL_SG_V VALU/SALU and CYL_SG_L memory instructions.
-#ifndef CYL_SCHED
-#define CYL_SCHED 2
-#endif
-#if CYL_SCHED == 0
-#define CYL_SCHED_MID __builtin_amdgcn_sched_barrier(0);
-#define CYL_SCHED_TAIL
-#elif CYL_SCHED == 1
-#define CYL_SCHED_MID
-#define CYL_SCHED_TAIL
-#else
-#ifndef CYL_SG_M
-#define CYL_SG_M 2
-#define CYL_SG_V 6
-#define CYL_SG_L 2
-#endif
-#define CYL_SCHED_MID
-// per MFMA: up to 2 VALU/SALU, then one memory instruction, woven between the matrix instructions
+// The next group's operand loads are woven into the MFMA block of the current group: after every 2 MFMAs up to
+// 6 VALU/SALU and 2 memory instructions (fastest measured placement at two workgroups per CU; round-1 experiments
+// with loads in front of the block, wave priorities and stubbed operand loads are in the git history).
 #define CYL_SCHED_TAIL                                                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < CN_PF * MT * NT; i_++) {                    \
-        __builtin_amdgcn_sched_group_barrier(0x008, CYL_SG_M, 0);                       \
-        __builtin_amdgcn_sched_group_barrier(0x006, CYL_SG_V, 0);                       \
-        __builtin_amdgcn_sched_group_barrier(0x120, CYL_SG_L, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x120, 2, 0);                              \
     }
-#endif
-#if CYL_EXP & 1
-#define CYL_EXP_A(x) (1.0f + (float)(g_ + p + t))
-#else
-#define CYL_EXP_A(x) (x)
-#endif
-#if CYL_EXP & 4
-#define CYL_EXP_OK(x) true
-#else
-#define CYL_EXP_OK(x) (x)
-#endif
-#if CYL_EXP & 2
-#define CYL_EXP_B(x) (0.5f + (float)(g_ + p + u))
-#else
-#define CYL_EXP_B(x) (x)
-#endif
 
-// -DCYL_PROF: cycle accounting of one wavefront (workgroup 300, wave 0) into g_cyl_prof, read back by
-// buf_debug_cyl_prof (development aid; not in the header): [0] tap loops, [1] MFMAs issued, [2] barrier before the
-// epilogue, [3] epilogue, [4] barrier after the layer, [5] whole kernel, [6] tap set-up (table reads, dispatch).
-#ifdef CYL_PROF
-__device__ unsigned long long g_cyl_prof[8];
-#define PROF_T() __builtin_readcyclecounter()
-#define PROF_ADD(i, dt) if (blockIdx.x == 300 && threadIdx.x == 0) g_cyl_prof[i] += (dt);
-#else
-#define PROF_T() 0ull
-#define PROF_ADD(i, dt)
-#endif
 struct CylNetParams {
     const float* wt[CN_LAYERS];     // [9*Cin][Cout], BN folded, in the MFMA B-operand tiling (blocks [K/16][Cout/16] of [lk][li][p])
     const float* bias[CN_LAYERS];   // [Cout]
@@ -140,10 +81,10 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         const float* wn_ = ws + (size_t)g_ * ntot * 256;      /* MFMA-tiled weights: one 16-byte load per N-tile */ \
         _Pragma("unroll") for (int u = 0; u < NT; u++) {                                               \
             const f32x4 bv_ = *reinterpret_cast<const f32x4*>(wn_ + u * 256);                          \
-            _Pragma("unroll") for (int p = 0; p < CN_PF; p++) B[p][u] = CYL_EXP_B(bv_[p]);             \
+            _Pragma("unroll") for (int p = 0; p < CN_PF; p++) B[p][u] = bv_[p];             \
         }                                                                                              \
         _Pragma("unroll") for (int p = 0; p < CN_PF; p++) {                                            \
-            _Pragma("unroll") for (int t = T0; t < T1; t++) A[p][t] = CYL_EXP_A(ib[io[t] + (g_ * CN_PF + p) * 4 * CN_STR]); \
+            _Pragma("unroll") for (int t = T0; t < T1; t++) A[p][t] = ib[io[t] + (g_ * CN_PF + p) * 4 * CN_STR]; \
         }                                                                                              \
     }
 #define CYL_MMA(A, B)                                                                                  \
@@ -159,14 +100,12 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         for (int g = 0; g < groups; g += 2) {
             __builtin_amdgcn_sched_barrier(0);
             CYL_LOAD(a1, b1, g + 1)
-            CYL_SCHED_MID
-            CYL_PRIO_HI CYL_MMA(a0, b0) CYL_PRIO_LO
+            CYL_MMA(a0, b0)
             CYL_SCHED_TAIL
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < groups) {
                 CYL_LOAD(a0, b0, g + 2)
-                CYL_SCHED_MID
-                CYL_PRIO_HI CYL_MMA(a1, b1) CYL_PRIO_LO
+                CYL_MMA(a1, b1)
                 CYL_SCHED_TAIL
             }
         }
@@ -176,7 +115,6 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
     using std::integral_constant;
 #pragma unroll 1
     for (int s = 0; s < 9; s++) {
-        unsigned long long tp6 = PROF_T();
         const int ky = s / 3 - 1;
         int io[MT];                                                     // lane's position in its channel row, per tile
 #pragma unroll
@@ -188,21 +126,14 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
         // drops its unused fifth tile.
         const bool skip_first = ky < 0 && mt0 == 0;
         const int t1 = mt_cnt - ((ky > 0 && mt0 + mt_cnt == CN_MT) ? 1 : 0);
-        unsigned long long tp0 = PROF_T();
-        PROF_ADD(6, tp0 - tp6)
         if (skip_first) run_tap(integral_constant<int, 1>{}, integral_constant<int, MT>{}, io, ws);
         else if (t1 == MT) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT>{}, io, ws);
         else if (t1 == MT - 1) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT - 1>{}, io, ws);
         else if constexpr (MT == 5) run_tap(integral_constant<int, 0>{}, integral_constant<int, MT - 2>{}, io, ws);
-        PROF_ADD(0, PROF_T() - tp0)
-        PROF_ADD(1, (unsigned long long)(groups * CN_PF * NT * (t1 - (skip_first ? 1 : 0))))
     }
     // The layer's output overwrites its input IN PLACE (one 72 KB LDS buffer per workgroup, so two workgroups
     // fit a CU and one computes while the other loads/stores): every wavefront has finished reading `in` here.
-    unsigned long long tp1 = PROF_T();
     __syncthreads();
-    PROF_ADD(2, PROF_T() - tp1)
-    tp1 = PROF_T();
     // epilogue: ReLU + store; C/D layout: col = lane & 15 (n), rows (lane >> 4)*4 + r (m).  Only the last M-tile has
     // rows past position 139 (its lanes with lk == 3); the branches below are wave-uniform except that one.
     const bool last_rows_ok = lk * 4 + 128 < CN_POS;
@@ -221,7 +152,6 @@ __device__ __forceinline__ void cyl_layer(const float* __restrict__ in, float* _
             else         *reinterpret_cast<f32x4*>(out_lds + n * CN_STR + m) = v;
         }
     }
-    PROF_ADD(3, PROF_T() - tp1)
 }
 
 __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restrict__ x, CylNetParams P, float* __restrict__ y)
@@ -241,10 +171,6 @@ __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restri
     }
     const int patch = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);     // wave-uniform: tile ranges branch on it
-    unsigned long long tk0 = PROF_T();
-#if CYL_PRIO == 2
-    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2);
-#endif
     {   // input: [16,3,7,20] = 48 folded channels x 140 positions, contiguous
         const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)patch * P.cin[0] * CN_POS);
         for (int i = threadIdx.x; i < P.cin[0] * (CN_POS / 4); i += CN_THREADS) {
@@ -269,16 +195,9 @@ __global__ void __launch_bounds__(CN_THREADS, 2) k_cyl_net(const float* __restri
             const int half = w & 1;
             cyl_layer<5, 1>(in, out, glb, postab, P.wt[l], P.bias[l], cin, cout, P.relu[l], half * 5, half ? 4 : 5, w >> 1);
         }
-        unsigned long long tb = PROF_T();
         __syncthreads();
-        PROF_ADD(4, PROF_T() - tb)
     }
-    PROF_ADD(5, PROF_T() - tk0)
 }
-
-#ifdef CYL_PROF
-extern "C" int buf_debug_cyl_prof(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cyl_prof), sizeof(g_cyl_prof)); }
-#endif
 
 // x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140].  wt/bias: DEVICE pointers per layer, passed in host arrays.
 extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
@@ -297,11 +216,8 @@ extern "C" int buf_cylindrical_net(const float* x, int npatch, const float* cons
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net: layer %d width mismatch", l);
     }
     size_t lds = sizeof(float) * CN_BUF + sizeof(unsigned short) * 9 * CN_TAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cyl_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsGrant grant;
+    if (int rc = grant_dynamic_lds((const void*)k_cyl_net, lds, grant)) return rc;
     // algorithmic flops of this launch: 2 * 140 positions * sum over layers of 9*Cin*Cout, per patch (0.1186 GFLOP)
     double macs = 0;
     for (int l = 0; l < CN_LAYERS; l++) macs += 9.0 * P.cin[l] * P.cout[l];

@@ -69,6 +69,19 @@ extern "C" long long buf_timing_collect(double* total_ms, double* total_bytes)
     return buf_timing_collect_kernel(BUF_TIMED_GRID_QUERY, total_ms, total_bytes);
 }
 
+static std::mutex g_grant_mu;
+int grant_dynamic_lds(const void* kernel, size_t bytes, LdsGrant& g)
+{
+    int dev = 0;
+    BUF_CHECK_HIP(hipGetDevice(&dev));
+    BUF_REQUIRE(dev >= 0 && dev < BUF_MAX_DEVICES, BUF_EINVAL, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> l(g_grant_mu);
+    if (g.bytes[dev] >= bytes) return BUF_OK;
+    BUF_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    g.bytes[dev] = bytes;
+    return BUF_OK;
+}
+
 extern "C" int buf_device_count(void)
 {
     int n = 0;
@@ -223,28 +236,36 @@ __global__ void __launch_bounds__(256) k_cell_rank(const int* __restrict__ cell_
     order_out[s + rank] = i;
 }
 
-// Upload prefix offsets of a host batch-length array (tiny) and validate their sum.
+// Prefix offsets of a host batch-length array -> device, validated against the expected total.  The values travel
+// BY VALUE in the kernel-argument block of a one-workgroup store kernel (128 per launch): no pageable-memory staging,
+// no host-blocking copy, safe from several host threads on several streams.
+#define OFFS_PER_LAUNCH 128
+struct OffsetChunk { int v[OFFS_PER_LAUNCH]; };
+
+__global__ void __launch_bounds__(OFFS_PER_LAUNCH) k_store_offsets(OffsetChunk c, int count, int* __restrict__ dst)
+{
+    if ((int)threadIdx.x < count) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+
 static int upload_offsets(int* dev, const int* lens_host, int nb, int expect_total, const char* what, hipStream_t s)
 {
-    int stackbuf[65];
-    int* off = nb + 1 <= 65 ? stackbuf : (int*)malloc(sizeof(int) * ((size_t)nb + 1));
-    off[0] = 0;
+    long long run = 0;
     for (int b = 0; b < nb; b++) {
-        if (lens_host[b] < 0) { if (off != stackbuf) free(off); buf_set_error("%s: negative batch length", what); return BUF_EINVAL; }
-        off[b + 1] = off[b] + lens_host[b];
+        if (lens_host[b] < 0) { buf_set_error("%s: negative batch length", what); return BUF_EINVAL; }
+        run += lens_host[b];
     }
-    int tot = off[nb];
-    if (tot != expect_total) {
-        if (off != stackbuf) free(off);
-        buf_set_error("%s: batch lengths sum to %d, expected %d", what, tot, expect_total);
+    if (run != expect_total) {
+        buf_set_error("%s: batch lengths sum to %lld, expected %d", what, run, expect_total);
         return BUF_EINVAL;
     }
-    // pageable source: the runtime stages the bytes before hipMemcpyAsync returns
-    hipError_t e = hipMemcpyAsync(dev, off, sizeof(int) * ((size_t)nb + 1), hipMemcpyHostToDevice, s);
-    if (off != stackbuf) {
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        free(off);
+    int off = 0;                                            // off = offsets[i0]
+    for (int i0 = 0; i0 <= nb; i0 += OFFS_PER_LAUNCH) {
+        OffsetChunk c;
+        int cnt = nb + 1 - i0 < OFFS_PER_LAUNCH ? nb + 1 - i0 : OFFS_PER_LAUNCH;
+        for (int j = 0; j < cnt; j++) { c.v[j] = off; if (i0 + j < nb) off += lens_host[i0 + j]; }
+        k_store_offsets<<<1, OFFS_PER_LAUNCH, 0, s>>>(c, cnt, dev + i0);
     }
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { buf_set_error("%s: offsets upload -> %s", what, hipGetErrorString(e)); return BUF_EHIP; }
     return BUF_OK;
 }

@@ -23,30 +23,17 @@
 #define CV_C32 36                 // position-row strides (floats) of maps with 32 / 64 / 128 channels
 #define CV_C64 68
 #define CV_C128 132
-#ifndef CV_EXP
-#define CV_EXP 0     // timing experiments only: 1 = no layer-0 GEMM, 2 = no layer-1 GEMM, 4 = no layers 2..9, 8 = no cost rows
-#endif
 
 typedef float cvx4 __attribute__((ext_vector_type(4)));
 
-// Placement of a group's operand loads against the previous group's MFMAs: CV_SCHED 0 = loads in front of the MFMA
-// block (sched_barrier), 2 = woven into it (after every 2 MFMAs up to 6 VALU/SALU and 2 memory instructions).
-#ifndef CV_SCHED
-#define CV_SCHED 2
-#endif
-#if CV_SCHED == 0
-#define CV_SCHED_MID __builtin_amdgcn_sched_barrier(0);
-#define CV_SCHED_TAIL(NMFMA, NMEM)
-#else
-#define CV_SCHED_MID
-// after every MFMA: up to 4 VALU/SALU and the group's memory instructions spread evenly (NMEM over NMFMA, rounded up)
+// A group's operand loads are woven into the previous group's MFMAs: after every MFMA up to 4 VALU/SALU and the
+// group's memory instructions spread evenly (NMEM over NMFMA, rounded up).
 #define CV_SCHED_TAIL(NMFMA, NMEM)                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < (NMFMA); i_++) {                            \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
         __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                              \
         __builtin_amdgcn_sched_group_barrier(0x120, ((NMEM) + (NMFMA) - 1) / (NMFMA), 0); \
     }
-#endif
 typedef const __attribute__((address_space(1))) cvx4* cv_gptr;     // global (not flat) 16-byte weight loads
 
 struct CostNetParams {
@@ -85,7 +72,6 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
     for (int g = 0; g < TOTAL; g++) {
         __builtin_amdgcn_sched_barrier(0);
         if (g + D - 1 < TOTAL) CVS_LOAD((g + D - 1) % D, g + D - 1)
-        CV_SCHED_MID
 #pragma unroll
         for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -208,8 +194,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
             __builtin_amdgcn_sched_barrier(0);
             if (cg + 1 < GPT) CVC_LOAD((cg + 1) & 1, cur, wcur, cg + 1)
             else              CVC_LOAD((cg + 1) & 1, nxt, wnxt, 0)
-            CV_SCHED_MID
-#pragma unroll
+    #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
                 for (int t = 0; t < MT; t++)
@@ -273,14 +258,14 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     m0 = m0 < 54 ? m0 : 53;
 #pragma unroll 1
     for (int nrow = 0; nrow < 18; nrow++) {
-        if (!(CV_EXP & 8)) cost_row(D, S, T, nrow + 2);         // slot of row nrow-1, which nobody reads any more
+        cost_row(D, S, T, nrow + 2);         // slot of row nrow-1, which nobody reads any more
         __syncthreads();
         {
             L0Loader L;
 #pragma unroll
             for (int dn = 0; dn < 3; dn++) L.row[dn] = D + ((nrow + dn) % 3) * (100 * CV_C32) + ((m0 / 18) * 20 + (m0 % 18)) * CV_C32 + lk * 4;
             cvx4 acc[1][2] = { { (cvx4){ b0v[0], b0v[0], b0v[0], b0v[0] }, (cvx4){ b0v[1], b0v[1], b0v[1], b0v[1] } } };   // bias first
-            if (!(CV_EXP & 1)) cv_gemm_static<1, 2, 4, 54>(acc, L, P.wt[0] + (size_t)lane * 4, 2);
+            cv_gemm_static<1, 2, 4, 54>(acc, L, P.wt[0] + (size_t)lane * 4, 2);
             // C/D layout: lane holds channel n = 16u + li at the four positions m = 16w + 4lk + r
 #pragma unroll
             for (int u = 0; u < 2; u++)
@@ -291,7 +276,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
                 }
         }
         __syncthreads();
-        if (!(CV_EXP & 2)) {
+        {
             L1Loader L;
             L.base = R + li * CV_C32 + lk * 4;
             const float* w1 = P.wt[1] + ((size_t)w * 64 + lane) * 4;      // N-tile w of 4; a dn slab = 18 groups
@@ -310,7 +295,6 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     }
 
     // ---- phase B: layers 2..9, ping-pong bufA <-> bufB ---------------------------------------------------
-    if (CV_EXP & 4) return;
     cv_conv_layer<13, 1, 64, 64, 16, 3>(bufA, bufB, P.wt[2], P.bias[2], w, true);            // 16x16 -> 14x14
     __syncthreads();
     cv_conv_layer<9, 2, 64, 128, 14, 3>(bufB, bufA, P.wt[3], P.bias[3], 2 * w, true);        // -> 12x12
@@ -351,11 +335,8 @@ extern "C" int buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, 
         BUF_REQUIRE(P.wt[l] && P.bias[l], BUF_EINVAL, "buf_cost_volume_net: null weights for layer %d", l);
     }
     size_t lds = sizeof(float) * 2 * CV_BUF;
-    static bool attr_set = false;
-    if (!attr_set) {
-        BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_cost_net, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsGrant grant;
+    if (int rc = grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
     // algorithmic flops per match (valid convolutions 20x5x20 -> 18x3x18 -> 16x1x16 -> 14 -> 12 -> 10 -> 8 -> 6 -> 4 -> 2 -> 1):
     // 2 * sum(out positions * K * Cout) = 0.160 GFLOP
     static const double macs_per_match =

@@ -8,10 +8,12 @@
 // (PPT points per lane), one workgroup barrier per round.
 //
 // Selection order reproduces the upstream kernel: temp starts at 1e10, points with
-// x^2+y^2+z^2 <= 1e-3 (double compare) neither update nor compete, the arg-max prefers, on equal
-// distance, the smaller (k mod T) and then the smaller k, T = min(512, 2^floor(log2 n)) being the
-// upstream block size (per-thread strict '>' over k = t, t+T, ...; pairwise tree keeps the lower
-// thread).  Keys are packed as (d2 bits << 32) | ~((k mod T) << 22 | k) and max-reduced.
+// x^2+y^2+z^2 <= 1e-3 (double compare) neither update nor compete.  T = min(512, 2^floor(log2 n)) is the
+// upstream block size: thread t scans k = t, t+T, ... with a strict '>' (its first maximum wins), then the
+// shared-memory tree folds slot t+s into slot t for s = T/2 .. 1 and keeps slot t on equality.  The LAST fold
+// (s = 1) separates even from odd threads, the one before it bit 1, ...: among equal maxima the thread that is
+// smallest in BIT-REVERSED order wins (T = 4, threads 1 and 2 tied -> thread 2).  Tie key, smaller wins:
+// bitrev_log2T(k mod T) << 22 | k.
 #define FPS_THREADS 512           // fallback kernel + the >16k-point register-resident variants
 #define FPS_WAVES (FPS_THREADS / WAVE)
 #define FPS_LDS_POINTS 12800      // clouds up to this size keep an xyz copy in LDS for the winner lookup
@@ -20,6 +22,11 @@
 struct FpsBatch { int off[FPS_MAXB]; int n[FPS_MAXB]; };   // per-cloud row offset and length (ragged batch)
 
 // wave64 max-reduction of a non-negative-or-(-1) float through DPP row shifts/broadcasts (no LDS traffic)
+__device__ __forceinline__ unsigned int fps_tie_rank(unsigned int t, int T)      // bit reversal of t in log2(T) bits
+{
+    return T > 1 ? __brev(t) >> (__clz(T) + 1) : 0u;       // T = 2^b: clz = 31 - b, shift = 32 - b
+}
+
 __device__ __forceinline__ float wave_max_f32(float v)
 {
 #define DPP_MAX(ctrl, rmask, bmask) \
@@ -67,7 +74,7 @@ __global__ void __launch_bounds__(THREADS) k_fps(const float* __restrict__ xyz, 
     __shared__ unsigned int stie[2][NW];
     float x1 = n > 0 ? P[0] : 0.f, y1 = n > 0 ? P[1] : 0.f, z1 = n > 0 ? P[2] : 0.f;
     if (tid == 0 && m > 0) out[0] = 0;
-    const unsigned int tmod = (unsigned int)(tid % T) << 22;
+    const unsigned int tmod = fps_tie_rank((unsigned int)(tid % T), T) << 22;
     for (int r = 1; r < m; r++) {
         // distances of all PPT points are independent; the arg-max is a balanced tree (max, then the
         // first j that attains it), so no serial compare/select chain sits on the critical path
@@ -91,7 +98,7 @@ __global__ void __launch_bounds__(THREADS) k_fps(const float* __restrict__ xyz, 
         float wmax = wave_max_f32(best);
         const int buf = r & 1;
         if (wmax >= 0.f) {
-            // smaller tie key wins among equal distances: (k mod T) << 22 | k
+            // smaller tie key wins among equal distances: bitrev(k mod T) << 22 | k
             unsigned int tk = tmod | (unsigned int)(tid + bj * THREADS);
             unsigned long long cand = __ballot(best == wmax);
             int win;
@@ -162,7 +169,7 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps_global(const float* __restr
             float d2 = fminf(sqdist3(x, y, z, x1, y1, z1), temp[k]);
             temp[k] = d2;
             unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) |
-                                     (unsigned int)~((((unsigned int)(k % T)) << 22) | (unsigned int)k);
+                                     (unsigned int)~((fps_tie_rank((unsigned int)(k % T), T) << 22) | (unsigned int)k);
             best = key > best ? key : best;
         }
         unsigned long long wbest = wave_max_u64(best);
@@ -202,7 +209,7 @@ extern "C" int buf_fps_ragged(const float* xyz, const int* lengths_host, int b, 
         // <= 12800 points: an xyz copy in LDS serves the winner lookup (one broadcast ds_read instead of an L2 round trip)
         const size_t lds = sizeof(float) * 3 * (size_t)nmax;
 #define FPS_LAUNCH(TH, PPT_, L) \
-    do { if (L) { static bool set_ = false; if (!set_) { BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_fps<TH, PPT_, L>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_LDS_POINTS * 12)); set_ = true; } } \
+    do { if (L) { static LdsGrant grant_; if (int rc_ = grant_dynamic_lds((const void*)k_fps<TH, PPT_, L>, FPS_LDS_POINTS * 12, grant_)) return rc_; } \
          k_fps<TH, PPT_, L><<<nb, TH, (L) ? lds : 0, s>>>(xyz, B, m, out); } while (0)
         if (nmax <= 4 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 4, true);
         else if (nmax <= 8 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 8, true);

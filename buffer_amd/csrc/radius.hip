@@ -421,10 +421,10 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
                               const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
                               int* max_count_out, void* todo_ws, void* stream)
 {
-    // self query in cell order: index and coordinates of query t come from the cell-ordered array itself
-    const int self_query = (q_order == g->order && queries == g->supports && nq == g->ns) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     BUF_REQUIRE(g && g->ws && q_batches_host, BUF_EINVAL, "buf_grid_query: null argument");
+    // self query in cell order: index and coordinates of query t come from the cell-ordered array itself
+    const int self_query = (q_order == g->order && queries == g->supports && nq == g->ns) ? 1 : 0;
     BUF_REQUIRE(nq >= 0 && k_out >= 0, BUF_EINVAL, "buf_grid_query: nq=%d k_out=%d", nq, k_out);
     BUF_REQUIRE(k_out == 0 || nbr_out, BUF_EINVAL, "buf_grid_query: null nbr_out");
     BUF_REQUIRE(radius <= g->radius, BUF_EINVAL, "buf_grid_query: radius %g > grid radius %g", radius, g->radius);

@@ -278,7 +278,7 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     int* hc = nb + 2 <= 66 ? stackc : (int*)malloc(sizeof(int) * ((size_t)nb + 2));
     hipError_t e = hipMemcpyAsync(hc, v.counts, sizeof(int) * ((size_t)nb + 2), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    int err = hc[nb];
+    int err = e == hipSuccess ? hc[nb] : 0;          // hc[] is valid only after a successful copy + sync
     int m = 0;
     rc = BUF_OK;
     if (e != hipSuccess) { buf_set_error("buf_grid_subsample_batch: %s", hipGetErrorString(e)); rc = BUF_EHIP; }

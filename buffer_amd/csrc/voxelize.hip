@@ -18,9 +18,6 @@
 #define VOX_CH 16
 #define VOX_MAXS 16           // max samples per voxel kept in the hit list
 #define VOX_GRID 16           // lookup grid cells per axis
-#ifndef VOX_EXP
-#define VOX_EXP 0             // timing experiments only: 1 no phase 1, 2 no phase 2, 4 no phase 3, 8 no Rodrigues, 16 no stores
-#endif
 #define VOX_PP 4              // points per step of a lane group in phase 1
 #define VOX_SENT 0xFFFFu      // end-of-list filler of a lookup row
 
@@ -52,7 +49,7 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
     if (tid == 0) {
         float R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
         float rx = 1.f, ry = 0.f, rz = 0.f;                      // KITTI/ETH: rand_axis = e_x, R = I (:143-147)
-        if (axis && !(VOX_EXP & 8)) {
+        if (axis) {
             // RodsRotatFormula(z_axis, e_z) (utils/common.py:501-525), returned transposed
             float ax = axis[3 * (size_t)p], ay = axis[3 * (size_t)p + 1], az = axis[3 * (size_t)p + 2];
             float cx = ay, cy = -ax, cz = 0.f;                   // a x e_z
@@ -110,7 +107,7 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
     // Phase 1: 8 lanes share a point and split its candidate list; VOX_PP points per step so that 3*VOX_PP table
     // loads (L2 hits) are in flight per lane.  The d^2 test is the one a full scan would do (same operand order),
     // the lookup grid only removes centres that cannot pass it.  Rows end in >= 8 VOX_SENT entries.
-    if (!(VOX_EXP & 1)) {
+    {
         const float lo = tab_hdr[0], inv_h = tab_hdr[1];
         const int sub = tid & 7, rs = vox_row_stride(ncentres);
         auto test = [&](unsigned short cj, const float4& q, unsigned* mrow, unsigned bit) {
@@ -160,7 +157,7 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
     // Phase 2: every centre lane lists its first `nsample` hits in index order.
     int cnt = 0, nreal = 0;                                      // accepted samples / samples kept in the list
     bool zero_slot = false;
-    if (active && !(VOX_EXP & 2)) {
+    if (active) {
         for (int w = 0; w < W && cnt < nsample; w++) {
             unsigned word = mask[w * VOX_THREADS + tid];
             while (word && cnt < nsample) {
@@ -176,7 +173,7 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
     float acc[VOX_CH];
 #pragma unroll
     for (int ch = 0; ch < VOX_CH; ch++) acc[ch] = -3.4e38f;
-    for (int sidx = 0; !(VOX_EXP & 4) && __any(sidx < nreal); sidx++) {
+    for (int sidx = 0; __any(sidx < nreal); sidx++) {
         if (sidx < nreal) {
             float4 q = pts[hits[sidx * VOX_THREADS + tid]];
             float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz = q.z;
@@ -187,7 +184,7 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
             }
         }
     }
-    if (active && !(VOX_EXP & 16)) {
+    if (active) {
         bool padded = cnt < nsample || zero_slot;                // zeroed slots go through the MLP as the origin
 #pragma unroll
         for (int ch = 0; ch < VOX_CH; ch++) {
@@ -267,11 +264,9 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
     }
     const size_t lds = sizeof(float4) * (size_t)npts + sizeof(unsigned) * (size_t)((npts + 31) / 32) * VOX_THREADS +
                        sizeof(unsigned short) * (size_t)nsample * VOX_THREADS;
-    static size_t lds_allowed = 48 * 1024;
-    if (lds > lds_allowed) {
-        BUF_CHECK_HIP(hipFuncSetAttribute((const void*)k_patch_voxelize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_allowed = lds;
-    }
+    static LdsGrant grant;
+    if (lds > 48 * 1024)
+        if (int rc = grant_dynamic_lds((const void*)k_patch_voxelize, lds, grant)) return rc;
     k_patch_voxelize<<<npatch, VOX_THREADS, lds, (hipStream_t)stream>>>(patches, axis, npts, des_r, centres, ncentres, azi_n,
                                                                       azi_cs, voxel_r * voxel_r, nsample, M, hdr, tab, out_x,
                                                                       out_R, out_rand, out_patches);

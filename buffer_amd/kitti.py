@@ -6,8 +6,8 @@
     <root>/icp/<drive>_<t0>_<t1>.npy                         ICP-refined ground truth (optional cache)
 
 The reference refines the odometry ground truth with open3d ICP on first use and caches it under icp/
-(dataset.py:95-117); open3d is not available here, so a cached file is used when present and the plain odometry
-transform otherwise.  Host code is file IO and bookkeeping; voxelisation, normals and registration run on the device."""
+(dataset.py:95-117); open3d is not available here, so the cached file is required unless --allow-odometry-gt is
+given, and the summary reports how many pairs used which source (`gt_source`).  Host code is file IO and bookkeeping; voxelisation, normals and registration run on the device."""
 import glob
 import math
 import os
@@ -29,34 +29,44 @@ def odometry_to_positions(odometry):
     return np.vstack((odometry.reshape(3, 4), [0, 0, 0, 1]))
 
 
-class KittiTestSet:
-    """KITTIDataset(split='test') (dataset.py:44-70): consecutive scan pairs at least 10 m apart."""
+def select_pairs(scan_ids, positions, min_dist=10.0, window=100):
+    """Test pairs of one drive (the rule of KITTI/dataset.py:52-67): starting from the first scan t, the partner is
+    the LAST frame before the vehicle has moved more than `min_dist` metres from t (searched over the next `window`
+    frames of the pose table); the following pair starts right after the partner.  A frame with no such partner in
+    the window is skipped.  positions f64[n_frames,3] (camera-0 translations), scan_ids = frames that have a scan.
+    Distances are taken against frame t only (O(window) per step, not the full n x n table)."""
+    have = set(int(i) for i in scan_ids)
+    pairs, t = [], int(min(have))
+    while t in have:
+        d = np.sqrt(((positions[t:t + window] - positions[t]) ** 2).sum(-1))
+        far = np.flatnonzero(d > min_dist)
+        partner = t + int(far[0]) - 1 if far.size else None
+        if partner is not None and partner in have:
+            pairs.append((t, partner))
+            t = partner + 1
+        else:
+            t += 1          # no partner in the window (or its scan file is missing): move on
+    return pairs
 
-    def __init__(self, root, drives=TEST_DRIVES, downsample=0.05, voxel_size_0=0.30, max_num_pts=40000):
+
+class KittiTestSet:
+    """KITTIDataset(split='test') (dataset.py:44-70): scan pairs about 10 m apart along the trajectory."""
+
+    def __init__(self, root, drives=TEST_DRIVES, downsample=0.05, voxel_size_0=0.30, max_num_pts=40000,
+                 allow_odometry_gt=False):
         self.pc_path = os.path.join(root, 'dataset')
         self.icp_path = os.path.join(root, 'icp')
         self.downsample, self.voxel_size_0, self.max_num_pts = downsample, voxel_size_0, max_num_pts
+        self.allow_odometry_gt = allow_odometry_gt
+        self.gt_source = {}                                          # pair index -> 'icp-cache' | 'odometry'
         self.files, self._odo = [], {}
         for drive in drives:
             fnames = glob.glob(os.path.join(self.pc_path, 'sequences', '%02d' % drive, 'velodyne', '*.bin'))
             if not fnames:
                 raise FileNotFoundError(f'no velodyne scans for drive {drive} under {self.pc_path}')
-            inames = sorted(int(os.path.split(f)[-1][:-4]) for f in fnames)
-            have = set(inames)
-            all_pos = np.array([odometry_to_positions(o) for o in self.odometry(drive)])
-            Ts = all_pos[:, :3, 3]
-            pdist = np.sqrt(((Ts.reshape(1, -1, 3) - Ts.reshape(-1, 1, 3)) ** 2).sum(-1))
-            more_than_10 = pdist > 10
-            curr = inames[0]
-            while curr in have:                                      # dataset.py:58-67, verbatim control flow
-                nxt = np.where(more_than_10[curr][curr:curr + 100])[0]
-                if len(nxt) == 0:
-                    curr += 1
-                else:
-                    nxt = nxt[0] + curr - 1
-                if not isinstance(nxt, np.ndarray) and nxt in have:
-                    self.files.append((drive, curr, int(nxt)))
-                    curr = int(nxt) + 1
+            scan_ids = [int(os.path.basename(f)[:-4]) for f in fnames]
+            positions = np.array([odometry_to_positions(o)[:3, 3] for o in self.odometry(drive)])
+            self.files += [(drive, t0, t1) for t0, t1 in select_pairs(scan_ids, positions)]
         if (8, 15, 58) in self.files:                                # "pair (8, 15, 58) is wrong" (dataset.py:69-71)
             self.files.remove((8, 15, 58))
 
@@ -69,11 +79,18 @@ class KittiTestSet:
         return len(self.files)
 
     def ground_truth(self, index):
-        """dataset.py:95-117: ICP-refined transform scan t0 -> scan t1 (cached) or the odometry one."""
+        """dataset.py:95-117: ICP-refined transform scan t0 -> scan t1 from the reference's cache file.  Without the
+        cache the raw odometry transform is a visibly worse ground truth at the 0.3 m / 1 degree criterion, so it is
+        used only when `allow_odometry_gt` is set, and every pair's source is recorded in `gt_source`."""
         drive, t0, t1 = self.files[index]
         cached = os.path.join(self.icp_path, '%d_%d_%d.npy' % (drive, t0, t1))
         if os.path.exists(cached):
+            self.gt_source[index] = 'icp-cache'
             return np.load(cached)
+        if not self.allow_odometry_gt:
+            raise FileNotFoundError(f'{cached} missing: the reference evaluates against ICP-refined poses; pass '
+                                    f'allow_odometry_gt=True (--allow-odometry-gt) to fall back to raw odometry')
+        self.gt_source[index] = 'odometry'
         p0, p1 = (odometry_to_positions(o) for o in self.odometry(drive)[[t0, t1]])
         return (VELO2CAM @ p0.T @ np.linalg.inv(p1.T) @ np.linalg.inv(VELO2CAM)).T
 
@@ -110,8 +127,10 @@ def summarize(dataset, poses, rte_thresh=0.3, rre_thresh=1.0):
         st.append([rte < rte_thresh and rre < rre_thresh, rte, rre])
     st = np.array(st, np.float64).reshape(-1, 3)
     good = st[:, 0] == 1
+    src = list(dataset.gt_source.values())
     return dict(pairs=int(st.shape[0]), recall=float(good.mean()) if st.size else 0.0,
-                te=float(st[good, 1].mean()) if good.any() else float('nan'), re=float(st[good, 2].mean()) if good.any() else float('nan'))
+                te=float(st[good, 1].mean()) if good.any() else float('nan'), re=float(st[good, 2].mean()) if good.any() else float('nan'),
+                gt_source={k: src.count(k) for k in ('icp-cache', 'odometry')})
 
 
 def main(argv=None):
@@ -129,13 +148,15 @@ def main(argv=None):
     ap.add_argument('--root', required=True)
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--limits', default=None)
+    ap.add_argument('--allow-odometry-gt', action='store_true',
+                    help='evaluate against raw odometry where <root>/icp/<drive>_<t0>_<t1>.npy is missing (lowers recall)')
     a = ap.parse_args(argv)
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('WORLD_SIZE', 1), ('LOCAL_RANK', 0)))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
-    ds = KittiTestSet(a.root)
+    ds = KittiTestSet(a.root, allow_odometry_gt=a.allow_odometry_gt)
     pipe = BufferPipeline(KITTI, dev)
     if a.limits:
         pipe.limits = [int(x) for x in a.limits.split(',')]

@@ -1,13 +1,12 @@
 """A8-A11 -- patch-wise embedder (MiniSpinNet, models/patch_embedder.py) on device.
 
-select_patches and the fused align/voxelise/point-MLP run as hand-written kernels (csrc/pointops.hip,
-csrc/voxelize.hip); the dense Cylindrical_Net stack (models/patchnet.py:15-85) currently goes through
-torch's convolution (MIOpen) with the reference's circular-azimuth / zero-elevation padding -- the
-hand-written MFMA implicit GEMM is SURVEY 8(f) N2.
+Every stage is a hand-written kernel behind the C ABI: select_patches (csrc/pointops.hip), the fused
+align / voxelise / point-MLP (csrc/voxelize.hip), the dense Cylindrical_Net stack (models/patchnet.py:15-85)
+as one fp32-MFMA implicit GEMM with the circular-azimuth / zero-elevation padding folded into its addressing,
+and the attention-pooling head (csrc/convnet.hip).  No library convolution runs in the product.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -49,54 +48,26 @@ class PatchEmbedder:
         self.mlp_s = s.astype(np.float32)
         self.mlp_t = (np.asarray(W['Desc.pnt_layer.1.bias'], np.float64)
                       - np.asarray(W['Desc.pnt_layer.1.running_mean'], np.float64) * s).astype(np.float32)
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         p = 'Desc.conv_net.ops'
-        self.convs = []
-        for i, bn in ((0, 1), (3, 4), (6, 7), (9, 10), (12, 13), (15, 16), (18, 19)):
-            w, b = _fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var'])
-            self.convs.append((t(w), t(b)))
-        self.last = (t(np.asarray(W[f'{p}.21.weight'], np.float32)), t(np.asarray(W[f'{p}.21.bias'], np.float32)))
-        # fused fp32-MFMA stack (csrc/convnet.hip): layer 0's radial depth folds into the channels (c16*3 + d)
+        # fused fp32-MFMA stack (csrc/convnet.hip): BN folded, layer 0's radial depth folds into the channels (c16*3 + d)
         layers = []
-        for i, (w, b) in enumerate(self.convs):
-            w = w.cpu().numpy()
-            if i == 0:
+        for n, (i, bn) in enumerate(((0, 1), (3, 4), (6, 7), (9, 10), (12, 13), (15, 16), (18, 19))):
+            w, b = _fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var'])
+            if n == 0:
                 w = w.reshape(w.shape[0], w.shape[1] * w.shape[2], 3, 3)
-            layers.append((w, b.cpu().numpy(), True))
-        layers.append((self.last[0].cpu().numpy(), self.last[1].cpu().numpy(), False))
+            layers.append((w, b, True))
+        layers.append((np.asarray(W[f'{p}.21.weight'], np.float32), np.asarray(W[f'{p}.21.bias'], np.float32), False))
         self.fused = ops.CylindricalNet(layers, device)
         q = 'Desc.pool_layer'
         w0, b0 = _fold_bn(W[f'{q}.0.weight'], W[f'{q}.0.bias'], W[f'{q}.1.running_mean'], W[f'{q}.1.running_var'],
                           W[f'{q}.1.weight'], W[f'{q}.1.bias'])
         w3, b3 = _fold_bn(W[f'{q}.3.weight'], W[f'{q}.3.bias'], W[f'{q}.4.running_mean'], W[f'{q}.4.running_var'],
                           W[f'{q}.4.weight'], W[f'{q}.4.bias'])
-        self.pool = [(t(w0), t(b0)), (t(w3), t(b3))]
         self.fused_head = ops.DescriptorHead(w0, b0, w3, b3, device)
-
-    @staticmethod
-    def _pad(x):
-        """pad_image / pad_image_3d (utils/common.py:265-310): circular azimuth (last dim), zeros in elevation."""
-        x = torch.cat([x[..., -1:], x, x[..., :1]], -1)
-        return F.pad(x, (0, 0, 1, 1))
-
-    def conv_net(self, x):
-        """Cylindrical_Net: x f32[P,16,3,7,20] -> f32[P,32,7,20]."""
-        w, b = self.convs[0]
-        x = F.relu(F.conv3d(self._pad(x), w, b)).squeeze(2)
-        for w, b in self.convs[1:]:
-            x = F.relu(F.conv2d(self._pad(x), w, b))
-        return F.conv2d(self._pad(x), *self.last)
 
     def head(self, x):
         """attention pooling + normalisation (patch_embedder.py:81-84), one fused launch."""
         return self.fused_head(x)
-
-    def head_library(self, x):
-        """the same head on library convolutions (kept for A/B measurement and the parity test)."""
-        w = F.relu(F.conv2d(x, *self.pool[0]))
-        w = F.relu(F.conv2d(w, *self.pool[1]))
-        f = (x * w).mean((2, 3))
-        return F.normalize(f, p=2, dim=1), F.normalize(x, p=2, dim=1)
 
     def embed_patches(self, patches, axis, want_patches=False):
         """patches f32[Q,S,3] (any number of clouds stacked), axis f32[Q,3] -> dict(desc, equi, R, rand_axis)."""
@@ -108,28 +79,14 @@ class PatchEmbedder:
         f, e = self.head(self.fused(x))
         return dict(desc=f, equi=e, R=R, rand_axis=rand_axis, x=x, patches=pn)
 
-    def __call__(self, pts, kpts, axis, perm=None, chunk=1024, want_patches=False, fused=True):
+    def __call__(self, pts, kpts, axis, perm=None, want_patches=False):
         """pts f32[N,3] (2 cm cloud), kpts f32[P,3], axis f32[P,3] -> dict(desc, equi, R, rand_axis[, patches])."""
         cfg = self.cfg
         if perm is None:
             perm = torch.randperm(pts.shape[0], device=pts.device)        # patch_embedder.py:97-98
         sup = pts[perm].contiguous()
         patches = ops.select_patches(sup, kpts.contiguous(), cfg.des_r, cfg.num_points_per_patch)
-        ax = axis.contiguous() if cfg.dataset in ('3DMatch', '3DLoMatch') else None
-        x, R, rand_axis, pn = ops.patch_voxelize(patches, ax, cfg.des_r, self.centres, self.azi_cs,
-                                                 cfg.delta / cfg.rad_n, cfg.voxel_sample, self.mlp_w, self.mlp_b,
-                                                 self.mlp_s, self.mlp_t, cfg.azi_n, want_patches)
-        descs, equis = [], []
-        if fused:
-            f, e = self.head(self.fused(x))
-            descs.append(f); equis.append(e)
-        else:       # library convolutions (kept for A/B measurement)
-            for s in range(0, x.shape[0], chunk):
-                y = self.conv_net(x[s:s + chunk].view(-1, 16, cfg.rad_n, cfg.ele_n, cfg.azi_n))
-                f, e = self.head_library(y)
-                descs.append(f); equis.append(e)
-        out = dict(desc=torch.cat(descs), equi=torch.cat(equis), R=R, rand_axis=rand_axis, x=x)
+        out = self.embed_patches(patches, axis, want_patches)
         if want_patches:
-            out['patches'] = pn
             out['init_patches'] = patches
         return out

@@ -108,7 +108,7 @@ class BufferPipeline:
                 return [torch.eye(4, device=dev) for _ in range(B)]
             good = [b for b in range(B) if b not in bad]            # rare: redo the healthy pairs one by one
             for b in good:
-                poses[b] = self.register(inps[b], seed=seeds[b])
+                poses[b] = self.register(inps[b], seed=seeds[b], perms=perms[b] if perms is not None else None)
             return [p if p is not None else torch.eye(4, device=dev) for p in poses]
         cand_p, cand_a = pts0[keep].contiguous(), axis_o[keep].contiguous()
         fps = ops.furthest_point_sample_ragged(cand_p, counts, cfg.num_keypts).long()       # one workgroup per cloud

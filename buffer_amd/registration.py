@@ -1,7 +1,6 @@
 """A12-A16 -- matching and pose recovery on device (models/BUFFER.py:283-333,335-359,382-464)."""
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .patch_embedder import _fold_bn
@@ -19,40 +18,26 @@ def mutual_matching(src_des, tgt_des):
 
 
 class CostVolume:
-    """CostVolume + CostNet (BUFFER.py:37-66, models/patchnet.py:88-147): fused fp32-MFMA kernel
-    (csrc/costnet.hip); the library-convolution path is kept for A/B measurement."""
+    """CostVolume + CostNet (BUFFER.py:37-66, models/patchnet.py:88-147): one fused fp32-MFMA kernel
+    (csrc/costnet.hip).  The kernel is written for the released geometry (32 channels, 5 elevation rows,
+    azi_n = 20); anything else raises -- there is no library-convolution path in the product."""
 
     def __init__(self, W, device, azi_n=20):
+        if azi_n != 20:
+            raise NotImplementedError(f'CostVolume: the fused kernel is built for azi_n = 20 (got {azi_n})')
         self.azi_n = azi_n
         p = 'Inlier.conv.ops'
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        self.convs = []
+        layers = []
         for i, bn in ((0, 1), (3, 4), (6, 7), (9, 10), (12, 13), (15, 16), (18, 19), (21, 22), (24, 25)):
-            w, b = _fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var'])
-            self.convs.append((t(w), t(b)))
-        self.last = (t(np.asarray(W[f'{p}.27.weight'], np.float32)), t(np.asarray(W[f'{p}.27.bias'], np.float32)))
-        layers = [(w.cpu().numpy(), b.cpu().numpy()) for w, b in self.convs] + \
-                 [(self.last[0].cpu().numpy(), self.last[1].cpu().numpy())]
-        self.fused = ops.CostVolumeNet(layers, device) if azi_n == 20 else None     # csrc/costnet.hip
-        cols = np.stack([np.roll(np.arange(azi_n), i) for i in range(azi_n)])     # BUFFER.py:41-46
-        self.cols = torch.from_numpy(cols.reshape(-1)).to(device)
-        self.bins = torch.arange(0, azi_n, dtype=torch.float32, device=device)
+            layers.append(_fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var']))
+        layers.append((np.asarray(W[f'{p}.27.weight'], np.float32), np.asarray(W[f'{p}.27.bias'], np.float32)))
+        self.fused = ops.CostVolumeNet(layers, device)                              # csrc/costnet.hip
 
-    def __call__(self, d1, d2, chunk=256, fused=True):
+    def __call__(self, d1, d2):
         """d1,d2 f32[M,32,5,20] -> expected azimuth shift f32[M]."""
-        if fused and self.fused is not None and tuple(d1.shape[1:]) == (32, 5, 20):
-            return self.fused(d1, d2)
-        outs = []
-        n = self.azi_n
-        for s in range(0, d1.shape[0], chunk):
-            a, b = d1[s:s + chunk], d2[s:s + chunk]
-            x = a[:, :, :, self.cols].reshape(a.shape[0], a.shape[1], a.shape[2], n, n).permute(0, 1, 3, 2, 4)
-            x = x - b.unsqueeze(2)
-            for w, bb in self.convs:
-                x = F.relu(F.conv3d(x, w, bb))
-            x = F.conv3d(x, *self.last).reshape(x.shape[0], -1)
-            outs.append(torch.sum(F.softmax(x, dim=-1) * self.bins[None], dim=-1))
-        return torch.cat(outs) if outs else torch.zeros(0, device=d1.device)
+        if tuple(d1.shape[1:]) != (32, 5, 20) or d1.shape != d2.shape:
+            raise ValueError(f'CostVolume: expected two [M,32,5,20] maps, got {tuple(d1.shape)} and {tuple(d2.shape)}')
+        return self.fused(d1, d2)
 
 
 def recover_pose(ind, ss_kpts, tt_kpts, ss_R, tt_R, cfg, seed=0):

@@ -8,7 +8,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream). All work
  *     is enqueued asynchronously on it unless the comment says "synchronises".
  *   - scratch memory is caller-owned: size it with the matching *_ws_bytes().
- *   - no torch types, no C++ types, no hidden global state.
+ *   - no torch types, no C++ types.  Process state is limited to: the thread-local error message, the per-device
+ *     record of raised dynamic-LDS limits (hipFuncSetAttribute is per device; a process may drive several GPUs),
+ *     and the optional HIP-event timing registry behind buf_timing_enable (off by default, mutex-guarded).
  *
  * Reference interfaces replaced (paths relative to the BUFFER repository):
  *   cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238        radius_neighbors.batch_query

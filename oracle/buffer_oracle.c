@@ -224,10 +224,12 @@ int orc_radius_neighbors(const float* q, int nq, const float* s, int ns,
  * over k; per thread strict '>' keeps its first maximum; the pairwise tree
  * keeps the LOWER thread on equality. temp starts at 1e10; points with
  * x*x+y*y+z*z <= 1e-3 (compared in double) never update or compete. */
-static int fps_threads(int n)
+int orc_fps_threads(int n)
 {
-    int p = 1;
-    while (p * 2 <= n && p * 2 <= 512) p *= 2;
+    /* upstream opt_n_threads(): pow_2 = log(n) / log(2) truncated, block = clamp(1 << pow_2, 1, 512) */
+    if (n < 1) return 1;
+    int pow_2 = (int)(log((double)n) / log(2.0));
+    int p = pow_2 >= 9 ? 512 : (1 << pow_2);
     return p < 1 ? 1 : p;
 }
 
@@ -235,7 +237,7 @@ void orc_fps(const float* xyz, int nbatch, int n, int m, int* idx)
 {
     if (m <= 0) return;
     float* temp = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
-    int T = fps_threads(n);
+    int T = orc_fps_threads(n);
     float* tb = (float*)malloc(sizeof(float) * (size_t)T);
     int* ti = (int*)malloc(sizeof(int) * (size_t)T);
     for (int b = 0; b < nbatch; b++) {
@@ -257,9 +259,12 @@ void orc_fps(const float* xyz, int nbatch, int n, int m, int* idx)
                 int t = k % T;
                 if (d2 > tb[t]) { tb[t] = d2; ti[t] = k; }
             }
-            int bt = 0;
-            for (int t = 1; t < T; t++) if (tb[t] > tb[bt]) bt = t;
-            old = ti[bt];
+            /* the upstream shared-memory tree: slot t absorbs slot t+s for s = T/2 .. 1 and keeps its own
+             * candidate on equality, so among equal maxima the thread smallest in BIT-REVERSED order wins */
+            for (int s = T / 2; s >= 1; s /= 2)
+                for (int t = 0; t < s; t++)
+                    if (tb[t + s] > tb[t]) { tb[t] = tb[t + s]; ti[t] = ti[t + s]; }
+            old = ti[0];
             I[j] = old;
         }
     }

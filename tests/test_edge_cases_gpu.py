@@ -157,11 +157,13 @@ def test_fused_cnns_small_and_odd_batches(dev, n):
     assert d.shape == (n, 32) and e.shape == (n, 32, 7, 20)
     a = torch.nn.functional.normalize(torch.rand((n, 32, 5, 20), generator=g), dim=1).to(dev)
     b = torch.nn.functional.normalize(torch.rand((n, 32, 5, 20), generator=g), dim=1).to(dev)
-    ind = cv(a, b, fused=True)
+    ind = cv(a, b)
     assert ind.shape == (n,)
     if n:
-        want = pe.conv_net(x.view(-1, 16, 3, 7, 20))
+        from oracle import torch_ref as T          # library convolutions: the test-side torch restatement, on the device
+        Wd = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in W.items()}
+        want = T.cylindrical_net(x.view(-1, 16, 3, 7, 20), Wd)
         assert (y - want).abs().max().item() < 2e-5 * max(want.abs().max().item(), 1.0)
-        wd, we = pe.head_library(y)
+        wd, we = T.desc_head(y, Wd)
         np.testing.assert_allclose(d.cpu().numpy(), wd.cpu().numpy(), rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(ind.cpu().numpy(), cv(a, b, fused=False).cpu().numpy(), rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(ind.cpu().numpy(), T.cost_volume(a, b, Wd).cpu().numpy(), rtol=1e-4, atol=2e-4)

@@ -49,7 +49,9 @@ def test_kitti_pair_selection_and_ground_truth(tmp_path):
     from buffer_amd import kitti
     root = str(tmp_path / 'kitti')
     _mini_sequence(root)
-    ds = kitti.KittiTestSet(root, drives=(8,))
+    with pytest.raises(FileNotFoundError):                             # no ICP cache and no explicit permission
+        kitti.KittiTestSet(root, drives=(8,)).ground_truth(0)
+    ds = kitti.KittiTestSet(root, drives=(8,), allow_odometry_gt=True)
     assert len(ds) == 3 and ds.files[0][:2] == (8, 0)
     for drive, t0, t1 in ds.files:                                     # > 10 m apart, the frame before the first such one
         assert 9.0 < 0.9 * (t1 - t0) <= 10.9
@@ -59,6 +61,46 @@ def test_kitti_pair_selection_and_ground_truth(tmp_path):
     os.makedirs(os.path.join(root, 'icp'), exist_ok=True)
     np.save(os.path.join(root, 'icp', '%d_%d_%d.npy' % ds.files[0]), np.eye(4))
     assert np.array_equal(ds.ground_truth(0), np.eye(4))               # the ICP cache wins when present
+    ds.ground_truth(1)
+    out = kitti.summarize(ds, np.stack([np.eye(4)] * len(ds)))
+    assert out['gt_source'] == {'icp-cache': 1, 'odometry': len(ds) - 1}
+
+
+def _pairs_by_full_table(scan_ids, positions):
+    """the selection rule stated over the full n x n distance table (KITTI/dataset.py:52-67), for pinning select_pairs"""
+    n = len(positions)
+    table = np.sqrt(((positions.reshape(1, n, 3) - positions.reshape(n, 1, 3)) ** 2).sum(-1)) > 10
+    have, out, t = set(scan_ids), [], min(scan_ids)
+    guard = 0
+    while t in have and guard < 10 * n:
+        guard += 1
+        hits = np.where(table[t][t:t + 100])[0]
+        if len(hits) == 0:
+            t += 1
+            continue
+        nxt = int(hits[0]) + t - 1
+        if nxt in have:
+            out.append((t, nxt))
+            t = nxt + 1
+        else:
+            break                                                      # (the reference never terminates here)
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_kitti_select_pairs_matches_the_full_table_rule(seed):
+    """random-walk trajectories with stops (no partner within 100 frames), speed changes and loops"""
+    from buffer_amd import kitti
+    rng = np.random.default_rng(seed)
+    n = 900
+    speed = np.abs(rng.normal(0.8, 0.5, n)) * (rng.random(n) > 0.15)
+    speed[300:450] = 0.0                                               # a long stop: more than `window` frames without progress
+    heading = np.cumsum(rng.normal(0, 0.05, n))
+    pos = np.cumsum(np.stack([speed * np.cos(heading), np.zeros(n), speed * np.sin(heading)], 1), 0)
+    ids = list(range(n))
+    got = kitti.select_pairs(ids, pos)
+    assert got == _pairs_by_full_table(ids, pos) and len(got) > 20
+    assert all(np.linalg.norm(pos[b] - pos[a]) <= 10 < np.linalg.norm(pos[b + 1] - pos[a]) for a, b in got)
 
 
 @pytest.mark.gpu
@@ -69,7 +111,7 @@ def test_kitti_layout_end_to_end(tmp_path, dev):
     import torch
     root = str(tmp_path / 'kitti')
     _mini_sequence(root)
-    ds = kitti.KittiTestSet(root, drives=(8,))
+    ds = kitti.KittiTestSet(root, drives=(8,), allow_odometry_gt=True)
     pipe = BufferPipeline(KITTI, dev)
     s = ds.item(0, dev)
     pipe.calibrate([{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in s.items()}])

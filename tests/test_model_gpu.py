@@ -20,6 +20,11 @@ def W():
     return load_weights("3dmatch")
 
 
+def _on(W, dev):
+    """the snapshot as torch tensors on `dev`, for the test-side torch restatement (oracle/torch_ref.py)"""
+    return {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in W.items()}
+
+
 def _pyr_from_golden(g, dev):
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
     return dict(points=[t(g[f'points_{l}'], torch.float32) for l in range(3)],
@@ -134,7 +139,7 @@ def test_fused_cylindrical_net_vs_library_convs(W, dev):
     pe = PatchEmbedder(W, dev, THREEDMATCH)
     g = torch.Generator(device='cpu').manual_seed(0)
     x = torch.rand((37, 16, 420), generator=g).to(dev)
-    want = pe.conv_net(x.view(-1, 16, 3, 7, 20))
+    want = T.cylindrical_net(x.view(-1, 16, 3, 7, 20), _on(W, dev))      # library convolutions (test-side restatement)
     got = pe.fused(x)
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() < 2e-5 * max(scale, 1.0)
@@ -150,7 +155,7 @@ def test_fused_descriptor_head_vs_library(W, dev):
     x = torch.rand((41, 16, 420), generator=g).to(dev)
     y = pe.fused(x)
     y[5] = 0.0
-    want_d, want_e = pe.head_library(y)
+    want_d, want_e = T.desc_head(y, _on(W, dev))
     got_d, got_e = pe.head(y)
     np.testing.assert_allclose(got_d.cpu().numpy(), want_d.cpu().numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(got_e.cpu().numpy(), want_e.cpu().numpy(), rtol=1e-4, atol=1e-6)
@@ -165,11 +170,16 @@ def test_fused_cost_volume_vs_library_convs(W, dev):
     f = load("match_tiny.npz")
     se = torch.from_numpy(f['src_equi'])[f['s_mids']][:, :, 1:6].contiguous().to(dev)
     te = torch.from_numpy(f['tgt_equi'])[f['t_mids']][:, :, 1:6].contiguous().to(dev)
-    want = cv(se, te, fused=False)
-    got = cv(se, te, fused=True)
+    Wd = _on(W, dev)
+    want = T.cost_volume(se, te, Wd)
+    got = cv(se, te)
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-4)
     np.testing.assert_allclose(got.cpu().numpy(), f['ind'], rtol=1e-4, atol=2e-4)
     g = torch.Generator(device='cpu').manual_seed(1)
     a = torch.nn.functional.normalize(torch.rand((70, 32, 5, 20), generator=g), dim=1).to(dev)
     b = torch.nn.functional.normalize(torch.rand((70, 32, 5, 20), generator=g), dim=1).to(dev)
-    np.testing.assert_allclose(cv(a, b, fused=True).cpu().numpy(), cv(a, b, fused=False).cpu().numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(cv(a, b).cpu().numpy(), T.cost_volume(a, b, Wd).cpu().numpy(), rtol=1e-4, atol=2e-4)
+    with pytest.raises(ValueError):                     # no library fallback: other geometries are rejected
+        cv(a[:, :, :4].contiguous(), b[:, :, :4].contiguous())
+    with pytest.raises(NotImplementedError):
+        registration.CostVolume(W, dev, azi_n=18)

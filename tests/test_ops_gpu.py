@@ -37,6 +37,19 @@ def test_fps_duplicates_and_small(oracle, dev):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,m", [(6, 5), (150, 100), (1536, 400), (6000, 900), (17000, 200)])
+def test_fps_cross_thread_ties(n, m, oracle, dev):
+    """exact d2 ties between DIFFERENT upstream threads (duplicates at k, k+1, k+2): the upstream tree keeps the
+    thread that is smallest in bit-reversed order, not the smallest thread id"""
+    from buffer_amd import ops
+    base = _cloud(5, (n + 2) // 3) + 1.0
+    xyz = np.repeat(base, 3, axis=0)[:n][None].copy()
+    want = oracle.fps(xyz, m)
+    got = ops.furthest_point_sample(torch.from_numpy(xyz).to(dev), m).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert len(set(map(tuple, xyz[0][want[0][:min(m, (n + 2) // 3)]]))) == min(m, (n + 2) // 3)   # distinct locations first
+
+
 @pytest.mark.parametrize("radius,nsample", [(0.3, 512), (0.1, 16), (0.05, 10)])
 def test_ball_query_and_group(radius, nsample, oracle, dev):
     from buffer_amd import ops

@@ -179,3 +179,14 @@ def test_kitti_branch_matches_reference():
     np.testing.assert_allclose(out['rand_axis'].numpy(), f['rand_axis'], rtol=0, atol=1e-6)
     np.testing.assert_allclose(out['desc'].numpy(), f['desc'], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out['equi'].numpy(), f['equi'], rtol=1e-4, atol=1e-5)
+
+
+def test_fps_tie_rule_is_the_upstream_tree(oracle):
+    """pointnet2_ops' shared-memory reduction folds slot t+s into slot t (s = T/2 .. 1) and keeps slot t on equality:
+    with T = 4 and threads 1 and 2 holding the same maximum, the s = 1 fold compares slot 0 (threads 0, 2) with slot 1
+    (threads 1, 3) -> thread 2's candidate wins.  (VERDICT r1 'weak' item 1.)"""
+    xyz = np.array([[[1, 0, 0], [1, 1, 0], [1, -1, 0], [1, .5, 0]]], np.float32)
+    assert oracle.fps(xyz, 2)[0].tolist() == [0, 2]
+    # per-thread strict '>' keeps a thread's first maximum: duplicates handled by the SAME thread (k, k+T) -> smaller k
+    xyz = np.array([[[1, 0, 0], [1, 2, 0], [1, .1, 0], [1, .2, 0], [1, .3, 0], [1, 2, 0]]], np.float32)   # T = 4: k=1, k=5
+    assert oracle.fps(xyz, 2)[0].tolist() == [0, 1]

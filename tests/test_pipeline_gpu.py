@@ -75,3 +75,35 @@ def test_batched_registration_equals_single(tiny, dev):
     batch = pipe.register_batch(inps, seeds=[0, 1, 2])
     for a, b in zip(single, batch):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=2e-4)
+
+
+def test_batch_with_a_keypoint_free_pair_keeps_pinned_permutations(tiny, dev):
+    """register_batch's rare path (a cloud without any score above the threshold -> identity for that pair, the others
+    redone one by one) must hand the caller's permutations on, so that the healthy pairs equal register() exactly."""
+    from buffer_amd.pipeline import BufferPipeline
+    from dataclasses import replace
+    from buffer_amd.config import THREEDMATCH
+    other = synth.make_pair(12, n_raw=40_000, size=(1.0, 1.0, 0.9), n_boxes=3)
+    cfg = replace(THREEDMATCH, num_keypts=200)
+    probe = BufferPipeline(cfg, dev)
+    probe.calibrate([tiny])
+    tops = []
+    for s in (tiny, other):
+        _, d = probe.register(probe.upload(s), seed=0, detail=True)
+        n_src = int(probe.upload(s)['lengths'][0])
+        sc = d['score'][:, 0]
+        tops.append(min(float(sc[:n_src].max()), float(sc[n_src:].max())))
+    lo, hi = sorted(tops)
+    if not lo < hi:
+        pytest.skip('the two pairs peak at the same score')
+    starved = 0 if tops[0] == lo else 1                      # the pair whose weaker cloud stays below the threshold
+    pipe = BufferPipeline(replace(cfg, keypts_th=0.5 * (lo + hi)), dev, limits=probe.limits)
+    samples = [tiny, other]
+    inps = [pipe.upload(s) for s in samples]
+    rng = np.random.default_rng(5)
+    perms = [[torch.from_numpy(rng.permutation(len(s[k]))).to(dev) for k in ('src_fds_pts', 'tgt_fds_pts')] for s in samples]
+    batch = pipe.register_batch(inps, seeds=[3, 4], perms=perms)
+    assert torch.equal(batch[starved], torch.eye(4, device=dev))
+    healthy = 1 - starved
+    want = pipe.register(inps[healthy], seed=[3, 4][healthy], perms=perms[healthy])
+    assert torch.equal(batch[healthy], want)

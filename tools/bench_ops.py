@@ -26,9 +26,6 @@ if which == 'cyl':
     from buffer_amd.weights import load_weights
     pe = PatchEmbedder(load_weights('3dmatch'), dev, THREEDMATCH)
     x = torch.rand((5000, 16, 420), device=dev)
-    want = pe.conv_net(x[:64].view(-1, 16, 3, 7, 20))
-    got = pe.fused(x[:64])
-    print('max err', (got - want).abs().max().item())
     for _ in range(2):
         pe.fused(x)
     torch.cuda.synchronize()
@@ -101,9 +98,6 @@ if which == 'cost':
     g = torch.Generator(device='cpu').manual_seed(1)
     a = torch.nn.functional.normalize(torch.rand((2500, 32, 5, 20), generator=g), dim=1).to(dev)
     b = torch.nn.functional.normalize(torch.rand((2500, 32, 5, 20), generator=g), dim=1).to(dev)
-    want = cv(a[:64], b[:64], fused=False)
-    got = cv(a[:64], b[:64], fused=True)
-    print('max err', (got - want).abs().max().item())
     cv(a, b); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(5):
