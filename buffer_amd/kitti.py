@@ -6,8 +6,9 @@
     <root>/icp/<drive>_<t0>_<t1>.npy                         ICP-refined ground truth (optional cache)
 
 The reference refines the odometry ground truth with open3d ICP on first use and caches it under icp/
-(dataset.py:95-117); open3d is not available here, so the cached file is required unless --allow-odometry-gt is
-given, and the summary reports how many pairs used which source (`gt_source`).  Host code is file IO and bookkeeping; voxelisation, normals and registration run on the device."""
+(dataset.py:95-117); here the cached file is used when present, otherwise the same ICP refinement runs on the device
+(buffer_amd/icp.py) and fills the cache; --allow-odometry-gt skips the refinement.  The summary reports how many pairs used
+which source (`gt_source`).  Host code is file IO and bookkeeping; voxelisation, normals and registration run on the device."""
 import glob
 import math
 import os
@@ -78,30 +79,46 @@ class KittiTestSet:
     def __len__(self):
         return len(self.files)
 
-    def ground_truth(self, index):
-        """dataset.py:95-117: ICP-refined transform scan t0 -> scan t1 from the reference's cache file.  Without the
-        cache the raw odometry transform is a visibly worse ground truth at the 0.3 m / 1 degree criterion, so it is
-        used only when `allow_odometry_gt` is set, and every pair's source is recorded in `gt_source`."""
+    def scan(self, drive, t):
+        fn = os.path.join(self.pc_path, 'sequences', '%02d' % drive, 'velodyne', '%06d.bin' % t)
+        return np.ascontiguousarray(np.fromfile(fn, dtype=np.float32).reshape(-1, 4)[:, :3])
+
+    def ground_truth(self, index, device=None):
+        """dataset.py:95-117: transform scan t0 -> scan t1.  The reference refines the odometry transform M with
+        point-to-point ICP on the raw scans (threshold 0.20 m, <= 200 iterations), stores `M @ T_icp` under
+        icp/<drive>_<t0>_<t1>.npy and evaluates against that.  Here: the cached file if present; otherwise the same
+        refinement on the device (buffer_amd/icp.py, needs `device`), written to the same cache; the raw odometry
+        transform only with `allow_odometry_gt`.  Every pair's source is recorded in `gt_source`."""
         drive, t0, t1 = self.files[index]
         cached = os.path.join(self.icp_path, '%d_%d_%d.npy' % (drive, t0, t1))
         if os.path.exists(cached):
-            self.gt_source[index] = 'icp-cache'
+            if self.gt_source.get(index) != 'icp-device':             # (a file this object refined itself keeps its label)
+                self.gt_source[index] = 'icp-cache'
             return np.load(cached)
-        if not self.allow_odometry_gt:
-            raise FileNotFoundError(f'{cached} missing: the reference evaluates against ICP-refined poses; pass '
-                                    f'allow_odometry_gt=True (--allow-odometry-gt) to fall back to raw odometry')
-        self.gt_source[index] = 'odometry'
         p0, p1 = (odometry_to_positions(o) for o in self.odometry(drive)[[t0, t1]])
-        return (VELO2CAM @ p0.T @ np.linalg.inv(p1.T) @ np.linalg.inv(VELO2CAM)).T
+        M = (VELO2CAM @ p0.T @ np.linalg.inv(p1.T) @ np.linalg.inv(VELO2CAM)).T
+        if self.allow_odometry_gt:
+            self.gt_source[index] = 'odometry'
+            return M
+        if device is None:
+            raise FileNotFoundError(f'{cached} missing: the reference evaluates against ICP-refined poses; call with a device '
+                                    f'to refine here, or pass allow_odometry_gt=True (--allow-odometry-gt) for raw odometry')
+        from . import icp
+        xyz0 = self.scan(drive, t0).astype(np.float64) @ M[:3, :3].T + M[:3, 3]
+        T_icp, _, _, _ = icp.icp_point_to_point(torch.from_numpy(xyz0.astype(np.float32)).to(device),
+                                                torch.from_numpy(self.scan(drive, t1)).to(device), 0.20, np.eye(4), 200)
+        M2 = M @ T_icp                                                 # the reference's composition order (dataset.py:110)
+        os.makedirs(self.icp_path, exist_ok=True)
+        np.save(cached, M2)
+        self.gt_source[index] = 'icp-device'
+        return M2
 
     def item(self, index, device, seed=None):
         """dataset.py:72-178 (test branch) -> sample dict of device tensors (+ relt_pose)."""
         drive, t0, t1 = self.files[index]
-        out = {'src_id': f'{drive:02d}/{t0:06d}', 'tgt_id': f'{drive:02d}/{t1:06d}', 'relt_pose': self.ground_truth(index)}
+        out = {'src_id': f'{drive:02d}/{t0:06d}', 'tgt_id': f'{drive:02d}/{t1:06d}', 'relt_pose': self.ground_truth(index, device)}
         for side, t in (('src', t0), ('tgt', t1)):
-            fn = os.path.join(self.pc_path, 'sequences', '%02d' % drive, 'velodyne', '%06d.bin' % t)
-            xyz = np.fromfile(fn, dtype=np.float32).reshape(-1, 4)[:, :3]
-            it = preprocess.prepare_fragment(torch.from_numpy(np.ascontiguousarray(xyz)).to(device), self.downsample,
+            it = preprocess.prepare_fragment(torch.from_numpy(self.scan(drive, t)).to(device), self.downsample,
                                              self.voxel_size_0, self.max_num_pts, seed=2 * index + (side == 'tgt') if seed is None else seed)
             out[f'{side}_fds_pts'], out[f'{side}_sds_pts'] = it['fds_pts'], it['sds_pts']
         return out
@@ -130,7 +147,7 @@ def summarize(dataset, poses, rte_thresh=0.3, rre_thresh=1.0):
     src = list(dataset.gt_source.values())
     return dict(pairs=int(st.shape[0]), recall=float(good.mean()) if st.size else 0.0,
                 te=float(st[good, 1].mean()) if good.any() else float('nan'), re=float(st[good, 2].mean()) if good.any() else float('nan'),
-                gt_source={k: src.count(k) for k in ('icp-cache', 'odometry')})
+                gt_source={k: src.count(k) for k in ('icp-cache', 'icp-device', 'odometry')})
 
 
 def main(argv=None):
@@ -149,7 +166,7 @@ def main(argv=None):
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--limits', default=None)
     ap.add_argument('--allow-odometry-gt', action='store_true',
-                    help='evaluate against raw odometry where <root>/icp/<drive>_<t0>_<t1>.npy is missing (lowers recall)')
+                    help='evaluate against raw odometry instead of refining it by ICP where <root>/icp/<drive>_<t0>_<t1>.npy is missing')
     a = ap.parse_args(argv)
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('WORLD_SIZE', 1), ('LOCAL_RANK', 0)))
     torch.cuda.set_device(local)

@@ -63,7 +63,7 @@ def test_kitti_pair_selection_and_ground_truth(tmp_path):
     assert np.array_equal(ds.ground_truth(0), np.eye(4))               # the ICP cache wins when present
     ds.ground_truth(1)
     out = kitti.summarize(ds, np.stack([np.eye(4)] * len(ds)))
-    assert out['gt_source'] == {'icp-cache': 1, 'odometry': len(ds) - 1}
+    assert out['gt_source'] == {'icp-cache': 1, 'icp-device': 0, 'odometry': len(ds) - 1}
 
 
 def _pairs_by_full_table(scan_ids, positions):
@@ -111,7 +111,7 @@ def test_kitti_layout_end_to_end(tmp_path, dev):
     import torch
     root = str(tmp_path / 'kitti')
     _mini_sequence(root)
-    ds = kitti.KittiTestSet(root, drives=(8,), allow_odometry_gt=True)
+    ds = kitti.KittiTestSet(root, drives=(8,))                         # no cache: ground truth refined by ICP on the device
     pipe = BufferPipeline(KITTI, dev)
     s = ds.item(0, dev)
     pipe.calibrate([{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in s.items()}])
@@ -119,3 +119,11 @@ def test_kitti_layout_end_to_end(tmp_path, dev):
     out = kitti.summarize(ds, poses, rte_thresh=0.6, rre_thresh=2.0)
     # a driver test, not a model-quality test: the synthetic street is far sparser than a real scan
     assert out['pairs'] == 3 and out['recall'] >= 2 / 3 and out['te'] < 0.3 and out['re'] < 1.5, out
+    assert out['gt_source']['icp-device'] + out['gt_source']['icp-cache'] == 3 and out['gt_source']['odometry'] == 0
+    # the refinement stays close to the (exact, synthetic) odometry transform and is read back from the cache afterwards
+    odo = kitti.KittiTestSet(root, drives=(8,), allow_odometry_gt=True)
+    os.rename(os.path.join(root, 'icp'), os.path.join(root, 'icp_kept'))
+    for i in range(3):
+        M = odo.ground_truth(i)
+        M2 = np.load(os.path.join(root, 'icp_kept', '%d_%d_%d.npy' % ds.files[i]))
+        assert np.abs(M2[:3, 3] - M[:3, 3]).max() < 0.1 and np.abs(M2[:3, :3] - M[:3, :3]).max() < 5e-3

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import torch_ref as T  # noqa: E402  (test-side torch restatement)
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
