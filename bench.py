@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """Registration throughput of the MI355X-native BUFFER inference path (BASELINE.json metric:
-registration pairs/sec; workload = configs[1], one 3DMatch-shape fragment pair, full inference, fp32).
+registration pairs/sec; default workload = configs[1], one 3DMatch-shape fragment pair, full inference, fp32,
+~5k keypoints per fragment).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step registers `--pairs-per-step` device-resident synthetic pairs on every rank through ONE set of
-stacked launches per stage (`--mode batch`; `--mode threads` runs them on separate streams instead).
-Pairs are sharded over the ranks with no data-path collective; one all_gather of the poses ends the
-timed region.  Rank 0 prints
-one JSON line (contract in the task description): whole-job pairs/s, the roofline of the dominant
-hand-written kernel (k_grid_query, timed with HIP events on its launch stream inside the library)
-and, at N=1, the CPU baseline (reference cpp_wrappers cores when oracle/_ref is built, else the
-plain-C port, + the torch-CPU restatement of the model stages) timed on the host cores.
+A step registers `--pairs-per-step` device-resident synthetic pairs on every rank through ONE set of stacked launches
+per stage.  Pairs are sharded over the ranks with no data-path collective; one all_gather of the poses ends the timed
+region (barrier + synchronize on both sides, max over ranks).  Rank 0 prints ONE JSON line: whole-job pairs/s, the
+`roofline` object of the dominant hand-written kernel (k_cyl_net; HIP events on its launch stream inside the library),
+`roofline_other` for every other kernel SURVEY 8(d) assigns a roofline class to, and, at N=1, `cpu_baseline`: the
+reference's cpp_wrappers cores (oracle/_ref) + the torch-CPU restatement of the model timed on this box's host cores on
+the SAME pair at the SAME keypoint count (no extrapolation).
+
+Other workloads (each prints its own line with the same metric; they are not the headline):
+  --workload stream   BASELINE configs[2]: 1623 synthetic pairs from RAW clouds, pre-processing included, with DGR recall + RR
+  --workload kitti    BASELINE configs[3]: KITTI-shape ring scans (~120k returns, 0.05 / 0.30 m voxels), KITTI constants
 """
 import argparse
 import ctypes as C
@@ -30,8 +34,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 COST_NET_FLOPS_PER_MATCH = 159994880.0   # csrc/costnet.hip (0.160 GFLOP/match)
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32), 64 FLOP/clk/SIMD
+CYL_NET_SKIPPED_FRACTION = 0.0679        # share of the dense (algorithmic) FLOPs k_cyl_net does not execute: 6 of 81
+#                                          (tap, tile) pairs read only zero elevation padding
+
+# library timing ids (include/buffer_hip.h BUF_TIMED_*)
+TIMED = {'grid_query': 0, 'cyl_net': 1, 'cost_net': 2, 'select_patches': 3, 'patch_voxelize': 4, 'fps': 5, 'nn1': 6,
+         'vn_gather': 7, 'grid_subsample': 8, 'desc_head': 9}
 
 
 def parse():
@@ -39,45 +49,136 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--keypts', type=int, default=5000, help='keypoints per fragment (BASELINE: ~5k)')
-    ap.add_argument('--pairs-per-step', type=int, default=32, help='pairs registered per GPU and step')
-    ap.add_argument('--mode', choices=['batch', 'threads'], default='batch',
-                    help='batch: the pairs of a step share one set of stacked launches; threads: one stream per pair')
+    ap.add_argument('--workload', choices=['pair', 'stream', 'kitti'], default='pair')
+    ap.add_argument('--keypts', type=int, default=None,
+                    help='keypoints per fragment (pair: 5000 = BASELINE; stream / kitti: 1500 = the reference configs)')
+    ap.add_argument('--pairs-per-step', type=int, default=None, help='pairs registered per GPU and step (pair: 32, kitti: 16)')
     ap.add_argument('--streams', type=int, default=1,
-                    help='batch mode: the pairs of a step are split into this many stacked batches, one host thread + HIP '
-                         'stream each, so that the latency-bound FPS of one batch overlaps the CNN kernels of another')
+                    help='the pairs of a step are split into this many stacked batches, one host thread + HIP stream each')
     ap.add_argument('--distinct-pairs', type=int, default=4, help='synthetic pairs generated per rank (cycled)')
+    ap.add_argument('--stream-pairs', type=int, default=1623)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-keypts', type=int, default=256, help='keypoint sample of the CPU baseline leg')
     return ap.parse_args()
 
 
-def cpu_baseline(sample, cfg, limits, keypts_full, keypts_sample):
-    """One pair through the CPU path on this box's host cores.  The descriptor/matching stages run on
-    a `keypts_sample`-keypoint sample and are scaled linearly to `keypts_full` (they are linear in the
-    number of patches / matches); pyramid, point learner and FPS run in full."""
-    from oracle import cpu, pipeline_ref
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(sample, cfg, limits):
+    """The CPU path on THIS box's host cores, one pair, full size (no sampling of keypoints, nothing extrapolated):
+    pyramid = the reference's cpp_wrappers cores (oracle/_ref, kind 'reference'; the plain-C port where that library was
+    not built) on min(16, nproc) concurrent workers like the reference's DataLoader (ThreeDMatch/config.py:22), each
+    building the pyramid of one pair; model stages = torch-CPU restatement on all threads.  Baseline only."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import cpu, pipeline_ref, torch_ref
     from buffer_amd.weights import load_weights
     cpu.build(ref=True)
     use_ref = cpu.have_ref()
     W = {k: torch.from_numpy(v) for k, v in load_weights(cfg.weights).items()}
     rng = np.random.default_rng(0)
     perms = [rng.permutation(len(sample['src_fds_pts'])), rng.permutation(len(sample['tgt_fds_pts']))]
+    workers = min(16, os.cpu_count() or 1)
+
+    def pyramid(_):
+        return torch_ref.collate(sample, limits, cfg.voxel_size_0, cfg.conv_radius, use_ref)
+
+    pyramid(0)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(workers) as ex:        # ctypes releases the GIL: the KD-tree / grid cores run truly concurrently
+        list(ex.map(pyramid, range(workers)))
+    t_pyr = (time.perf_counter() - t0) / workers   # seconds per pair at `workers` loaders
     tm = {}
     t0 = time.perf_counter()
-    pipeline_ref.register_pair(sample, W, limits, cfg, 0, perms, num_keypts=keypts_sample, use_ref=use_ref, timings=tm)
+    pipeline_ref.register_pair(sample, W, limits, cfg, 0, perms, use_ref=use_ref, timings=tm)
     wall = time.perf_counter() - t0
-    scale = keypts_full / keypts_sample
-    # FPS is run for keypts_sample rounds only: scale it too (rounds are identical work)
-    est = tm['pyramid'] + tm['point_learner'] + (tm['keypoints'] + tm['descriptors'] + tm['matching']) * scale + tm['pose']
-    return dict(value=1.0 / est, unit='pairs/s', cores=torch.get_num_threads(),
+    t_model = sum(v for k, v in tm.items() if k != 'pyramid')
+    # the reference overlaps its loader workers with the model process: steady-state rate = the slower of the two legs
+    return dict(value=1.0 / max(t_pyr, t_model), unit='pairs/s', cores=torch.get_num_threads(), workers=workers,
                 kind='reference' if use_ref else 'port',
-                sample=f'1 pair: pyramid (cpp_wrappers cores, 1 thread) + point learner in full; FPS/descriptor/matching '
-                       f'stages on {keypts_sample} of {keypts_full} keypoints per fragment, scaled x{scale:.1f}; '
-                       f'torch-CPU {torch.get_num_threads()} threads; measured {wall:.1f} s',
-                stages_s={k: round(v, 3) for k, v in tm.items()})
+                sample=f'1 pair of the timed workload at full size ({cfg.num_keypts} keypoints per fragment, nothing scaled): '
+                       f'pyramid by the {"reference cpp_wrappers cores" if use_ref else "plain-C port"} on {workers} concurrent '
+                       f'workers ({t_pyr * 1e3:.1f} ms per pair), model stages on torch-CPU with {torch.get_num_threads()} threads '
+                       f'({t_model:.1f} s per pair; {wall:.1f} s measured); value = 1 / max(loader leg, model leg)',
+                stages_s={k: round(v, 3) for k, v in tm.items()}, pyramid_s_per_pair_at_workers=round(t_pyr, 4))
 
 
+# ------------------------------------------------------------------------------------------------ helpers
+def collect_timed(L):
+    out = {}
+    for name, kid in TIMED.items():
+        ms, work = C.c_double(0), C.c_double(0)
+        n = L.buf_timing_collect_kernel(kid, C.byref(ms), C.byref(work))
+        out[name] = (int(n), ms.value, work.value)
+    return out
+
+
+def load_traffic():
+    p = os.path.join(ROOT, 'profiles', 'traffic.json')
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+def roof_entry(timed, name, label, bound, peak, unit, scale, traffic=None, **extra):
+    n, ms, work = timed[name]
+    if not n:
+        return None
+    ach = (work / n) / (ms / n * 1e-3) / scale
+    e = {'kernel': label, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak, 'traffic': traffic,
+         'launches': n, 'avg_us': ms / n * 1e3, 'avg_algorithmic_' + ('bytes' if unit == 'GB/s' else 'flops'): work / n}
+    e.update(extra)
+    return e
+
+
+def traffic_of(pmc, kernel, units):
+    """HBM bytes per launch from the committed PMC summary (profiles/traffic.json: bytes per unit of work, measured with
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes and the gfx950 FETCH correction) x the units of this run's launch."""
+    k = pmc.get('kernels', {}).get(kernel)
+    return k['hbm_bytes_per_unit'] * units if k and units else None
+
+
+def rooflines(timed, pmc, fps_bytes_per_launch, units):
+    """`roofline` (dominant kernel) + `roofline_other` (every other kernel with a roofline class in SURVEY 8d)."""
+    main = roof_entry(timed, 'cyl_net', 'k_cyl_net (A11 Cylindrical_Net, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
+                      traffic_of(pmc, 'k_cyl_net', units.get('patches')),
+                      flops='dense algorithmic count (SURVEY 8d: 0.1187 GFLOP/patch); the kernel skips the (tap, tile) pairs '
+                            'that only read zero elevation padding', executed_fraction_of_dense=1 - CYL_NET_SKIPPED_FRACTION)
+    matches = timed['cost_net'][2] / max(timed['cost_net'][0], 1) / COST_NET_FLOPS_PER_MATCH
+    other = [
+        roof_entry(timed, 'cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
+                   traffic_of(pmc, 'k_cost_net', matches),
+                   flops='dense algorithmic count (SURVEY 8d: 0.160 GFLOP/match)'),
+        roof_entry(timed, 'grid_query', 'k_grid_query_wave (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                   traffic_of(pmc, 'k_grid_query_wave', units.get('pairs'))),
+        roof_entry(timed, 'grid_subsample', 'k_vox_* + scan + k_cell_scatter (A1 grid subsample, whole call)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9),
+        roof_entry(timed, 'vn_gather', 'k_vn_gather (A4 fused VN neighbour block)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                   traffic_of(pmc, 'k_vn_gather', units.get('pairs'))),
+        roof_entry(timed, 'select_patches', 'k_select_patches (A8 ball query + grouping)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                   traffic_of(pmc, 'k_select_patches', units.get('patches_per_select'))),
+        roof_entry(timed, 'patch_voxelize', 'k_patch_voxelize (A9 + A10 + point MLP)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                   traffic_of(pmc, 'k_patch_voxelize', units.get('patches'))),
+        roof_entry(timed, 'desc_head', 'k_desc_head (A11 attention pooling + normalisation)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                   traffic_of(pmc, 'k_desc_head', units.get('patches'))),
+        roof_entry(timed, 'nn1', 'k_nn1 (A12 mutual 1-NN, exact fp32 VALU)', 'valu', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12),
+    ]
+    n, ms, rounds = timed['fps']
+    if n:
+        by = fps_bytes_per_launch
+        other.append({'kernel': 'k_fps (A6 furthest point sampling)', 'bound': 'latency', 'launches': n, 'avg_us': ms / n * 1e3,
+                      'rounds_per_launch': rounds / n, 'us_per_round': ms / rounds * 1e3,
+                      'achieved': by / (ms / n * 1e-3) / 1e9 if by else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': by / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if by else None, 'traffic': None,
+                      'avg_algorithmic_bytes': by})
+    return main, [e for e in other if e]
+
+
+def dgr_ok(poses, gts):
+    ok = 0
+    for pose, gt in zip(poses, gts):
+        T = np.asarray(pose, np.float64)
+        rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
+        rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+        ok += int(rte < 0.3 and rre < 15)
+    return ok
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -99,11 +200,11 @@ def main():
                          f'--nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port <P> bench.py --gpus {a.gpus} ...')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
-    local = local % torch.cuda.device_count()      # (only matters for the single-GPU gloo smoke run below)
+    local = local % torch.cuda.device_count()      # (only matters for the single-GPU gloo run of the N>1 logic, see tests)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    backend = os.environ.get('BENCH_BACKEND', 'nccl')   # 'gloo' = code-path smoke test of the N>1 logic on one GPU
+    backend = os.environ.get('BENCH_BACKEND', 'nccl')   # 'gloo' = the N>1 code path on one GPU (tests/test_bench_contract_gpu.py)
     if world > 1:
         import torch.distributed as dist
         if backend == 'nccl':
@@ -113,22 +214,27 @@ def main():
     cdev = dev if backend == 'nccl' else torch.device('cpu')
 
     from buffer_amd import _lib, synth
-    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.config import KITTI, THREEDMATCH
     from buffer_amd.pipeline import BufferPipeline
-    cfg = replace(THREEDMATCH, num_keypts=a.keypts)
+    L = _lib.lib()
+    if a.workload == 'stream':
+        return run_stream(a, rank, world, dev, cdev, dist, L)
+    kitti = a.workload == 'kitti'
+    keypts = a.keypts or (1500 if kitti else 5000)
+    pps = a.pairs_per_step or (16 if kitti else 32)
+    cfg = replace(KITTI if kitti else THREEDMATCH, num_keypts=keypts)
+    make = synth.make_kitti_pair if kitti else synth.make_pair
     pipe = BufferPipeline(cfg, dev)
-    calib = synth.make_pair(1000)                     # same calibration pair on every rank -> identical limits
+    calib = make(1000)                                # same calibration pair on every rank -> identical limits
     limits = pipe.calibrate([calib])
-    samples = [synth.make_pair(2000 + rank * 97 + i) for i in range(a.distinct_pairs)]
+    samples = [make(2000 + rank * 97 + i) for i in range(a.distinct_pairs)]
     inputs = [pipe.upload(s) for s in samples]
     torch.cuda.synchronize()
-    L = _lib.lib()
 
-    # pairs of one step run concurrently, one host thread + one HIP stream each: the latency-bound stages of
-    # one pair (FPS occupies 2 CUs for milliseconds) overlap the chip-filling stages of another
+    # optional: the pairs of a step split over several stacked batches, one host thread + HIP stream each
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    nconc = max(1, a.pairs_per_step) if a.mode == 'threads' else max(1, min(a.streams, a.pairs_per_step))
+    nconc = max(1, min(a.streams, pps))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nconc)]
     tls = threading.local()
     slot_lock = threading.Lock()
@@ -141,10 +247,6 @@ def main():
             torch.cuda.set_device(local)
         return streams[tls.slot]
 
-    def one_pair(k):
-        with torch.cuda.stream(_bind()):
-            return pipe.register(inputs[k], seed=k)
-
     def one_batch(ks):
         with torch.cuda.stream(_bind()):
             return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
@@ -152,19 +254,15 @@ def main():
     pool = ThreadPoolExecutor(max_workers=nconc) if nconc > 1 else None
 
     def step(i):
-        ks = [(i * a.pairs_per_step + j) % len(inputs) for j in range(a.pairs_per_step)]
-        if a.mode == 'batch':
-            if pool is None:
-                return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
-            parts = [ks[j::nconc] for j in range(nconc)]
-            outs = list(pool.map(one_batch, parts))
-            poses = [None] * len(ks)
-            for j, o in enumerate(outs):
-                poses[j::nconc] = o
-            return poses
+        ks = [(i * pps + j) % len(inputs) for j in range(pps)]
         if pool is None:
-            return [pipe.register(inputs[k], seed=k) for k in ks]
-        return list(pool.map(one_pair, ks))
+            return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
+        parts = [ks[j::nconc] for j in range(nconc)]
+        outs = list(pool.map(one_batch, parts))
+        poses = [None] * len(ks)
+        for j, o in enumerate(outs):
+            poses[j::nconc] = o
+        return poses
 
     for i in range(a.warmup):
         step(i)
@@ -177,6 +275,7 @@ def main():
     for i in range(a.steps):
         all_poses += step(i)
     mine = torch.stack(all_poses).to(cdev)
+    gathered = None
     if dist:                                           # the path's one exchange: poses of every shard
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -185,69 +284,99 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     L.buf_timing_enable(0)
-    timed = {}
-    for kid, name in ((0, 'grid_query'), (1, 'cyl_net'), (2, 'cost_net')):
-        ms, work = C.c_double(0), C.c_double(0)
-        n = L.buf_timing_collect_kernel(kid, C.byref(ms), C.byref(work))
-        timed[name] = (int(n), ms.value, work.value)
+    timed = collect_timed(L)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # registration quality on this rank's pairs (DGR criterion of ThreeDMatch/test.py:264-270)
-    ok = 0
-    for n, pose in enumerate(all_poses):
-        gt = samples[n % len(samples)]['relt_pose']
-        T = pose.cpu().numpy().astype(np.float64)
-        rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
-        rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
-        ok += int(rte < 0.3 and rre < 15)
+    gts = [samples[n % len(samples)]['relt_pose'] for n in range(len(all_poses))]
+    ok = dgr_ok(mine.cpu().numpy(), gts)
 
     if rank == 0:
-        pairs = world * a.steps * a.pairs_per_step
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        pmc = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        per_launch = a.pairs_per_step / nconc if a.mode == 'batch' else 1      # pairs covered by one launch
-
-        def roof(name, label, bound, peak, unit, scale, traffic):
-            n, ms, work = timed[name]
-            ach = (work / n) / (ms / n * 1e-3) / scale if n else 0.0
-            return {'kernel': label, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit, 'frac': ach / peak,
-                    'traffic': traffic, 'launches': n, 'avg_us': (ms / n * 1e3) if n else None,
-                    'avg_algorithmic_' + ('bytes' if bound == 'hbm' else 'flops'): (work / n) if n else None}
-
-        # HBM bytes per launch measured offline with rocprofv3 --pmc (profiles/traffic.json, separate passes)
-        t_cyl = pmc.get('k_cyl_net_hbm_bytes_per_patch')
-        t_cost = pmc.get('k_cost_net_hbm_bytes_per_match')
-        t_grid = pmc.get('k_grid_query_hbm_bytes_per_launch_per_pair')
-        npatch = 2 * a.keypts * per_launch
-        gpu_ms = {k: v[1] / a.steps for k, v in timed.items()}
+        pairs = world * a.steps * pps
+        per_launch = pps / nconc                                          # pairs covered by one stacked launch
+        pmc = load_traffic()
+        n_sel = timed['select_patches'][0]
+        units = {'pairs': per_launch, 'patches': 2 * keypts * per_launch,
+                 'patches_per_select': 2 * keypts * pps * a.steps / n_sel if n_sel else None}
+        # A6 bytes: 12 N' + 4 P per cloud; N' (points above the score threshold) <= the sds cloud sizes
+        fps_bytes = (sum(12.0 * int(x) for inp in inputs for x in inp['lengths']) / len(inputs) + 8.0 * keypts) * per_launch
+        main_roof, other = rooflines(timed, pmc, fps_bytes, units)
+        label = ('KITTI-shape scan pair (~120k returns per scan, 0.05 / 0.30 m voxels, KITTI constants), full BUFFER inference '
+                 '(BASELINE configs[3])') if kitti else 'one 3DMatch-shape fragment pair, full BUFFER inference (BASELINE configs[1])'
         out = {
             'metric': 'registration pairs/sec', 'value': pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'one 3DMatch-shape fragment pair, full BUFFER inference (BASELINE configs[1])',
-                       'pairs_per_step_per_gpu': a.pairs_per_step, 'step_mode': a.mode, 'streams': nconc, 'keypoints_per_fragment': a.keypts,
-                       'fds_points': [int(s['src_fds_pts'].shape[0]) for s in samples[:1]]
-                       + [int(s['tgt_fds_pts'].shape[0]) for s in samples[:1]],
+            'config': {'workload': label, 'pairs_per_step_per_gpu': pps, 'streams': nconc, 'keypoints_per_fragment': keypts,
+                       'fds_points': [int(samples[0]['src_fds_pts'].shape[0]), int(samples[0]['tgt_fds_pts'].shape[0])],
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,
-                       'weights': '3DMatch 06132318 (released)', 'parallelism': f'pair-sharded x{world}',
-                       'registered_ok': f'{ok}/{len(all_poses)} (rank 0, RTE<0.3 m & RRE<15 deg)'},
-            # the dominant kernel of the step (k_cyl_net: ~60 % of the GPU time, profiles/r01_kernel_stats.csv)
-            'roofline': roof('cyl_net', 'k_cyl_net (A11 Cylindrical_Net, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s',
-                             1e12, t_cyl * npatch if t_cyl else None),
-            'roofline_other': [
-                roof('cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s',
-                     1e12, t_cost * timed['cost_net'][2] / max(timed['cost_net'][0], 1) / COST_NET_FLOPS_PER_MATCH if t_cost else None),
-                roof('grid_query', 'k_grid_query (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
-                     t_grid * per_launch if t_grid else None)],
-            'timed_kernel_ms_per_step': gpu_ms,
+                       'weights': ('KITTI 06050001' if kitti else '3DMatch 06132318') + ' (released)', 'parallelism': f'pair-sharded x{world}',
+                       'registered_ok': f'{ok}/{len(all_poses)} (rank 0, RTE<0.3 m & RRE<15 deg)',
+                       'gathered_poses': [int(g.shape[0]) for g in gathered] if gathered else None},
+            'roofline': main_roof, 'roofline_other': other,
+            'timed_kernel_ms_per_step': {k: v[1] / a.steps for k, v in timed.items() if v[0]},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits, a.keypts, a.cpu_keypts)
+            out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits)
         print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def run_stream(a, rank, world, dev, cdev, dist, L):
+    """BASELINE configs[2]: `--stream-pairs` synthetic pairs (a quarter at 0.3 overlap) from RAW device-resident clouds:
+    voxelisation x2 + normals + registration inside the timed region; pair i -> rank i mod W; one all_gather of poses."""
+    from buffer_amd import dist as bdist, stream, synth
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.pipeline import BufferPipeline
+    from buffer_amd.threedmatch import upload
+    cfg = replace(THREEDMATCH, num_keypts=a.keypts or 1500)
+    pipe = BufferPipeline(cfg, dev)
+    n = a.stream_pairs
+    ids = list(bdist.shard_indices(n, rank, world))
+    mine = [synth.make_raw_pair_device(20000 + i, stream.OVERLAPS[i % len(stream.OVERLAPS)], dev) for i in ids]
+    first = stream.prepare(synth.make_raw_pair_device(20000, stream.OVERLAPS[0], dev), cfg, 0)     # same pair on every rank
+    limits = pipe.calibrate([{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in first.items()}])
+    batch = a.pairs_per_step or 16
+    stream.run(pipe, mine[:batch], batch)                                                           # warm-up
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    L.buf_timing_enable(1)
+    t0 = time.perf_counter()
+    poses = []
+    for lo in range(0, len(ids), batch):
+        chunk = range(lo, min(lo + batch, len(ids)))
+        inps = [upload(stream.prepare(mine[j], cfg, ids[j])) for j in chunk]
+        poses += pipe.register_batch(inps, seeds=[ids[j] for j in chunk])
+    local_poses = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
+    if world > 1:
+        bdist.gather_poses(ids, local_poses, n, device=cdev)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.buf_timing_enable(0)
+    timed = collect_timed(L)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        quality = stream.evaluate_stream(mine, local_poses.cpu().numpy())          # (N > 1: rank 0 scores its own shard)
+        quality['scored'] = f'{len(ids)} pairs' + (' (rank 0 shard)' if world > 1 else '')
+        main_roof, other = rooflines(timed, load_traffic(), None, {})
+        print(json.dumps({
+            'metric': 'registration pairs/sec', 'value': n / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': 1, 'warmup': 0,
+            'ms_per_step': elapsed * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'{n} synthetic 3DMatch-shape pairs streamed from raw clouds, pre-processing included '
+                                   f'(BASELINE configs[2]); overlaps {list(stream.OVERLAPS)} in equal shares',
+                       'keypoints_per_fragment': cfg.num_keypts, 'pairs_per_launch': batch, 'neighbor_limits': limits,
+                       'parallelism': f'pair-sharded x{world}'},
+            'quality': quality, 'roofline': main_roof, 'roofline_other': other}), flush=True)
     if dist:
         dist.destroy_process_group()
 

@@ -302,7 +302,10 @@ extern "C" int buf_descriptor_head(const float* y, int npatch, const float* para
     BUF_REQUIRE(npatch >= 0, BUF_EINVAL, "buf_descriptor_head: npatch=%d", npatch);
     if (npatch == 0) return BUF_OK;
     BUF_REQUIRE(y && params && desc && equi, BUF_EINVAL, "buf_descriptor_head: null argument");
+    TimedSpan span;
+    bool timed = timing_begin((hipStream_t)stream, &span, (2.0 * DH_C * CN_POS * 4 + 4.0 * DH_C) * npatch, BUF_TIMED_DESC_HEAD);
     k_desc_head<<<npatch, DH_THREADS, 0, (hipStream_t)stream>>>(y, params, desc, equi);
+    if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

@@ -206,6 +206,8 @@ extern "C" int buf_fps_ragged(const float* xyz, const int* lengths_host, int b, 
             nmax = n > nmax ? n : nmax;
         }
         int* out = idx_out + (size_t)c0 * m;
+        TimedSpan span;
+        bool timed = timing_begin(s, &span, (double)m, BUF_TIMED_FPS);            // work = rounds; bytes follow from the lengths
         // <= 12800 points: an xyz copy in LDS serves the winner lookup (one broadcast ds_read instead of an L2 round trip)
         const size_t lds = sizeof(float) * 3 * (size_t)nmax;
 #define FPS_LAUNCH(TH, PPT_, L) \
@@ -221,6 +223,7 @@ extern "C" int buf_fps_ragged(const float* xyz, const int* lengths_host, int b, 
             BUF_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)row, BUF_EWORKSPACE, "buf_fps: workspace too small");
             k_fps_global<<<nb, FPS_THREADS, 0, s>>>(xyz, B, m, (float*)ws, out);
         }
+        if (timed) timing_end(s, &span);
         row0 = row;
     }
     BUF_LAUNCH_CHECK();
@@ -380,7 +383,10 @@ extern "C" int buf_select_patches(const float* pts, const float* kpts, int n, in
     if (m == 0) return BUF_OK;
     BUF_REQUIRE(kpts && patches && (n == 0 || pts), BUF_EINVAL, "buf_select_patches: null argument");
     float r2 = radius * radius;
+    TimedSpan span;
+    bool timed = timing_begin((hipStream_t)stream, &span, 12.0 * n + 12.0 * m + 12.0 * m * nsample, BUF_TIMED_SELECT_PATCHES);
     k_select_patches<<<cdiv(m, BQ_WAVES), BQ_WAVES * WAVE, 0, (hipStream_t)stream>>>(pts, kpts, n, m, r2, nsample, patches);
+    if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
@@ -557,7 +563,10 @@ extern "C" int buf_knn(const float* ref, const float* query, int b, int n, int n
         unsigned long long* best = (unsigned long long*)ws;
         BUF_CHECK_HIP(hipMemsetAsync(best, 0xff, sizeof(unsigned long long) * (size_t)b * nq, s));
         dim3 g1(cdiv(nq, WAVE), cdiv(n, NN1_SPLIT), b);
+        TimedSpan span;
+        bool timed = timing_begin(s, &span, 2.0 * b * nq * (double)n * 32, BUF_TIMED_NN1);
         k_nn1<32><<<g1, 256, 0, s>>>(ref, query, n, nq, best);
+        if (timed) timing_end(s, &span);
         long long total = (long long)b * nq;
         k_nn1_finish<<<cdiv(total, 256), 256, 0, s>>>(best, total, dist, idx);
         BUF_LAUNCH_CHECK();

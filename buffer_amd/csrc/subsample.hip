@@ -257,6 +257,8 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
         *out_m_host = 0;
         return BUF_OK;
     }
+    TimedSpan span;      // the whole kernel sequence of one call (bbox .. emit); M is bounded by N in the byte count
+    bool timed = timing_begin(s, &span, 24.0 * n + 4.0 * nb, BUF_TIMED_GRID_SUBSAMPLE);
     BUF_CHECK_HIP(hipMemsetAsync(v.table, 0, sizeof(int) * (size_t)max_cells, s));
     k_vox_bbox<<<nb, 1024, 0, s>>>(pts, v.off, v.grids, dl);
     k_vox_offsets<<<1, 1, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
@@ -273,6 +275,7 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     float* fdst = max_p > 0 ? v.feat_tmp : out_feats;
     k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.key_sorted, v.cell_sorted, v.head, n, v.st, dst, fdim > 0 ? feats : nullptr, fdim, fdst);
     k_vox_counts<<<cdiv(nb + 1, 64), 64, 0, s>>>(v.head, v.off, nb, n, 0, v.total, v.st, v.counts);
+    if (timed) timing_end(s, &span);
     BUF_LAUNCH_CHECK();
     int stackc[66];
     int* hc = nb + 2 <= 66 ? stackc : (int*)malloc(sizeof(int) * ((size_t)nb + 2));

@@ -220,9 +220,12 @@ extern "C" int buf_vn_gather_block(const float* q_pts, const float* s_pts, const
     int cinp = cin + (mode == 6 ? 3 : 1);
     size_t lds = sizeof(float) * 2 * (size_t)cout * cinp;
     long long total = (long long)nq * cout;
+    TimedSpan span;
+    bool timed = timing_begin((hipStream_t)stream, &span, 4.0 * nq * k + 12.0 * nq + 12.0 * nq * cin + 12.0 * nq * cout, BUF_TIMED_VN_GATHER);
     k_vn_gather<<<cdiv(total, 256), 256, lds, (hipStream_t)stream>>>(q_pts, s_pts, feats, idx, nq, ns, k, cin, cout,
                                                                    mode == 6 ? 1 : 0, scale,
                                                                    make_params(wf, wd, bn_scale, bn_shift, slope), out);
+    if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

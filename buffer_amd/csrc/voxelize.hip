@@ -267,9 +267,12 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
     static LdsGrant grant;
     if (lds > 48 * 1024)
         if (int rc = grant_dynamic_lds((const void*)k_patch_voxelize, lds, grant)) return rc;
+    TimedSpan span;
+    bool timed = timing_begin((hipStream_t)stream, &span, 12.0 * npatch * npts + 4.0 * npatch * VOX_CH * ncentres, BUF_TIMED_PATCH_VOXELIZE);
     k_patch_voxelize<<<npatch, VOX_THREADS, lds, (hipStream_t)stream>>>(patches, axis, npts, des_r, centres, ncentres, azi_n,
                                                                       azi_cs, voxel_r * voxel_r, nsample, M, hdr, tab, out_x,
                                                                       out_R, out_rand, out_patches);
+    if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

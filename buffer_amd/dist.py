@@ -2,8 +2,27 @@
 (one process per GPU, interleaved i -> rank i mod W to balance scenes of unequal size) with no
 data-path collective; the only exchange is ONE all_gather of the per-pair poses (+ pair ids) at the
 end -- RCCL over xGMI on the GPU box (backend 'nccl'), gloo in the CPU tests."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def init(local_rank):
+    """One process per GPU under torchrun: -> (rank, world, device, comm_device).  Backend 'nccl' (= RCCL over xGMI) unless
+    BUFFER_DIST_BACKEND=gloo, which runs the same sharding / gather logic with host tensors (several ranks may then share
+    one GPU: the CPU-side tests of the N > 1 path)."""
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    backend = os.environ.get('BUFFER_DIST_BACKEND', 'nccl')
+    local = local_rank % max(torch.cuda.device_count(), 1) if backend == 'gloo' else local_rank
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, dev, (dev if backend == 'nccl' else torch.device('cpu'))
 
 
 def shard_indices(n_pairs, rank, world):

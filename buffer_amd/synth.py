@@ -205,3 +205,56 @@ def make_kitti_pair(seed, beams=64, az_steps=1900, fds_voxel=0.05, sds_voxel=0.3
     out['src_id'] = f'kitti_synth/{seed}_0'
     out['tgt_id'] = f'kitti_synth/{seed}_1'
     return out
+
+
+def make_raw_pair_device(seed, overlap, device, n_raw=250_000, size=(1.9, 1.9, 1.7), n_boxes=5, jitter=0.003):
+    """A fragment pair as RAW (un-voxelised) clouds in device memory: what a 3DMatch .ply holds before
+    ThreeDMatch/dataset.py:91-153 voxelises it.  Same room / window / sensor construction as make_pair(); the scene
+    comes from the seeded numpy generator, the ~n_raw surface samples per fragment from a seeded torch generator on the
+    device (a 1623-pair stream is a few seconds of generation instead of minutes).
+    -> dict(src_raw f32[n,3], tgt_raw f32[m,3] (device, each in its own sensor frame), relt_pose f64[4,4] numpy src->tgt,
+            overlap_pts f32[k,3] (device): tgt-frame points of the shared slab, for the RMSE-proxy information matrix)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    rects = make_scene(rng, size, n_boxes)
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    o = torch.tensor(np.stack([r['o'] for r in rects]), dtype=torch.float32, device=device)
+    u = torch.tensor(np.stack([r['u'] for r in rects]), dtype=torch.float32, device=device)
+    v = torch.tensor(np.stack([r['v'] for r in rects]), dtype=torch.float32, device=device)
+    area = torch.linalg.norm(torch.linalg.cross(u, v), dim=1)
+    sx = size[0]
+    width = sx / (2 - overlap)
+    windows = [(0.0, width), (sx - width, sx)]
+    sensors = [np.array([0.55 * width, 0.6 * size[1], 0.5 * size[2]]), np.array([sx - 0.55 * width, 0.55 * size[1], 0.55 * size[2]])]
+    out, poses = {}, []
+    for name, (lo, hi), sensor in zip(('src', 'tgt'), windows, sensors):
+        which = torch.multinomial(area / area.sum(), n_raw, replacement=True, generator=g)
+        ab = torch.rand((n_raw, 2), generator=g, device=device)
+        pts = o[which] + ab[:, :1] * u[which] + ab[:, 1:] * v[which] + jitter * torch.randn((n_raw, 3), generator=g, device=device)
+        pts = pts[(pts[:, 0] >= lo) & (pts[:, 0] <= hi)]
+        R = random_rotation(rng, np.pi if name == 'tgt' else 0.3)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, -R @ sensor
+        poses.append(T)
+        Rt = torch.tensor(R, dtype=torch.float32, device=device)
+        tt = torch.tensor(T[:3, 3], dtype=torch.float32, device=device)
+        if name == 'tgt':
+            shared = pts[(pts[:, 0] >= windows[1][0]) & (pts[:, 0] <= windows[0][1])]
+            out['overlap_pts'] = (shared[:: max(1, shared.shape[0] // 4096)] @ Rt.T + tt).contiguous()
+        out[f'{name}_raw'] = (pts @ Rt.T + tt).contiguous()
+    out['relt_pose'] = poses[1] @ np.linalg.inv(poses[0])
+    return out
+
+
+def information_matrix(points):
+    """6x6 information matrix of a set of overlap points p (fragment-j frame), in the convention of the 3DMatch
+    gt.info files that ThreeDMatch/test.py:92-111 consumes: for er = [t, q_xyz] (translation and quaternion vector part of
+    a small residual transform) the displacement of p is t + 2 q x p = [I, -2[p]x] er, so  er^T (sum J^T J) er / info[0,0]
+    is the mean squared displacement over the overlap -- the RMSE proxy thresholded at 0.2^2 by the RR metric."""
+    p = np.asarray(points, np.float64).reshape(-1, 3)
+    J = np.zeros((p.shape[0], 3, 6))
+    J[:, 0, 0] = J[:, 1, 1] = J[:, 2, 2] = 1.0
+    J[:, 0, 4], J[:, 0, 5] = 2 * p[:, 2], -2 * p[:, 1]
+    J[:, 1, 3], J[:, 1, 5] = -2 * p[:, 2], 2 * p[:, 0]
+    J[:, 2, 3], J[:, 2, 4] = 2 * p[:, 1], -2 * p[:, 0]
+    return np.einsum('nij,nik->jk', J, J)

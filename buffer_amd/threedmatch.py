@@ -185,11 +185,7 @@ def main(argv=None):
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--limits', default=None, help='frozen neighbourhood limits "a,b,c" (default: calibrate like dataloader.py:18-51)')
     a = ap.parse_args(argv)
-    rank, world, local = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('WORLD_SIZE', 1), ('LOCAL_RANK', 0)))
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+    rank, world, dev, cdev = bdist.init(int(os.environ.get('LOCAL_RANK', 0)))
     ds = ThreeDMatchTestSet(a.root, a.dataset)
     pipe = BufferPipeline(device=dev)
     if a.limits:
@@ -201,10 +197,10 @@ def main(argv=None):
                 s = ds.item(i, dev)
                 host.append({k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in s.items()})
             pipe.calibrate(host)
-        pipe.limits = bdist.broadcast_limits(pipe.limits if rank == 0 else [0, 0, 0], device=dev)
+        pipe.limits = bdist.broadcast_limits(pipe.limits if rank == 0 else [0, 0, 0], device=cdev)
     ids = bdist.shard_indices(len(ds), rank, world)
     t0 = time.perf_counter()
-    poses = bdist.gather_poses(ids, register_pairs(pipe, ds, ids, a.batch), len(ds), device=dev)
+    poses = bdist.gather_poses(ids, register_pairs(pipe, ds, ids, a.batch), len(ds), device=cdev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

@@ -51,6 +51,14 @@ int         buf_device_count(void);
 #define BUF_TIMED_GRID_QUERY 0
 #define BUF_TIMED_CYL_NET    1
 #define BUF_TIMED_COST_NET   2
+#define BUF_TIMED_SELECT_PATCHES 3   /* A8:  work = 12*Nf + 12*P + 12*P*nsample bytes */
+#define BUF_TIMED_PATCH_VOXELIZE 4   /* A10: work = 12*P*npts + 4*P*16*ncentres bytes */
+#define BUF_TIMED_FPS            5   /* A6:  work = rounds (m) of the launch; bytes = 12*N' + 4*m per cloud */
+#define BUF_TIMED_NN1            6   /* A12: work = 2*Q*N*D flops */
+#define BUF_TIMED_VN_GATHER      7   /* A4:  work = 4*N*K + 12*N + 12*N*Cin + 12*N*Cout bytes */
+#define BUF_TIMED_GRID_SUBSAMPLE 8   /* A1:  work = 12*N + 12*M(capacity N) + 4*B bytes; spans the whole kernel sequence */
+#define BUF_TIMED_DESC_HEAD      9   /* A11 tail: work = (2*32*140*4 + 128) bytes per patch */
+#define BUF_TIMED_NKERNELS       10
 void        buf_timing_enable(int on);
 long long   buf_timing_collect(double* total_ms, double* total_bytes);
 long long   buf_timing_collect_kernel(int kernel_id, double* total_ms, double* total_work);

@@ -1,4 +1,5 @@
-"""bench.py's one-line JSON contract (metric, whole-job value, roofline and cpu_baseline objects) on a short run."""
+"""bench.py's one-line JSON contract (metric, whole-job value, roofline and cpu_baseline objects) on short runs, and the
+N > 1 launch path: two ranks on ONE device over gloo (BENCH_BACKEND=gloo) -- the only multi-rank form a 1-GPU box can run."""
 import json
 import os
 import subprocess
@@ -10,23 +11,57 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(args, env=None, timeout=1200):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=timeout,
+                         cwd=ROOT, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')][-1])
+
+
 def test_bench_json_line(dev):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--pairs-per-step', '4',
-                          '--keypts', '1500', '--cpu-keypts', '64'], capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')][-1]
-    d = json.loads(line)
+    d = _run(['--steps', '2', '--warmup', '1', '--pairs-per-step', '4', '--keypts', '600'])
     assert d['metric'] == 'registration pairs/sec' and d['unit'] == 'pairs/s' and d['higher_is_better'] is True
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
     assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['vs_baseline'] is None
     assert abs(d['value'] - 4 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']           # pairs / wall time
-    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert 'workload' in d['config'] and 'model' not in d['config'] and 'configs[1]' in d['config']['workload']
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3 and r['launches'] == 2
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.3 < r['frac'] < 1.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.2 < r['frac'] < 1.0
     assert r['traffic'] is None or r['traffic'] > 0
-    kinds = {o['bound'] for o in d['roofline_other']}
-    assert kinds == {'mfma', 'hbm'}
+    assert 0.9 < r['executed_fraction_of_dense'] < 1.0
+    # every kernel SURVEY 8(d) gives a roofline class: A1, A2, A4, A6, A8, A10, A11 head, A12, A13
+    names = ' '.join(o['kernel'] for o in d['roofline_other'])
+    for k in ('k_cost_net', 'k_grid_query', 'k_vox_', 'k_vn_gather', 'k_select_patches', 'k_patch_voxelize', 'k_desc_head', 'k_nn1', 'k_fps'):
+        assert k in names, k
+    for o in d['roofline_other']:
+        assert o['launches'] > 0 and o['avg_us'] > 0 and (o['frac'] is None or 0 < o['frac'] < 1.0), o
     c = d['cpu_baseline']
-    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'pairs/s' and c['sample']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['workers'] >= 1 and c['value'] > 0 and c['unit'] == 'pairs/s'
+    assert 'nothing scaled' in c['sample'] and c['stages_s']['descriptors'] > 0
     assert d['config']['registered_ok'].startswith('8/8')
+
+
+def test_bench_two_ranks_on_one_device_over_gloo(dev):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts torch.distributed.run itself; both ranks share cuda:0."""
+    d = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--pairs-per-step', '3', '--keypts', '400', '--no-cpu-baseline'],
+             env={'BENCH_BACKEND': 'gloo'})
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and 'cpu_baseline' not in d
+    assert d['config']['parallelism'] == 'pair-sharded x2' and d['config']['gathered_poses'] == [6, 6]     # steps x pairs, per rank
+    assert abs(d['value'] - 2 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']                      # whole-job pairs / max-rank time
+    assert d['config']['registered_ok'].startswith('6/6')
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE='1', RANK='0'), timeout=300)
+    assert out.returncode != 0 and 'torch.distributed.run' in (out.stderr + out.stdout)
+
+
+def test_bench_kitti_and_stream_workloads(dev):
+    k = _run(['--workload', 'kitti', '--steps', '1', '--warmup', '1', '--pairs-per-step', '2', '--keypts', '300', '--no-cpu-baseline',
+              '--distinct-pairs', '2'])
+    assert 'configs[3]' in k['config']['workload'] and k['value'] > 0 and k['config']['sds_points'][0] > 3000
+    s = _run(['--workload', 'stream', '--stream-pairs', '24', '--pairs-per-step', '8', '--keypts', '600'])
+    assert 'configs[2]' in s['config']['workload'] and s['quality']['pairs'] == 24 and len(s['quality']['per_scene']) == 8
+    assert s['quality']['dgr_recall'] >= 0.8 and s['value'] > 0

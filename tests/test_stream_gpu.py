@@ -1,0 +1,41 @@
+"""BASELINE config #3 at its size: 1623 synthetic pairs streamed from RAW clouds through the device pre-processing and
+the batched registration path on one GPU, scored with the 3DMatch protocol (ThreeDMatch/test.py:227-308)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N_PAIRS = int(os.environ.get('BUF_STREAM_PAIRS', 1623))
+
+
+def test_stream_1623_pairs_from_raw_clouds(dev):
+    from buffer_amd import stream
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.pipeline import BufferPipeline
+    from buffer_amd.threedmatch import upload
+    cfg = THREEDMATCH                                                    # the reference's constants, 1500 keypoints
+    pipe = BufferPipeline(cfg, dev)
+    raws = stream.generate(N_PAIRS, dev)
+    first = stream.prepare(raws[0], cfg, 0)
+    pipe.calibrate([{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in first.items()}])
+    stream.run(pipe, raws[:16], batch=16)                                # warm-up (allocator, code objects)
+    poses, seconds = stream.run(pipe, raws, batch=16)
+    poses = poses.cpu().numpy()
+    out = stream.evaluate_stream(raws, poses)
+    out.update(pairs_per_sec_incl_preprocessing=N_PAIRS / seconds, seconds=seconds, limits=pipe.limits)
+    print('STREAM ' + json.dumps(out))
+    assert out['pairs'] == N_PAIRS and len(out['per_scene']) == 8
+    assert np.isfinite(poses).all()
+    # quality floor on the synthetic rooms (a quarter of the pairs at 0.3 overlap): see profiles/r02_stream.json
+    assert out['dgr_recall'] > 0.85 and out['registration_recall'] > 0.85, out
+    # batched launches == one pair at a time, on a sample spread over the stream (same seeds, same device-side shuffles)
+    sample = list(range(0, N_PAIRS, max(1, N_PAIRS // 6)))[:6]
+    worst = 0.0
+    for k in sample:
+        single = pipe.register(upload(stream.prepare(raws[k], cfg, k)), seed=k).cpu().numpy()
+        worst = max(worst, float(np.abs(single - poses[k]).max()))
+    print('STREAM batch-vs-single max |dpose| =', worst)
+    assert worst < 1e-4, worst

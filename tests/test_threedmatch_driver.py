@@ -98,3 +98,38 @@ def test_threedmatch_layout_end_to_end(tmp_path, dev):
     keys, traj = evaluate.read_trajectory(os.path.join(log_root, scenes[0], 'run.log'))
     assert [tuple(k[:2]) for k in keys] == [('0', '1'), ('0', '2'), ('1', '2')]
     np.testing.assert_allclose(np.linalg.inv(traj[1].astype(np.float64)), poses[1], rtol=0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_threedmatch_cli_two_gloo_ranks_write_the_same_logs(tmp_path, dev):
+    """python -m buffer_amd.threedmatch under 2 ranks (sharing the one device, BUFFER_DIST_BACKEND=gloo): pair i -> rank
+    i mod 2, one all_gather of poses, rank 0 writes the logs -- same files as the 1-rank run (poses to fp32 round-off: the
+    stacked launches of the two runs group the pairs differently)."""
+    import json
+    import subprocess
+    import sys
+    from buffer_amd import evaluate, threedmatch as tdm
+    root = str(tmp_path / 'data')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _mini_dataset(root, tdm.SCENES[:4], seed=7)
+    common = ['--root', root, '--log-name', 'run.log', '--batch', '4', '--limits', '17,20,24']
+    env = dict(os.environ, BUFFER_DIST_BACKEND='gloo', PYTHONPATH=repo)
+    one = subprocess.run([sys.executable, '-m', 'buffer_amd.threedmatch', '--log-root', str(tmp_path / 'one')] + common,
+                         capture_output=True, text=True, env=env, cwd=repo, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29547', '-m', 'buffer_amd.threedmatch', '--log-root', str(tmp_path / 'two')] + common,
+                         capture_output=True, text=True, env=env, cwd=repo, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    o1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
+    o2 = json.loads([l for l in two.stdout.splitlines() if l.startswith('{')][-1])
+    assert o1['pairs'] == o2['pairs'] == 12 and o2['n_gpus'] == 2 and o1['n_gpus'] == 1
+    assert o1['registration_recall'] == o2['registration_recall'] and o1['dgr_recall'] == o2['dgr_recall']
+    worst = 0.0
+    for scene in tdm.SCENES[:4]:
+        k1, t1 = evaluate.read_trajectory(os.path.join(str(tmp_path / 'one'), scene, 'run.log'))
+        k2, t2 = evaluate.read_trajectory(os.path.join(str(tmp_path / 'two'), scene, 'run.log'))
+        assert [tuple(k) for k in k1] == [tuple(k) for k in k2]
+        worst = max(worst, float(np.abs(np.asarray(t1, np.float64) - np.asarray(t2, np.float64)).max()))
+    print('1-rank vs 2-rank log difference:', worst)
+    assert worst < 1e-4
