@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
-COST_NET_FLOPS_PER_MATCH = 159994880.0   # csrc/costnet.hip (0.160 GFLOP/match)
+COST_NET_DENSE_FLOPS_PER_MATCH = 159994880.0      # 0.160 GFLOP/match, every layer as a dense convolution
+COST_NET_FLOPS_PER_MATCH = 109085696.0            # executed by csrc/costnet.hip: layer 0 separated into its S- and T-terms
 CYL_NET_SKIPPED_FRACTION = 0.0679        # share of the dense (algorithmic) FLOPs k_cyl_net does not execute: 6 of 81
 #                                          (tap, tile) pairs read only zero elevation padding
 
@@ -143,7 +144,9 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
     other = [
         roof_entry(timed, 'cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
                    traffic_of(pmc, 'k_cost_net', matches),
-                   flops='dense algorithmic count (SURVEY 8d: 0.160 GFLOP/match)'),
+                   flops='executed count (0.109 GFLOP/match: layer 0 separated exactly into an S-term and a T-term, 1.4 M MAC '
+                         'instead of 26.9 M); the dense count of SURVEY 8d is 0.160 GFLOP/match',
+                   dense_equivalent_tflops=(COST_NET_DENSE_FLOPS_PER_MATCH * matches) / (timed['cost_net'][1] / max(timed['cost_net'][0], 1) * 1e-3) / 1e12),
         roof_entry(timed, 'grid_query', 'k_grid_query_wave (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_grid_query_wave', units.get('pairs'))),
         roof_entry(timed, 'grid_subsample', 'k_vox_* + scan + k_cell_scatter (A1 grid subsample, whole call)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9),

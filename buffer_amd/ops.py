@@ -493,8 +493,25 @@ class DescriptorHead:
         return desc, equi
 
 
+def separate_cost_layer0(w):
+    """Layer 0 of CostNet is linear in cost[c][n][k][l] = S[c][k][(l-n) mod 20] - T[c][k][l] (models/BUFFER.py:49-60), so its
+    3x3x3 kernel w [32,32,3(dn),3(dk),3(dl)] separates exactly into a kernel on S indexed by e = dl - dn (the S-term of an
+    output depends on (k', (l'-n') mod 20) only) and one on T summed over dn (the T-term does not depend on n'):
+      Ws[(dk*5 + e+2)*32 + c][o] = sum_{dl-dn=e} w[o][c][dn][dk][dl],   Wt[(dk*3 + dl)*32 + c][o] = sum_dn w[o][c][dn][dk][dl]
+    (fp64 sums, fp32 storage) -> (Ws f32[480,32], Wt f32[288,32])."""
+    w = np.asarray(w, np.float64)
+    cout, cin = w.shape[0], w.shape[1]
+    ws = np.zeros((3, 5, cin, cout))
+    for dn in range(3):
+        for dl in range(3):
+            ws[:, dl - dn + 2] += np.transpose(w[:, :, dn, :, dl], (2, 1, 0))        # [dk, c, o]
+    wt = np.transpose(w.sum(2), (2, 3, 1, 0))                                       # [dk, dl, c, o]
+    return ws.reshape(-1, cout).astype(np.float32), wt.reshape(-1, cout).astype(np.float32)
+
+
 class CostVolumeNet:
-    """Device weights of CostNet re-laid for csrc/costnet.hip: per layer Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout], MFMA-tiled."""
+    """Device weights of CostNet re-laid for csrc/costnet.hip: layer 0 in its separated form (separate_cost_layer0: Ws then
+    Wt in one buffer), layers 1..9 as Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout]; all MFMA-tiled."""
 
     def __init__(self, layers, device):
         """layers: 10 x (w [Cout,Cin,KD,KH,KW] np.float32 with BN folded, b [Cout])"""
@@ -502,8 +519,14 @@ class CostVolumeNet:
         self.wt, self.bias = [], []
         for i, (w, b) in enumerate(layers):
             cout, cin = w.shape[0], w.shape[1]
-            wt = np.transpose(w, (2, 3, 4, 1, 0)).reshape(-1, cout)
             b = np.asarray(b, np.float32)
+            if i == 0:
+                assert tuple(w.shape) == (32, 32, 3, 3, 3), w.shape
+                tiled = np.concatenate([mfma_tile_weights(m, lk_major=True) for m in separate_cost_layer0(w)])
+                self.wt.append(torch.from_numpy(tiled).to(device))
+                self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
+                continue
+            wt = np.transpose(w, (2, 3, 4, 1, 0)).reshape(-1, cout)
             if i == 9:                                    # 20 logits -> two full 16-column tiles
                 wt = np.concatenate([wt, np.zeros((wt.shape[0], 32 - cout), np.float32)], 1)
                 b = np.concatenate([b, np.zeros(32 - cout, np.float32)])

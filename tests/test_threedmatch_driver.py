@@ -111,7 +111,7 @@ def test_threedmatch_cli_two_gloo_ranks_write_the_same_logs(tmp_path, dev):
     from buffer_amd import evaluate, threedmatch as tdm
     root = str(tmp_path / 'data')
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    _mini_dataset(root, tdm.SCENES[:4], seed=7)
+    _mini_dataset(root, tdm.SCENES, seed=7)
     common = ['--root', root, '--log-name', 'run.log', '--batch', '4', '--limits', '17,20,24']
     env = dict(os.environ, BUFFER_DIST_BACKEND='gloo', PYTHONPATH=repo)
     one = subprocess.run([sys.executable, '-m', 'buffer_amd.threedmatch', '--log-root', str(tmp_path / 'one')] + common,
@@ -123,10 +123,10 @@ def test_threedmatch_cli_two_gloo_ranks_write_the_same_logs(tmp_path, dev):
     assert two.returncode == 0, two.stderr[-3000:]
     o1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
     o2 = json.loads([l for l in two.stdout.splitlines() if l.startswith('{')][-1])
-    assert o1['pairs'] == o2['pairs'] == 12 and o2['n_gpus'] == 2 and o1['n_gpus'] == 1
+    assert o1['pairs'] == o2['pairs'] == 24 and o2['n_gpus'] == 2 and o1['n_gpus'] == 1
     assert o1['registration_recall'] == o2['registration_recall'] and o1['dgr_recall'] == o2['dgr_recall']
     worst = 0.0
-    for scene in tdm.SCENES[:4]:
+    for scene in tdm.SCENES:
         k1, t1 = evaluate.read_trajectory(os.path.join(str(tmp_path / 'one'), scene, 'run.log'))
         k2, t2 = evaluate.read_trajectory(os.path.join(str(tmp_path / 'two'), scene, 'run.log'))
         assert [tuple(k) for k in k1] == [tuple(k) for k in k2]
