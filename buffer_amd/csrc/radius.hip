@@ -202,49 +202,67 @@ __global__ void __launch_bounds__(WAVE) k_grid_query(const CellGrid* __restrict_
 }
 
 // Fast path: a 16-lane group per query, four queries per wavefront (a neighbourhood holds 10-35 points, so a
-// full wavefront per query would leave most lanes idle in the scan and in the sort).
-//   - lanes 0..8 of a group fetch the 9 cell-run bounds, a width-16 shuffle hands every lane all nine;
-//   - the runs are flattened and scanned 16 candidates at a time per group (float4 loads, contiguous inside a
-//     run), accepted (d2,index) keys are compacted into the group's LDS slice through ballot + popcount prefix;
-//   - every key ranks itself against the group's other keys (LDS reads, broadcast inside the group): an exact
-//     sort by (d2, index) for rows of up to QW_CAP neighbours.  Longer rows are pushed on a todo list and
-//     redone by k_grid_query (lane-per-query, unbounded rows) in the same stream.
+// full wavefront per query would leave most lanes idle in the scan and in the sort).  The kernel is VALU-issue bound
+// (DESIGN.md section 5), so every phase is shaped to cost few instructions per wavefront:
+//   - the grid is 2-D: blockIdx.y = batch element, so the element's grid descriptor and offsets are wave-uniform
+//     (scalar registers, no per-query search), blockIdx.x = chunk of 16 queries of that element;
+//   - cell coordinates stay in fp64 (a query must land in exactly the cell its coordinates round to: the cell edge
+//     exceeds the radius by 1e-5 only), but lane d of a group computes dimension d only and a group shuffle shares them;
+//   - lanes 0..8 of a group fetch the 9 cell-run bounds and pass them to the group through LDS (five ds_read_b128);
+//     the runs are flattened and scanned 16 candidates at a time (float4 loads, contiguous inside a run), candidate c
+//     maps to its run through per-run offsets (compare + select per run);
+//   - accepted (d2,index) keys are compacted in arrival order through ballot + popcount prefix, and counted into 16
+//     distance buckets per query (bucket = floor(d2 * 16 / r2), monotone in d2);
+//   - sorting = exclusive scan of the bucket counts over the group's 16 lanes (DPP), a scatter of the keys into bucket
+//     order, then every key ranks itself against the keys of ITS bucket only (2-3 instead of 35): an exact sort by
+//     (d2, index) for rows of up to QW_CAP neighbours.  Longer rows are pushed on a todo list and redone by
+//     k_grid_query (lane-per-query, unbounded rows) in the same stream.
 #define QW_WAVES 4
 #define QG 16                       // lanes per query
 #define QPW (WAVE / QG)             // queries per wavefront
 #define QW_CAP 64
+#define QW_QPB (QW_WAVES * QPW)     // queries per workgroup
 
-#define QMAXB 128                   // batch elements whose descriptors are staged in LDS per workgroup
+// exclusive prefix sum over each row of 16 lanes (DPP row shifts, zero fill)
+__device__ __forceinline__ int row16_excl_scan(int v)
+{
+    int inc = v;
+#define ROW_SHR_ADD(ctrl) inc += __builtin_amdgcn_update_dpp(0, inc, ctrl, 0xf, 0xf, true)
+    ROW_SHR_ADD(0x111);   // row_shr:1
+    ROW_SHR_ADD(0x112);   // row_shr:2
+    ROW_SHR_ADD(0x114);   // row_shr:4
+    ROW_SHR_ADD(0x118);   // row_shr:8
+#undef ROW_SHR_ADD
+    return inc - v;
+}
 
 __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellGrid* __restrict__ grids, const int* __restrict__ table,
                                                                   const float4* __restrict__ sorted, const float* __restrict__ queries,
-                                                                  int nq, const int* __restrict__ q_off, int nb,
-                                                                  const int* __restrict__ q_order, int self_query, float r2,
+                                                                  const int* __restrict__ q_off,
+                                                                  const int* __restrict__ q_order, int self_query, float r2, float bin_scale,
                                                                   int k_out, int shadow,
                                                                   int* __restrict__ nbr_out, int* __restrict__ counts_out,
                                                                   int* __restrict__ max_count_out, int* __restrict__ todo,
                                                                   int* __restrict__ todo_n)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long keys[QW_WAVES][QPW][QW_CAP + 8];   // + sentinels
-    __shared__ int s_off[QMAXB + 1];
-    __shared__ CellGrid s_grid[QMAXB];
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[QW_WAVES][QPW][QW_CAP];       // arrival order
+    __shared__ __attribute__((aligned(16))) unsigned long long bkeys[QW_WAVES][QPW][QW_CAP];      // bucket order
+    __shared__ __attribute__((aligned(16))) int runs[QW_WAVES][QPW][20];                           // 9 starts | 9 lengths
+    __shared__ int hist[QW_WAVES][QPW][QG];                                                        // bucket counts
+    __shared__ int pref[QW_WAVES][QPW][QG + 4];                                                    // exclusive prefix, [16] = total
+    __shared__ int cur[QW_WAVES][QPW][QG];                                                         // scatter cursors
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int grp = lane / QG, l16 = lane & (QG - 1);
-    const int t = (blockIdx.x * QW_WAVES + w) * QPW + grp;
-    const bool active = t < nq;
-    // The dependent-load chain of a query is what bounds this kernel: element offsets and grid descriptors are
-    // staged once per workgroup, a self query reads index AND coordinates from the cell-ordered array in one
-    // load, and all candidate chunks of a pass are requested before the first one is consumed.
-    const bool staged = nb <= QMAXB;
-    if (staged) {
-        for (int i = threadIdx.x; i <= nb; i += QW_WAVES * WAVE) s_off[i] = q_off[i];
-        for (int i = threadIdx.x; i < nb * (int)(sizeof(CellGrid) / 4); i += QW_WAVES * WAVE)
-            reinterpret_cast<int*>(s_grid)[i] = reinterpret_cast<const int*>(grids)[i];
-    }
+    const int b = blockIdx.y;                                             // batch element: wave-uniform
+    const int e_lo = q_off[b], e_n = q_off[b + 1] - e_lo;                 // scalar loads
+    if ((int)blockIdx.x * QW_QPB >= e_n) return;                          // chunk past this element's queries
+    const int tl = (blockIdx.x * QW_WAVES + w) * QPW + grp;               // query number inside the element
+    const bool active = tl < e_n;
+    const int t = e_lo + tl;
     int qi = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (active) {
-        if (self_query) {
+        if (self_query) {                                                 // index AND coordinates from the cell-ordered array
             const float4 s = sorted[t];
             qi = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z;
         } else {
@@ -252,34 +270,37 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
             qx = queries[3 * (size_t)qi]; qy = queries[3 * (size_t)qi + 1]; qz = queries[3 * (size_t)qi + 2];
         }
     }
-    if (staged) __syncthreads();
-    int rs = 0, len = 0;
-    if (active) {
-        const int b = find_elem(staged ? s_off : q_off, nb, qi);
-        const CellGrid g = staged ? s_grid[b] : grids[b];
-        double fx = floor(((double)qx - (double)g.mn[0]) * g.inv_cell);
-        double fy = floor(((double)qy - (double)g.mn[1]) * g.inv_cell);
-        double fz = floor(((double)qz - (double)g.mn[2]) * g.inv_cell);
-        fx = fmin(fmax(fx, -2.0), (double)g.dim[0] + 1.0);      // far-away queries simply find no cell
-        fy = fmin(fmax(fy, -2.0), (double)g.dim[1] + 1.0);
-        fz = fmin(fmax(fz, -2.0), (double)g.dim[2] + 1.0);
-        const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    const CellGrid g = grids[b];                                          // uniform address: scalar loads
+    hist[w][grp][l16] = 0;
+    // cell coordinate of dimension d = l16 % 3 in fp64, shared through a width-16 shuffle
+    const int d = l16 % 3;
+    const float qd = d == 0 ? qx : (d == 1 ? qy : qz);
+    const float mnd = d == 0 ? g.mn[0] : (d == 1 ? g.mn[1] : g.mn[2]);
+    const int dimd = d == 0 ? g.dim[0] : (d == 1 ? g.dim[1] : g.dim[2]);
+    double fd = floor(((double)qd - (double)mnd) * g.inv_cell);
+    fd = fmin(fmax(fd, -2.0), (double)dimd + 1.0);                        // far-away queries simply find no cell
+    const int cd = (int)fd;
+    const int cx = __shfl(cd, 0, QG), cy = __shfl(cd, 1, QG), cz = __shfl(cd, 2, QG);
+    {
+        int rs = 0, len = 0;
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-        if (l16 < 9) {
-            const int y = cy + (l16 % 3) - 1, z = cz + (l16 / 3) - 1;
-            if (x0 <= x1 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
-                const int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
-                rs = g0 == 0 ? 0 : table[g0 - 1];
-                len = table[g0 + (x1 - x0)] - rs;
-            }
+        const int y = cy + (l16 % 3) - 1, z = cz + (l16 / 3) - 1;
+        if (active && l16 < 9 && x0 <= x1 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+            const int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
+            rs = g0 == 0 ? 0 : table[g0 - 1];
+            len = table[g0 + (x1 - x0)] - rs;
         }
+        if (l16 < 10) { runs[w][grp][l16] = rs; runs[w][grp][10 + l16] = len; }          // slots 9 / 19: zero padding
     }
+    __builtin_amdgcn_wave_barrier();
     int st[9], pre[9], total = 0;
+    {
+        const int4* R4 = reinterpret_cast<const int4*>(runs[w][grp]);
+        const int4 a0 = R4[0], a1 = R4[1], a2 = R4[2], a3 = R4[3], a4 = R4[4];
+        const int sv[9] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x };
+        const int lv[9] = { a2.z, a2.w, a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z };
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
-        st[j] = __shfl(rs, j, QG);
-        pre[j] = total;
-        total += __shfl(len, j, QG);
+        for (int j = 0; j < 9; j++) { pre[j] = total; st[j] = sv[j] - total; total += lv[j]; }   // st = start - prefix
     }
     unsigned long long* K = keys[w][grp];
     const unsigned long long gmask_lo = (1ull << l16) - 1ull;
@@ -289,10 +310,10 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
 #pragma unroll
         for (int u = 0; u < 4; u++) {               // all four chunk loads of the pass are in flight together
             const int c = c0 + u * QG + l16;
-            int p = st[0] + c;
+            int off = st[0];
 #pragma unroll
-            for (int j = 1; j < 9; j++) p = c >= pre[j] ? st[j] + (c - pre[j]) : p;
-            cand[u] = c < total ? sorted[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 1; j < 9; j++) off = c >= pre[j] ? st[j] : off;
+            cand[u] = c < total ? sorted[c + off] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -302,7 +323,10 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
             const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(cand[u].w);
             const unsigned long long mask = (__ballot(hit) >> (grp * QG)) & 0xffffull;
             const int pos = m + __popcll(mask & gmask_lo);
-            if (hit && pos < QW_CAP) K[pos] = key;
+            if (hit && pos < QW_CAP) {
+                K[pos] = key;
+                atomicAdd(&hist[w][grp][min((int)(d2 * bin_scale), QG - 1)], 1);
+            }
             m += __popcll(mask);
         }
     }
@@ -317,27 +341,53 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     }
     int* row = nbr_out + (size_t)qi * k_out;
     int mmax = m;
-    for (int d = QG; d < WAVE; d <<= 1) mmax = max(mmax, __shfl_xor(mmax, d, WAVE));      // max over the 4 groups
+    for (int dd = QG; dd < WAVE; dd <<= 1) mmax = max(mmax, __shfl_xor(mmax, dd, WAVE));      // max over the 4 groups
     mmax = __builtin_amdgcn_readfirstlane(mmax);
-    // the rank loop runs 4 keys per step up to the wavefront's longest row: pad every group's slice with sentinels
-    for (int i = m + l16; i < ((mmax + 3) & ~3); i += QG) K[i] = ~0ull;
+    // bucket offsets: exclusive scan of the 16 counts over the group's lanes
     __builtin_amdgcn_wave_barrier();
-    const ulonglong2* K2 = reinterpret_cast<const ulonglong2*>(K);
-    for (int s0 = 0; s0 < mmax; s0 += QG) {
-        const int i = s0 + l16;
-        const bool have = i < m;
-        const unsigned long long mine = have ? K[i] : 0ull;       // 0 never ranks above anything
-        int rank = 0;
-        for (int j = 0; j < mmax; j += 4) {
-            const ulonglong2 a = K2[j >> 1], b = K2[(j >> 1) + 1];
-            rank += (a.x < mine ? 1 : 0) + (a.y < mine ? 1 : 0) + (b.x < mine ? 1 : 0) + (b.y < mine ? 1 : 0);
+    {
+        const int cnt = hist[w][grp][l16];
+        const int ex = row16_excl_scan(cnt);
+        pref[w][grp][l16] = ex;
+        cur[w][grp][l16] = ex;
+        if (l16 == QG - 1) pref[w][grp][QG] = ex + cnt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long* B = bkeys[w][grp];
+    const int rounds = (mmax + QG - 1) / QG;
+    // scatter into bucket order; every key remembers the extent of its bucket
+    unsigned long long mine[QW_CAP / QG];
+    int blo[QW_CAP / QG], bhi[QW_CAP / QG];
+#pragma unroll
+    for (int r = 0; r < QW_CAP / QG; r++) {
+        mine[r] = 0ull; blo[r] = 0; bhi[r] = 0;
+        if (r < rounds) {
+            const int i = r * QG + l16;
+            if (i < m) {
+                const unsigned long long key = K[i];
+                const int bk = min((int)(__uint_as_float((unsigned int)(key >> 32)) * bin_scale), QG - 1);
+                B[atomicAdd(&cur[w][grp][bk], 1)] = key;
+                mine[r] = key; blo[r] = pref[w][grp][bk]; bhi[r] = pref[w][grp][bk + 1];
+            }
         }
-        if (have && rank < k_out) row[rank] = (int)(unsigned int)(mine & 0xffffffffu);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rank inside the bucket (the keys of lower buckets are all smaller), then write the row
+#pragma unroll
+    for (int r = 0; r < QW_CAP / QG; r++) {
+        if (r < rounds) {
+            int rank = blo[r];
+            for (int tt = 0; __any(blo[r] + tt < bhi[r]); tt++) {
+                const int p = blo[r] + tt;
+                const unsigned long long o = B[p < bhi[r] ? p : 0];
+                rank += (p < bhi[r] && o < mine[r]) ? 1 : 0;
+            }
+            if (r * QG + l16 < m && rank < k_out) row[rank] = (int)(unsigned int)(mine[r] & 0xffffffffu);
+        }
     }
     // shadow padding (skipped for rows handed to the fallback: it rewrites the whole row)
     if (active) {
-        const int filled = m;
-        for (int i = filled + l16; i < k_out; i += QG) row[i] = shadow;
+        for (int i = m + l16; i < k_out; i += QG) row[i] = shadow;
     }
 }
 
@@ -447,9 +497,17 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
     bool timed = timing_begin(s, &span, 12.0 * nq + 12.0 * g->ns + 4.0 * (double)nq * k_out);
     // todo list (query ids of rows longer than QW_CAP) is carved behind the caller's output: it needs at
     // most nq ints; the first k_out==0 launch never produces one.
-    k_grid_query_wave<<<cdiv(nq, QW_WAVES * QPW), QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
-                                                                   queries, nq, ex.q_off, g->nb, q_order, self_query, r2, k_out, g->ns, nbr_out,
-                                                                   counts_out, max_count_out, todo, ex.todo_n);
+    // 2-D launch: y = batch element, x = chunks of 16 queries of the longest element (chunks past an element's end exit at once)
+    int qmax = 0;
+    for (int bb = 0; bb < g->nb; bb++) qmax = q_batches_host[bb] > qmax ? q_batches_host[bb] : qmax;
+    if (qmax > 0) {
+        BUF_REQUIRE(g->nb <= 65535, BUF_EINVAL, "buf_grid_query: %d batch elements (at most 65535 per call)", g->nb);
+        dim3 grid2(cdiv(qmax, QW_QPB), g->nb);
+        const float bin_scale = r2 > 0.f ? (float)QG / r2 : 0.f;           // distance bucket = floor(d2 * 16 / r2), monotone in d2
+        k_grid_query_wave<<<grid2, QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries,
+                                                          ex.q_off, q_order, self_query, r2, bin_scale, k_out, g->ns, nbr_out,
+                                                          counts_out, max_count_out, todo, ex.todo_n);
+    }
     if (timed) timing_end(s, &span);
     if (k_out > 0) {
         // fallback pass over the (normally empty) todo list; exits at once when the device-side count is 0
