@@ -53,6 +53,9 @@ _SIGNATURES = {
     "buf_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "buf_three_nn": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "buf_select_patches": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp]),
+    "buf_select_patches_batched_ws_bytes": (_sz, [_i, _i]),
+    "buf_select_patches_batched": (_i, [_vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _sz, _vp]),
+    "buf_permute_clouds": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "buf_compact_ws_bytes": (_sz, [_i]),
     "buf_compact_greater": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "buf_knn_ws_bytes": (_sz, [_i, _i, _i]),

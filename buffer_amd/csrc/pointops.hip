@@ -391,6 +391,235 @@ extern "C" int buf_select_patches(const float* pts, const float* kpts, int n, in
     return BUF_OK;
 }
 
+// ---- A8 batched: every cloud of a step in ONE launch ----------------------------------------------------------------
+// A keypoint's ball (r = 0.3 m on a 2.5 cm cloud) holds 450-900 of ~23 000 points: often fewer than the 511 the patch
+// keeps, so the index-ordered brute-force scan above reads the WHOLE cloud for such queries.  Here the ball is found
+// through the A2 cell grid built over the stacked (permuted) clouds: the candidates of the 27 cells around the keypoint
+// (~2 000) are tested and every in-ball point sets ITS bit in a per-query LDS bitmask over the cloud's indices; the mask is
+// then walked in index order (popcount prefix over the lanes), which restores exactly the "first 511 in index order"
+// semantics.  Where the ball is so dense that the ordered scan would stop early anyway (KITTI: des_r = 3 m), the kernel
+// keeps the brute-force scan; the choice is per query, made from the candidate count, and changes speed only.
+#define SPB_WAVES 4
+#define SPB_MAX_MASK_BYTES 16384            // per query: clouds up to 131 072 points take the mask path
+
+// pseudo-random permutation of [0, n): 4-round Feistel network on an even number of bits >= log2 n, cycle-walked into range
+__device__ __forceinline__ unsigned int prp_hash(unsigned int x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ unsigned int prp_index(unsigned int i, unsigned int n, int half_bits, unsigned long long key)
+{
+    const unsigned int hm = (1u << half_bits) - 1u;
+    unsigned int v = i;
+    do {
+        unsigned int l = v >> half_bits, r = v & hm;
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            const unsigned int f = prp_hash(r ^ (unsigned int)(key >> (16 * rd)) ^ (0x9e3779b9u * (rd + 1))) & hm;
+            const unsigned int nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        v = (l << half_bits) | r;
+    } while (v >= n);
+    return v;
+}
+
+#define PERM_MAXC 64
+struct PermBatch { const float* src[PERM_MAXC]; int off[PERM_MAXC + 1]; unsigned long long key[PERM_MAXC]; };
+
+// out[off[c] + j] = src_c[prp_c(j)]: cloud c shuffled by its own keyed permutation (patch_embedder.py:97-98's randperm)
+__global__ void __launch_bounds__(256) k_permute_clouds(PermBatch B, int nc, float* __restrict__ out)
+{
+    const int c = blockIdx.y;
+    const int n = B.off[c + 1] - B.off[c];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int hb = 1;
+    while ((1u << (2 * hb)) < (unsigned int)n) hb++;
+    const unsigned int k = prp_index((unsigned int)j, (unsigned int)n, hb, B.key[c]);
+    const Pt3 p = *reinterpret_cast<const Pt3*>(B.src[c] + 3 * (size_t)k);
+    *reinterpret_cast<Pt3*>(out + 3 * ((size_t)B.off[c] + j)) = p;
+}
+
+// clouds_host: nc HOST pointers to DEVICE clouds f32[n_c,3]; keys_host: nc 64-bit permutation keys -> out f32[sum n_c, 3]
+extern "C" int buf_permute_clouds(const float* const* clouds_host, const int* lengths_host, const unsigned long long* keys_host,
+                                  int nc, float* out, void* stream)
+{
+    BUF_REQUIRE(nc >= 0, BUF_EINVAL, "buf_permute_clouds: nc=%d", nc);
+    if (nc == 0) return BUF_OK;
+    BUF_REQUIRE(clouds_host && lengths_host && keys_host && out, BUF_EINVAL, "buf_permute_clouds: null argument");
+    long long base = 0;
+    for (int c0 = 0; c0 < nc; c0 += PERM_MAXC) {
+        PermBatch B;
+        const int cnt = nc - c0 < PERM_MAXC ? nc - c0 : PERM_MAXC;
+        int nmax = 0;
+        B.off[0] = 0;
+        for (int i = 0; i < cnt; i++) {
+            const int n = lengths_host[c0 + i];
+            BUF_REQUIRE(n >= 0 && (n == 0 || clouds_host[c0 + i]), BUF_EINVAL, "buf_permute_clouds: cloud %d", c0 + i);
+            B.src[i] = clouds_host[c0 + i]; B.key[i] = keys_host[c0 + i]; B.off[i + 1] = B.off[i] + n;
+            nmax = n > nmax ? n : nmax;
+        }
+        if (nmax > 0) k_permute_clouds<<<dim3(cdiv(nmax, 256), cnt), 256, 0, (hipStream_t)stream>>>(B, cnt, out + 3 * base);
+        base += B.off[cnt];
+    }
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+// One wavefront per keypoint; blockIdx.y = cloud.  kpts: m keypoints per cloud, stacked; patches f32[nc*m, nsample, 3].
+__global__ void __launch_bounds__(SPB_WAVES * WAVE) k_select_patches_grid(const CellGrid* __restrict__ grids, const int* __restrict__ table,
+                                                                      const float4* __restrict__ sorted, const float* __restrict__ pts,
+                                                                      const int* __restrict__ s_off, const float* __restrict__ kpts, int m,
+                                                                      float r2, int nsample, int mask_words, float* __restrict__ patches)
+{
+    extern __shared__ unsigned long long spb_mask[];             // [SPB_WAVES][mask_words]
+    const int c = blockIdx.y;
+    const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const int q = blockIdx.x * SPB_WAVES + w;
+    if (q >= m) return;
+    const int lo = s_off[c], n = s_off[c + 1] - lo;              // scalar loads: the cloud's rows in the stacked array
+    const float* P = pts + 3 * (size_t)lo;
+    const float* Q = kpts + 3 * ((size_t)c * m + q);
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    float* row = patches + ((size_t)c * m + q) * nsample * 3;
+    const int keep = nsample - 1;
+    const CellGrid g = grids[c];
+    // the 9 cell runs around the keypoint (lanes 0..8), flattened
+    int rs = 0, len = 0;
+    {
+        double fx = floor(((double)qx - (double)g.mn[0]) * g.inv_cell);
+        double fy = floor(((double)qy - (double)g.mn[1]) * g.inv_cell);
+        double fz = floor(((double)qz - (double)g.mn[2]) * g.inv_cell);
+        fx = fmin(fmax(fx, -2.0), (double)g.dim[0] + 1.0);
+        fy = fmin(fmax(fy, -2.0), (double)g.dim[1] + 1.0);
+        fz = fmin(fmax(fz, -2.0), (double)g.dim[2] + 1.0);
+        const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        const int y = cy + (lane % 3) - 1, z = cz + (lane / 3) - 1;
+        if (lane < 9 && x0 <= x1 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+            const int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
+            rs = g0 == 0 ? 0 : table[g0 - 1];
+            len = table[g0 + (x1 - x0)] - rs;
+        }
+    }
+    int st[9], pre[9], total = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int sj = __builtin_amdgcn_readlane(rs, j), lj = __builtin_amdgcn_readlane(len, j);
+        pre[j] = total; st[j] = sj - total; total += lj;
+    }
+    int cnt = 0;
+    // Path choice (speed only).  Expected in-ball points ~ 0.4 * candidates on surface-like clouds; the ordered scan stops
+    // after about keep / that * n indices at ~25 instructions per 64 indices, the grid path tests every candidate at ~35 per 64.
+    const float in_ball = 0.4f * (float)total;
+    const bool grid_path = mask_words > 0 && (in_ball <= (float)keep || (float)keep / in_ball * (float)n * 25.f > (float)total * 35.f + 64.f * 300.f);
+    if (grid_path) {
+        unsigned long long* M = spb_mask + (size_t)w * mask_words;
+        const int nw = (n + 63) >> 6;
+        for (int i = lane; i < nw; i += WAVE) M[i] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        for (int c0 = 0; c0 < total; c0 += WAVE) {
+            const int cc = c0 + lane;
+            int off = st[0];
+#pragma unroll
+            for (int j = 1; j < 9; j++) off = cc >= pre[j] ? st[j] : off;
+            if (cc < total) {
+                const float4 p = sorted[cc + off];
+                if (sqdist3(qx, qy, qz, p.x, p.y, p.z) < r2) {
+                    const int k = __float_as_int(p.w) - lo;                  // index inside the cloud
+                    atomicOr(&M[k >> 6], 1ull << (k & 63));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ordered emission: lane l owns the words [l*wpl, (l+1)*wpl); slot of its first hit = hits in the lanes below
+        const int wpl = (nw + WAVE - 1) / WAVE;
+        int mine = 0;
+        for (int i = 0; i < wpl; i++) { const int wi = lane * wpl + i; mine += wi < nw ? __popcll(M[wi]) : 0; }
+        int incl = mine;
+        for (int dd = 1; dd < WAVE; dd <<= 1) { const int o = __shfl_up(incl, dd, WAVE); if (lane >= dd) incl += o; }
+        int slot = incl - mine;
+        cnt = __builtin_amdgcn_readlane(incl, WAVE - 1);
+        for (int i = 0; i < wpl && slot < keep; i++) {
+            const int wi = lane * wpl + i;
+            unsigned long long bits = wi < nw ? M[wi] : 0ull;
+            while (bits && slot < keep) {
+                const int bpos = __ffsll((long long)bits) - 1;
+                bits &= bits - 1ull;
+                const Pt3 p = *reinterpret_cast<const Pt3*>(P + 3 * (size_t)(wi * 64 + bpos));
+                *reinterpret_cast<Pt3*>(row + 3 * slot) = p;
+                slot++;
+            }
+        }
+    } else {
+        for (int base = 0; base < n && cnt < keep; base += WAVE) {           // index-ordered scan with early exit
+            const int k = base + lane;
+            bool hit = false;
+            Pt3 p = { 0.f, 0.f, 0.f };
+            if (k < n) {
+                p = *reinterpret_cast<const Pt3*>(P + 3 * (size_t)k);
+                hit = sqdist3(qx, qy, qz, p.x, p.y, p.z) < r2;
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const int slot = cnt + lane_prefix(mask, lane);
+                if (hit && slot < keep) *reinterpret_cast<Pt3*>(row + 3 * slot) = p;
+                cnt += __popcll(mask);
+            }
+        }
+    }
+    if (cnt > keep) cnt = keep;
+    if (cnt == 0 && nsample > 1) {                                           // empty ball: slot 0 = point 0 of the cloud
+        if (lane == 0 && n > 0) { row[0] = P[0]; row[1] = P[1]; row[2] = P[2]; }
+        cnt = n > 0 ? 1 : 0;
+    }
+    for (int j = cnt + lane; j < nsample; j += WAVE) { row[3 * j] = qx; row[3 * j + 1] = qy; row[3 * j + 2] = qz; }
+}
+
+extern "C" size_t buf_select_patches_batched_ws_bytes(int n_total, int nc) { return buf_grid_ws_bytes(n_total, nc > 0 ? nc : 1, 0) + 256; }
+
+// pts f32[sum n_c, 3]: the (already permuted) support clouds stacked; lengths_host int[nc]; kpts f32[nc*m,3]: m keypoints per
+// cloud -> patches f32[nc*m, nsample, 3].  One grid build + one launch for all clouds.
+extern "C" int buf_select_patches_batched(const float* pts, const int* lengths_host, int nc, const float* kpts, int m, float radius,
+                                          int nsample, float* patches, void* ws, size_t ws_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    BUF_REQUIRE(nc >= 0 && m >= 0 && nsample >= 1 && radius > 0.f, BUF_EINVAL, "buf_select_patches_batched: nc=%d m=%d nsample=%d radius=%g", nc, m, nsample, radius);
+    if (nc == 0 || m == 0) return BUF_OK;
+    BUF_REQUIRE(lengths_host && kpts && patches && ws, BUF_EINVAL, "buf_select_patches_batched: null argument");
+    BUF_REQUIRE(nc <= 65535, BUF_EINVAL, "buf_select_patches_batched: %d clouds (at most 65535 per call)", nc);
+    long long ntot = 0;
+    int nmax = 0;
+    for (int c = 0; c < nc; c++) {
+        BUF_REQUIRE(lengths_host[c] >= 0, BUF_EINVAL, "buf_select_patches_batched: negative length");
+        ntot += lengths_host[c];
+        nmax = lengths_host[c] > nmax ? lengths_host[c] : nmax;
+    }
+    BUF_REQUIRE(ntot < 0x7fffffffLL && (ntot == 0 || pts), BUF_EINVAL, "buf_select_patches_batched: points");
+    BUF_REQUIRE(ws_bytes >= buf_select_patches_batched_ws_bytes((int)ntot, nc), BUF_EWORKSPACE, "buf_select_patches_batched: workspace %zu < %zu",
+                ws_bytes, buf_select_patches_batched_ws_bytes((int)ntot, nc));
+    buf_grid_t g;
+    int rc = buf_grid_build(&g, pts, (int)ntot, lengths_host, nc, radius, 0, ws, ws_bytes, stream);
+    if (rc) return rc;
+    int mask_words = (nmax + 63) / 64;
+    if ((size_t)mask_words * 8 > SPB_MAX_MASK_BYTES) mask_words = 0;         // huge clouds: ordered scan only
+    const size_t lds = (size_t)SPB_WAVES * mask_words * 8;
+    static LdsGrant grant;
+    if (lds > 48 * 1024)
+        if (int rc2 = grant_dynamic_lds((const void*)k_select_patches_grid, lds, grant)) return rc2;
+    TimedSpan span;
+    bool timed = timing_begin(s, &span, 12.0 * ntot + (12.0 + 12.0 * nsample) * (double)nc * m, BUF_TIMED_SELECT_PATCHES);
+    k_select_patches_grid<<<dim3(cdiv(m, SPB_WAVES), nc), SPB_WAVES * WAVE, lds, s>>>((const CellGrid*)g.desc, g.table, (const float4*)g.sorted, pts,
+                                                                                 g.s_off, kpts, m, radius * radius, nsample, mask_words, patches);
+    if (timed) timing_end(s, &span);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
 // ------------------------------------------------------------------------------------------ A18
 __global__ void __launch_bounds__(256) k_three_nn(const float* __restrict__ unknown, const float* __restrict__ known,
                                                 int n, int m, float* __restrict__ dist, int* __restrict__ idx)

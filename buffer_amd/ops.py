@@ -212,6 +212,50 @@ def select_patches(pts, kpts, radius, nsample, out=None):
     return out
 
 
+_MASK64 = (1 << 64) - 1
+
+
+def perm_key(seed, cloud):
+    """64-bit key of the keyed permutation of cloud `cloud` (0 = src, 1 = tgt) of the pair registered with `seed`."""
+    x = ((int(seed) * 2 + int(cloud)) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & _MASK64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _MASK64
+    return x ^ (x >> 31)
+
+
+def permute_clouds(clouds, keys):
+    """clouds: list of f32[n_c,3] device tensors -> (f32[sum n_c,3] stacked and shuffled cloud by cloud, int32[nc] lengths).
+    One launch; the permutation of a cloud depends on its key and length only (patch_embedder.py:97-98's randperm)."""
+    L = _lib.lib()
+    clouds = [_dev(c, torch.float32, "permute_clouds") for c in clouds]
+    lens = np.array([c.shape[0] for c in clouds], np.int32)
+    out = torch.empty((int(lens.sum()), 3), dtype=torch.float32, device=clouds[0].device)
+    nc = len(clouds)
+    ptrs = (C.c_void_p * nc)(*[c.data_ptr() for c in clouds])
+    ks = (C.c_ulonglong * nc)(*[int(k) & _MASK64 for k in keys])
+    check(L.buf_permute_clouds(ptrs, _hptr(lens), ks, nc, _ptr(out), _stream()), "buf_permute_clouds")
+    return out, lens
+
+
+def select_patches_batched(sup, lengths, kpts, m, radius, nsample, out=None):
+    """MiniSpinNet.select_patches for every cloud of a step in one launch: sup f32[sum n_c,3] (the permuted support
+    clouds stacked), kpts f32[nc*m,3] (m keypoints per cloud) -> f32[nc*m, nsample, 3]."""
+    L = _lib.lib()
+    sup = _dev(sup, torch.float32, "select_patches_batched.sup")
+    kpts = _dev(kpts, torch.float32, "select_patches_batched.kpts")
+    lengths = _host_i32(lengths)
+    nc = int(lengths.shape[0])
+    if kpts.shape[0] != nc * m:
+        raise _lib.BufferHipError(f"select_patches_batched: {kpts.shape[0]} keypoints for {nc} clouds x {m}")
+    if out is None:
+        out = torch.empty((nc * m, nsample, 3), dtype=torch.float32, device=sup.device)
+    nbytes = L.buf_select_patches_batched_ws_bytes(int(sup.shape[0]), nc)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=sup.device)
+    check(L.buf_select_patches_batched(_ptr(sup), _hptr(lengths), nc, _ptr(kpts), int(m), float(radius), int(nsample), _ptr(out),
+                                       _ptr(ws), nbytes, _stream()), "buf_select_patches_batched")
+    return out
+
+
 def compact_greater(x, threshold):
     """ascending int32 indices i with x[i] > threshold (x f32[n] or [n,1]); one host read-back for the count."""
     L = _lib.lib()

@@ -55,12 +55,16 @@ class BufferPipeline:
         fps = ops.furthest_point_sample_ragged(torch.cat(cand_p), [c.shape[0] for c in cand_p], cfg.num_keypts).long()
         kp = [cand_p[i][fps[i]].contiguous() for i in range(2)]
         ka = [cand_a[i][fps[i]].contiguous() for i in range(2)]
-        g = torch.Generator(device=self.device)
-        g.manual_seed(seed)
-        res = []
-        for i, raw in enumerate((inp['src_raw'], inp['tgt_raw'])):
-            perm = perms[i] if perms is not None else torch.randperm(raw.shape[0], device=self.device, generator=g)
-            res.append(self.desc(raw, kp[i], ka[i], perm))
+        raws = (inp['src_raw'], inp['tgt_raw'])
+        if perms is not None:                               # caller-pinned permutations (parity tests)
+            sup = torch.cat([raws[i][perms[i]] for i in range(2)]).contiguous()
+            sup_len = [raws[0].shape[0], raws[1].shape[0]]
+        else:                                               # keyed device permutation, the same one register_batch uses
+            sup, sup_len = ops.permute_clouds(raws, [ops.perm_key(seed, j) for j in range(2)])
+        P = cfg.num_keypts
+        patches = ops.select_patches_batched(sup, sup_len, torch.cat(kp), P, cfg.des_r, cfg.num_points_per_patch)
+        emb = self.desc.embed_patches(patches, torch.cat(ka), want_patches=detail)
+        res = [{k: (v[i * P:(i + 1) * P] if v is not None else None) for k, v in emb.items()} for i in range(2)]
         s_mids, t_mids = registration.mutual_matching(res[0]['desc'], res[1]['desc'])
         if s_mids.shape[0] < 3:
             return self._identity(out, detail)
@@ -116,15 +120,13 @@ class BufferPipeline:
         gidx = (fps + off[:, None]).reshape(-1)
         P = cfg.num_keypts
         kp, ka = cand_p[gidx].contiguous(), cand_a[gidx].contiguous()                        # [2B*P, 3]
-        patches = torch.empty((2 * B * P, cfg.num_points_per_patch, 3), dtype=torch.float32, device=dev)
-        for b in range(B):
-            g = torch.Generator(device=dev)
-            g.manual_seed(seeds[b])
-            for j, raw in enumerate((inps[b]['src_raw'], inps[b]['tgt_raw'])):
-                c = 2 * b + j
-                perm = perms[b][j] if perms is not None else torch.randperm(raw.shape[0], device=dev, generator=g)
-                ops.select_patches(raw[perm].contiguous(), kp[c * P:(c + 1) * P], cfg.des_r, cfg.num_points_per_patch,
-                                   out=patches[c * P:(c + 1) * P])
+        raws = [r for i in inps for r in (i['src_raw'], i['tgt_raw'])]
+        if perms is not None:
+            sup = torch.cat([raws[2 * b + j][perms[b][j]] for b in range(B) for j in range(2)]).contiguous()
+            sup_len = [r.shape[0] for r in raws]
+        else:                                               # one launch shuffles every cloud of the step (keyed per pair seed)
+            sup, sup_len = ops.permute_clouds(raws, [ops.perm_key(seeds[b], j) for b in range(B) for j in range(2)])
+        patches = ops.select_patches_batched(sup, sup_len, kp, P, cfg.des_r, cfg.num_points_per_patch)   # one grid, one launch
         emb = self.desc.embed_patches(patches, ka)
         desc = emb['desc'].view(B, 2, P, -1)
         _, s_idx = ops.knn(desc[:, 1].contiguous(), desc[:, 0].contiguous(), 1)            # BUFFER.py:347: ref = tgt

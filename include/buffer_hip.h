@@ -156,6 +156,18 @@ int     buf_three_nn(const float* unknown, const float* known, int b, int n, int
  * kpts f32[m,3] -> patches f32[m,nsample,3] with the keypoint in every unused slot and in the last slot. */
 int     buf_select_patches(const float* pts, const float* kpts, int n, int m, float radius, int nsample,
                            float* patches, void* stream);
+/* The same for every cloud of a step in one launch: pts f32[sum n_c,3] = the (already permuted) support clouds stacked,
+ * lengths_host int[nc], kpts f32[nc*m,3] (m keypoints per cloud) -> patches f32[nc*m,nsample,3].  Builds an A2 cell grid
+ * over the stacked clouds in `ws` and walks a per-query bitmask of in-ball points in index order (identical results to
+ * buf_select_patches cloud by cloud). */
+size_t  buf_select_patches_batched_ws_bytes(int n_total, int nc);
+int     buf_select_patches_batched(const float* pts, const int* lengths_host, int nc, const float* kpts, int m, float radius,
+                                   int nsample, float* patches, void* ws, size_t ws_bytes, void* stream);
+/* The random permutation of the support cloud that precedes the ball query (patch_embedder.py:97-98: torch.randperm) for nc
+ * clouds in one launch: out[off_c + j] = cloud_c[prp_c(j)], prp_c = a keyed pseudo-random permutation of [0, n_c) (4-round
+ * Feistel network, cycle-walked).  clouds_host: nc HOST-side pointers to DEVICE arrays f32[n_c,3]; keys_host: nc keys. */
+int     buf_permute_clouds(const float* const* clouds_host, const int* lengths_host, const unsigned long long* keys_host,
+                           int nc, float* out, void* stream);
 
 /* A5b  ordered compaction of `x > threshold` (torch.where at models/BUFFER.py:255-259): ascending indices.
  * x f32 read with element stride `stride` (score[:,0] of an [n,1] tensor: stride 1); idx_out int32[n] capacity;

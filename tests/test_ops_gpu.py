@@ -182,3 +182,52 @@ def test_row_linear_vs_torch(dev):
     assert ops.row_linear(x[:0], w, b).shape == (0, 32)
     with pytest.raises(Exception):
         ops.row_linear(torch.zeros((4, 33), device=dev), torch.zeros((2, 33), device=dev), torch.zeros((2,), device=dev))
+
+
+def test_select_patches_batched_equals_cloud_by_cloud(dev):
+    """one grid + one launch over stacked clouds (bitmask walked in index order) == the index-ordered scan per cloud:
+    sparse balls (< 511 hits: grid path), dense balls (early exit: scan path), empty balls, ragged and tiny clouds"""
+    from buffer_amd import ops
+    rng = np.random.default_rng(7)
+    clouds = [_cloud(11, 23000), _cloud(12, 9000), _cloud(13, 700), rng.random((40, 3)).astype(np.float32), _cloud(14, 30000)]
+    m = 150
+    kp = []
+    for c in clouds:
+        k = c[rng.integers(0, len(c), m)].copy()
+        k[:3] += 25.0                                   # empty balls -> slot 0 = point 0 of the cloud
+        kp.append(k)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    sup, lens = t(np.concatenate(clouds)), [len(c) for c in clouds]
+    for radius, ns in ((0.3, 512), (0.12, 64), (1.5, 512), (0.05, 16)):
+        got = ops.select_patches_batched(sup, lens, t(np.concatenate(kp)), m, radius, ns).cpu().numpy()
+        for i, c in enumerate(clouds):
+            want = ops.select_patches(t(c), t(kp[i]), radius, ns).cpu().numpy()
+            assert np.array_equal(got[i * m:(i + 1) * m], want), (radius, ns, i)
+    # a cloud beyond the bitmask capacity (> 131072 points) falls back to the scan inside the same kernel
+    big = np.concatenate([_cloud(15, 40000) + np.float32(0.002 * j) for j in range(4)])
+    kb = big[rng.integers(0, len(big), 64)]
+    got = ops.select_patches_batched(t(big), [len(big)], t(kb), 64, 0.1, 128).cpu().numpy()
+    assert np.array_equal(got, ops.select_patches(t(big), t(kb), 0.1, 128).cpu().numpy())
+    assert ops.select_patches_batched(sup, lens, t(np.zeros((0, 3), np.float32)), 0, 0.3, 512).shape == (0, 512, 3)
+
+
+def test_permute_clouds_is_a_keyed_permutation(dev):
+    from buffer_amd import ops
+    clouds = [torch.from_numpy(_cloud(21, n)).to(dev) for n in (23001, 4096, 5, 1, 777)]
+    keys = [ops.perm_key(3, j) for j in range(len(clouds))]
+    out, lens = ops.permute_clouds(clouds, keys)
+    again, _ = ops.permute_clouds(clouds, keys)
+    assert torch.equal(out, again) and lens.tolist() == [c.shape[0] for c in clouds]
+    other, _ = ops.permute_clouds(clouds, [ops.perm_key(4, j) for j in range(len(clouds))])
+    lo = 0
+    for c in clouds:
+        n = c.shape[0]
+        a, b = out[lo:lo + n].cpu().numpy(), c.cpu().numpy()
+        assert np.array_equal(a[np.lexsort(a.T)], b[np.lexsort(b.T)])                  # same rows, reordered
+        if n > 100:
+            assert (a != b).any(1).mean() > 0.99 and (a != other[lo:lo + n].cpu().numpy()).any(1).mean() > 0.99
+            # no structure left: the shuffled order is uncorrelated with the input order
+            src = {tuple(r): i for i, r in enumerate(b)}
+            pos = np.array([src[tuple(r)] for r in a])
+            assert abs(np.corrcoef(pos, np.arange(n))[0, 1]) < 4.0 / np.sqrt(n)        # a random permutation: sigma = 1/sqrt(n-1)
+        lo += n
