@@ -56,6 +56,8 @@ def parse():
     ap.add_argument('--pairs-per-step', type=int, default=None, help='pairs registered per GPU and step (pair: 32, kitti: 16)')
     ap.add_argument('--streams', type=int, default=1,
                     help='the pairs of a step are split into this many stacked batches, one host thread + HIP stream each')
+    ap.add_argument('--no-pipeline', action='store_true',
+                    help='do not overlap the keypoint stage of step i+1 with the descriptor stage of step i (two HIP streams)')
     ap.add_argument('--distinct-pairs', type=int, default=4, help='synthetic pairs generated per rank (cycled)')
     ap.add_argument('--stream-pairs', type=int, default=1623)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -267,16 +269,21 @@ def main():
             poses[j::nconc] = o
         return poses
 
-    for i in range(a.warmup):
-        step(i)
+    def run_steps(first, count):
+        """`count` steps -> list of poses.  Default: the steps are software-pipelined over two HIP streams
+        (BufferPipeline.register_batches: keypoint stage of step i+1 beside the CNN kernels of step i)."""
+        if pool is None and not a.no_pipeline:
+            ks = [[((first + i) * pps + j) % len(inputs) for j in range(pps)] for i in range(count)]
+            return [p for ps in pipe.register_batches([[inputs[k] for k in kk] for kk in ks], seeds=ks) for p in ps]
+        return [p for i in range(count) for p in step(first + i)]
+
+    run_steps(0, a.warmup)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     L.buf_timing_enable(1)
     t0 = time.perf_counter()
-    all_poses = []
-    for i in range(a.steps):
-        all_poses += step(i)
+    all_poses = run_steps(a.warmup, a.steps)
     mine = torch.stack(all_poses).to(cdev)
     gathered = None
     if dist:                                           # the path's one exchange: poses of every shard
@@ -312,7 +319,8 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': label, 'pairs_per_step_per_gpu': pps, 'streams': nconc, 'keypoints_per_fragment': keypts,
+            'config': {'workload': label, 'pairs_per_step_per_gpu': pps, 'streams': nconc,
+                       'steps_pipelined': bool(pool is None and not a.no_pipeline), 'keypoints_per_fragment': keypts,
                        'fds_points': [int(samples[0]['src_fds_pts'].shape[0]), int(samples[0]['tgt_fds_pts'].shape[0])],
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,
                        'weights': ('KITTI 06050001' if kitti else '3DMatch 06132318') + ' (released)', 'parallelism': f'pair-sharded x{world}',

@@ -83,9 +83,49 @@ class BufferPipeline:
     @torch.no_grad()
     def register_batch(self, inps, seeds=None, perms=None):
         """Several pairs through ONE set of launches per stage (the MI355X-native form: the pyramid, the VN
-        blocks, FPS (one workgroup per cloud), voxelisation, both CNNs and the 1-NN search all take the
+        blocks, FPS (one workgroup per cloud), patch selection, voxelisation, both CNNs and the 1-NN search all take the
         stacked batch; only the per-pair pose recovery loops).  inps: list of upload() dicts ->
         list of pose f32[4,4] device tensors.  Per pair the arithmetic is that of register()."""
+        return self._describe_and_match(self._keypoints(inps, seeds, perms))
+
+    @torch.no_grad()
+    def register_batches(self, batches, seeds=None):
+        """A sequence of batches, software-pipelined over two HIP streams: the keypoint stage of batch i+1 (pyramid, point
+        learner, FPS -- short kernels, FPS latency-bound on 2B of the 256 CUs) is enqueued on a high-priority side stream
+        BEFORE the descriptor / matching stage of batch i goes onto the current stream, so it runs beside the chip-filling
+        CNN kernels instead of in front of them.  Results are those of register_batch batch by batch.
+        batches: list of lists of upload() dicts; seeds: list of lists -> list of lists of poses."""
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        if not hasattr(self, '_kp_stream'):
+            self._kp_stream = torch.cuda.Stream(device=dev, priority=-1)
+        side = self._kp_stream
+        seeds = [None] * len(batches) if seeds is None else seeds
+        out = []
+
+        def stage1(i):
+            with torch.cuda.stream(side):
+                st = self._keypoints(batches[i], seeds[i], None)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return st, ev
+
+        side.wait_stream(main)
+        nxt = stage1(0) if batches else None
+        for i in range(len(batches)):
+            st, ev = nxt
+            main.wait_event(ev)
+            for t in st.get('cross', ()):                  # produced on the side stream, consumed on the current one
+                t.record_stream(main)
+            st = self._describe(st)                        # ~300 ms of CNN work queued on the current stream, no host sync
+            # the next batch's keypoint stage goes out NOW: its host round trip (per-cloud candidate counts) waits on the
+            # side stream only, while the current stream is busy with the kernels queued above
+            nxt = stage1(i + 1) if i + 1 < len(batches) else None
+            out.append(self._match(st))
+        return out
+
+    def _keypoints(self, inps, seeds, perms):
+        """pyramid -> point learner -> threshold -> FPS for a stacked batch -> state for _describe_and_match."""
         cfg, dev = self.cfg, self.device
         B = len(inps)
         if self.limits is None:
@@ -105,21 +145,36 @@ class BufferPipeline:
         axis_o = orient_axes(axis, pts0)                                                    # BUFFER.py:244-249 (row-wise)
         keep = ops.compact_greater(score[:, 0], cfg.keypts_th).long()                        # :255-259, ascending
         counts = torch.bincount(cloud_id[keep], minlength=2 * B).cpu().numpy()
-        poses = [None] * B
-        if (counts == 0).any():
-            bad = set(int(c) // 2 for c in np.nonzero(counts == 0)[0])
-            if len(bad) == B:
-                return [torch.eye(4, device=dev) for _ in range(B)]
-            good = [b for b in range(B) if b not in bad]            # rare: redo the healthy pairs one by one
-            for b in good:
-                poses[b] = self.register(inps[b], seed=seeds[b], perms=perms[b] if perms is not None else None)
-            return [p if p is not None else torch.eye(4, device=dev) for p in poses]
+        st = dict(inps=inps, seeds=seeds, perms=perms, B=B)
+        if (counts == 0).any():                             # rare: some cloud has no point above the threshold
+            st['starved'] = set(int(c) // 2 for c in np.nonzero(counts == 0)[0])
+            return st
         cand_p, cand_a = pts0[keep].contiguous(), axis_o[keep].contiguous()
         fps = ops.furthest_point_sample_ragged(cand_p, counts, cfg.num_keypts).long()       # one workgroup per cloud
         off = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)).to(dev)
         gidx = (fps + off[:, None]).reshape(-1)
+        st['kp'], st['ka'] = cand_p[gidx].contiguous(), cand_a[gidx].contiguous()           # [2B*P, 3]
+        st['cross'] = (st['kp'], st['ka'])
+        return st
+
+    def _describe_and_match(self, st):
+        """patches -> descriptors -> mutual matches -> cost volume -> per-pair pose recovery."""
+        return self._match(self._describe(st))
+
+    def _describe(self, st):
+        """patch selection, voxelisation, descriptor CNN and the two 1-NN searches of a stacked batch: everything up to
+        the first host round trip of the stage (the match count), enqueued without blocking."""
+        cfg, dev = self.cfg, self.device
+        inps, seeds, perms, B = st['inps'], st['seeds'], st['perms'], st['B']
+        poses = [None] * B
+        if 'starved' in st:
+            bad = st['starved']
+            for b in (b for b in range(B) if b not in bad):        # redo the healthy pairs one by one
+                poses[b] = self.register(inps[b], seed=seeds[b], perms=perms[b] if perms is not None else None)
+            st['poses'] = [p if p is not None else torch.eye(4, device=dev) for p in poses]
+            return st
+        kp, ka = st['kp'], st['ka']
         P = cfg.num_keypts
-        kp, ka = cand_p[gidx].contiguous(), cand_a[gidx].contiguous()                        # [2B*P, 3]
         raws = [r for i in inps for r in (i['src_raw'], i['tgt_raw'])]
         if perms is not None:
             sup = torch.cat([raws[2 * b + j][perms[b][j]] for b in range(B) for j in range(2)]).contiguous()
@@ -132,8 +187,18 @@ class BufferPipeline:
         _, s_idx = ops.knn(desc[:, 1].contiguous(), desc[:, 0].contiguous(), 1)            # BUFFER.py:347: ref = tgt
         _, t_idx = ops.knn(desc[:, 0].contiguous(), desc[:, 1].contiguous(), 1)
         s_nn, t_nn = s_idx[:, :, 0], t_idx[:, :, 0]
-        mutual = t_nn.gather(1, s_nn) == torch.arange(P, device=dev)[None]
-        mm = torch.nonzero(mutual)                                                          # (pair, s) ascending
+        st['mutual'] = t_nn.gather(1, s_nn) == torch.arange(P, device=dev)[None]
+        st['s_nn'], st['emb'] = s_nn, emb
+        return st
+
+    def _match(self, st):
+        """mutual matches (first host round trip) -> cost volume -> per-pair pose recovery."""
+        if 'poses' in st:
+            return st['poses']
+        cfg, dev = self.cfg, self.device
+        seeds, B, kp, emb, s_nn, P = st['seeds'], st['B'], st['kp'], st['emb'], st['s_nn'], self.cfg.num_keypts
+        poses = [None] * B
+        mm = torch.nonzero(st['mutual'])                                                    # (pair, s) ascending
         pair_of, s_mid = mm[:, 0], mm[:, 1]
         t_mid = s_nn[pair_of, s_mid]
         m_counts = torch.bincount(pair_of, minlength=B).cpu().numpy()
