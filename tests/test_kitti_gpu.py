@@ -50,7 +50,12 @@ def test_kitti_registration_matches_cpu_oracle(kitti_pair, dev):
         assert np.array_equal(d['kpts'][i].cpu().numpy(), wd['kpts'][i].numpy())
     assert np.array_equal(d['s_mids'].cpu().numpy(), wd['s_mids'])
     np.testing.assert_allclose(d['ind'].cpu().numpy(), wd['ind'].numpy(), rtol=1e-4, atol=5e-4)
-    np.testing.assert_allclose(pose.cpu().numpy(), want, rtol=0, atol=2e-3)
+    # 1e-4 relative on the recovered SE(3): rotation entries to 1e-4, translation to 1e-4 of the scene extent (the scan spans
+    # ~80 m; coordinates of that size carry 8e-6 m of fp32 round-off each)
+    got = pose.cpu().numpy()
+    extent = float(np.abs(kitti_pair['src_fds_pts']).max())
+    print('KITTI pose vs oracle: dR', np.abs(got[:3, :3] - want[:3, :3]).max(), 'dt', np.abs(got[:3, 3] - want[:3, 3]).max(), 'extent', extent)
+    assert np.abs(got[:3, :3] - want[:3, :3]).max() < 1e-4 and np.abs(got[:3, 3] - want[:3, 3]).max() < 1e-4 * extent
 
 
 def test_kitti_branch_vs_reference_fixture(dev):

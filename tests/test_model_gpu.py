@@ -185,3 +185,49 @@ def test_fused_cost_volume_vs_library_convs(W, dev):
         cv(a[:, :, :4].contiguous(), b[:, :, :4].contiguous())
     with pytest.raises(NotImplementedError):
         registration.CostVolume(W, dev, azi_n=18)
+
+
+def _truth64(pyr_npz, feats, Wnp, scale=1.0):
+    """the same network evaluated in float64 on the CPU (oracle/torch_ref.py is dtype-agnostic): the reference point for
+    separating fp32 conditioning from implementation error"""
+    W64 = {k: torch.from_numpy(np.asarray(v)).double() for k, v in Wnp.items()}
+    z = torch.zeros((0, 1), dtype=torch.long)
+    b = dict(points=[torch.from_numpy(pyr_npz[f'points_{l}']).double() for l in range(3)],
+             neighbors=[torch.from_numpy(pyr_npz[f'neighbors_{l}']).long() for l in range(3)],
+             pools=[torch.from_numpy(pyr_npz[f'pools_{l}']).long() for l in range(2)] + [z],
+             upsamples=[torch.from_numpy(pyr_npz[f'upsamples_{l}']).long() for l in range(2)] + [z],
+             features=torch.from_numpy(feats).double(), stack_lengths=[torch.from_numpy(pyr_npz[f'lengths_{l}']) for l in range(3)])
+    with torch.no_grad():
+        axis, eps, bottle, skips = T.efcnn_forward(b, W64, scale)
+        score = T.detnet_forward(b, bottle, skips, W64)
+    return dict(axis=axis.numpy(), eps=eps.numpy(), bottle=bottle.numpy(), score=score.numpy())
+
+
+@pytest.mark.parametrize("which", ["3dmatch", "kitti"])
+def test_point_learner_error_is_the_fp32_conditioning_of_the_network(which, dev):
+    """Why the element-wise tolerances of the point-learner tests sit above 1e-4: the REFERENCE'S OWN fp32 outputs (fixtures
+    F3 / F7) differ from the exact (float64) network by up to 5e-4 element-wise (values near zero after InstanceNorm), i.e.
+    the fixture is one fp32 summation order among many.  The bound that holds: measured against the float64 network and
+    normalised by the tensor's scale, the HIP path is as accurate as the reference's run (within 3x) and below 1e-4
+    (below three times the reference's own error where that already exceeds 3e-5: the KITTI branch at 80 m coordinates)."""
+    from buffer_amd.config import KITTI, THREEDMATCH
+    from buffer_amd.point_learner import PointLearner
+    from buffer_amd.weights import load_weights
+    cfg = KITTI if which == 'kitti' else THREEDMATCH
+    g = load('kitti_tiny.npz' if which == 'kitti' else 'pyramid_tiny.npz')
+    f = g if which == 'kitti' else load('point_learner_tiny.npz')
+    Wn = load_weights(which)
+    truth = _truth64(g, f['features'], Wn, cfg.scale)
+    pl = PointLearner(Wn, dev, cfg.scale)
+    axis, eps, bottle, skips, _ = pl.efcnn(_pyr_from_golden(g, dev), torch.from_numpy(f['features']).to(dev))
+    score = pl.detnet(_pyr_from_golden(g, dev), bottle, skips)
+    got = dict(axis=axis.cpu().numpy(), eps=eps.cpu().numpy(), score=score.cpu().numpy())
+    for k in ('axis', 'eps', 'score'):
+        scale = np.abs(truth[k]).max()
+        e_ref = np.abs(f[k] - truth[k]).max() / scale                # the reference's own fp32 run vs the exact network
+        e_hip = np.abs(got[k] - truth[k]).max() / scale
+        print(f'{which} {k}: reference fp32 vs fp64 {e_ref:.2e}, HIP vs fp64 {e_hip:.2e}, HIP vs reference '
+              f'{np.abs(got[k] - f[k]).max() / scale:.2e} (of the tensor scale {scale:.3g})')
+        # (KITTI: 80 m coordinates put the reference's own run at ~2e-4 of the exact axis; 1e-4 is not available to anyone there)
+        assert e_hip <= max(3 * e_ref, 2e-5) and e_hip < max(1e-4, 3 * e_ref), (k, e_ref, e_hip)
+        assert np.abs(got[k] - f[k]).max() <= max(1e-4, 3 * e_ref) * scale
