@@ -231,3 +231,19 @@ def test_point_learner_error_is_the_fp32_conditioning_of_the_network(which, dev)
         # (KITTI: 80 m coordinates put the reference's own run at ~2e-4 of the exact axis; 1e-4 is not available to anyone there)
         assert e_hip <= max(3 * e_ref, 2e-5) and e_hip < max(1e-4, 3 * e_ref), (k, e_ref, e_hip)
         assert np.abs(got[k] - f[k]).max() <= max(1e-4, 3 * e_ref) * scale
+
+
+def test_point_learner_honours_test_scale(W, dev):
+    """test.scale = voxel_size_0 / voxel_size_1 != 1 (generalization/*/config.py, SURVEY Appendix D: 5 for 3DMatch -> ETH):
+    the neighbour offsets are divided by it in every block (models/point_learner.py:332-343).  HIP vs the torch restatement."""
+    from buffer_amd.point_learner import PointLearner
+    g, f = load("pyramid_tiny.npz"), load("point_learner_tiny.npz")
+    for scale in (5.0, 0.5):
+        truth = _truth64(g, f['features'], W, scale)
+        pl = PointLearner(W, dev, scale)
+        axis, eps, bottle, skips, _ = pl.efcnn(_pyr_from_golden(g, dev), torch.from_numpy(f['features']).to(dev))
+        score = pl.detnet(_pyr_from_golden(g, dev), bottle, skips)
+        for k, v in (('axis', axis), ('eps', eps), ('score', score)):
+            sc = np.abs(truth[k]).max()
+            assert np.abs(v.cpu().numpy() - truth[k]).max() <= 1e-4 * sc, (scale, k)
+        assert np.abs(axis.cpu().numpy() - f['axis']).max() > 1e-3          # and it is not the scale = 1 answer

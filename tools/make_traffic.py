@@ -1,0 +1,61 @@
+"""profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected SEPARATELY, as
+MI355X_MICROARCH.md prescribes: they do not fit one pass) of the same bench.py command.
+
+    python tools/make_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <bench json line file> <out json>
+
+Units and gfx950 correction (MI355X_MICROARCH.md, HBM): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1024 B);
+FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> doubled; WRITE_SIZE taken as is."""
+import collections
+import csv
+import json
+import sys
+
+fetch_csv, write_csv, bench_file, out = sys.argv[1:5]
+bench = json.loads([l for l in open(bench_file).read().splitlines() if l.startswith('{')][-1])
+
+
+def per_launch(path, counter):
+    agg, disp = collections.defaultdict(float), collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
+        agg[k] += float(r['Counter_Value'])
+        disp[k].add(r['Dispatch_Id'])
+    return {k: agg[k] / len(disp[k]) * 1024.0 for k in agg}, {k: len(v) for k, v in disp.items()}
+
+
+fetch, n_f = per_launch(fetch_csv, 'FETCH_SIZE')
+write, n_w = per_launch(write_csv, 'WRITE_SIZE')
+cfg = bench['config']
+pairs = cfg['pairs_per_step_per_gpu']
+patches = 2 * cfg['keypoints_per_fragment'] * pairs
+cost = [o for o in bench['roofline_other'] if o['kernel'].startswith('k_cost_net')][0]
+matches = cost['avg_algorithmic_flops'] / 109085696.0
+# unit of work per launch and the algorithmic bytes per unit (SURVEY 8d formulas)
+units = {
+    'k_cyl_net': (patches, 'patch', 48 * 140 * 4 + 32 * 140 * 4),
+    'k_desc_head': (patches, 'patch', 2 * 32 * 140 * 4 + 128),
+    'k_patch_voxelize': (patches, 'patch', 12 * 512 + 4 * 16 * 420),
+    'k_select_patches_grid': (patches, 'patch', 12 * 512 + 12),
+    'k_cost_net': (matches, 'match', 2 * 3200 * 4 + 4),
+    'k_grid_query_wave': (pairs, 'pair (mean over the 7 query shapes)', None),
+    'k_vn_gather': (pairs, 'pair (mean over the 5 blocks)', None),
+    'k_nn1': (pairs, 'pair', None),
+    'k_fps': (pairs, 'pair', None),
+}
+kernels = {}
+for k, (u, unit, alg) in units.items():
+    if k not in fetch or k not in write:
+        continue
+    hbm = 2.0 * fetch[k] + write[k]
+    kernels[k] = dict(fetch_size_bytes_per_launch_raw=fetch[k], write_size_bytes_per_launch=write[k], hbm_bytes_per_launch=hbm,
+                      launches_profiled=n_f[k], units_per_launch=u, unit=unit, hbm_bytes_per_unit=hbm / u,
+                      algorithmic_bytes_per_unit=alg)
+json.dump(dict(source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on the bench.py command of '
+                      'the line in `bench`; per-dispatch means',
+               correction='gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; '
+                          'counters are in KB (1024 B)',
+               bench=dict(value=bench['value'], config=cfg), kernels=kernels), open(out, 'w'), indent=1)
+for k, v in kernels.items():
+    print(f"{k:26s} {v['hbm_bytes_per_unit']:12.1f} B per {v['unit']}" + (f"   (algorithmic {v['algorithmic_bytes_per_unit']})" if v['algorithmic_bytes_per_unit'] else ''))
