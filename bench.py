@@ -310,7 +310,7 @@ def main():
         torch.cuda.synchronize()
         L.buf_timing_enable(0)
         timed_alone = collect_timed(L)
-    gts = [samples[n % len(samples)]['relt_pose'] for n in range(len(all_poses))]
+    gts = [samples[(a.warmup * pps + n) % len(samples)]['relt_pose'] for n in range(len(all_poses))]    # step i, slot j -> pair (i*pps + j) mod distinct
     ok = dgr_ok(mine.cpu().numpy(), gts)
 
     if rank == 0:
