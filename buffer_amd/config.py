@@ -44,3 +44,14 @@ THREEDMATCH = Config()
 KITTI = replace(Config(), dataset='KITTI', downsample=0.05, voxel_size_0=0.30, voxel_size_1=0.30, max_num_pts=40000,
                 keypts_th=0.5, des_r=3.0, dist_th=0.30, inlier_th=2.0, similar_th=0.9, confidence=1.0,
                 pose_refine=False, refine_threshold=1.2, weights='kitti')
+
+# Cross-dataset experiments of the reference (generalization/*/config.py): data constants of the TARGET
+# data set, weights of the SOURCE data set, test.scale = voxel_size_0 / voxel_size_1 rescaling the neighbour offsets.
+THREEDMATCH_TO_KITTI = replace(KITTI, voxel_size_1=0.03, weights='3dmatch')                         # generalization/ThreeD2KITTI
+THREEDMATCH_TO_ETH = replace(Config(), dataset='ETH', downsample=0.05, voxel_size_0=0.15, voxel_size_1=0.03, keypts_th=0.5,
+                             des_r=1.0, dist_th=0.20, inlier_th=1.5, similar_th=0.9, confidence=1.0, pose_refine=False,
+                             refine_threshold=0.10, weights='3dmatch')                                  # generalization/ThreeD2ETH
+KITTI_TO_ETH = replace(THREEDMATCH_TO_ETH, voxel_size_1=0.30, inlier_th=2.0, weights='kitti')           # generalization/KITTI2ETH
+KITTI_TO_3DLOMATCH = replace(Config(), dataset='3DLoMatch', voxel_size_1=0.30, keypts_th=0.0, weights='kitti')   # generalization/KITTI2ThreeD
+PRESETS = {'3DMatch': THREEDMATCH, 'KITTI': KITTI, '3DMatch->KITTI': THREEDMATCH_TO_KITTI, '3DMatch->ETH': THREEDMATCH_TO_ETH,
+           'KITTI->ETH': KITTI_TO_ETH, 'KITTI->3DLoMatch': KITTI_TO_3DLOMATCH}

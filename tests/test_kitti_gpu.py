@@ -89,3 +89,22 @@ def test_kitti_branch_vs_reference_fixture(dev):
     np.testing.assert_allclose(out['rand_axis'].cpu().numpy(), f['rand_axis'], rtol=0, atol=2e-6)
     np.testing.assert_allclose(out['desc'].cpu().numpy(), f['desc'], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(out['equi'].cpu().numpy(), f['equi'], rtol=1e-4, atol=2e-5)
+
+
+def test_cross_dataset_presets(kitti_pair, dev):
+    """generalization/*/config.py as presets: target-data constants, source-data weights, test.scale = voxel_size_0 / voxel_size_1.
+    3DMatch weights on the KITTI-shape pair (generalization/ThreeD2KITTI: scale 10) registers it."""
+    from buffer_amd import config as C
+    from buffer_amd.pipeline import BufferPipeline
+    assert abs(C.THREEDMATCH_TO_KITTI.scale - 10.0) < 1e-9 and abs(C.THREEDMATCH_TO_ETH.scale - 5.0) < 1e-9
+    assert abs(C.KITTI_TO_ETH.scale - 0.5) < 1e-9 and abs(C.KITTI_TO_3DLOMATCH.scale - 0.035 / 0.30) < 1e-9
+    assert C.THREEDMATCH_TO_KITTI.weights == '3dmatch' and C.KITTI_TO_3DLOMATCH.weights == 'kitti' and not C.THREEDMATCH_TO_ETH.pose_refine
+    cfg = replace(C.THREEDMATCH_TO_KITTI, num_keypts=1500)
+    pipe = BufferPipeline(cfg, dev)
+    pipe.calibrate([kitti_pair])
+    pose = pipe.register(pipe.upload(kitti_pair), seed=0).cpu().numpy().astype(np.float64)
+    gt = kitti_pair['relt_pose']
+    rte = np.linalg.norm(pose[:3, 3] - gt[:3, 3])
+    rre = np.degrees(np.arccos(np.clip((np.trace(pose[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
+    print('3DMatch->KITTI on the synthetic scan pair: RTE', rte, 'RRE', rre)
+    assert np.isfinite(pose).all() and rte < 0.6 and rre < 5.0, (rte, rre)

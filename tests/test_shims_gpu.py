@@ -64,3 +64,46 @@ def test_pointnet2_knn_svd_shims(oracle, dev):
     a = torch.from_numpy(rng.normal(size=(50, 3, 3)).astype(np.float32)).to(dev)
     u, s, v = svd(a)
     np.testing.assert_allclose(((u * s[:, None]) @ v.transpose(1, 2)).cpu().numpy(), a.cpu().numpy(), atol=2e-5)
+
+
+def test_subsample_label_voting(dev):
+    """classes= of subsample_batch / subsample (grid_subsampling.cpp:97-103): majority label per voxel and label column,
+    returned after the features like the CPython module does"""
+    import buffer_amd.shims as shims
+    shims.install()
+    import cpp_wrappers.cpp_subsampling.grid_subsampling as cpp_subsampling
+    d = synth.make_config1_pair()
+    pts = np.concatenate([d['src_sds_pts'][:, :3], d['tgt_sds_pts'][:, :3]]).astype(np.float32)
+    lens = np.array([5000, 5000], np.int32)
+    rng = np.random.default_rng(3)
+    labels = np.stack([(pts[:, 0] > np.median(pts[:, 0])).astype(np.int32) * 7 + (rng.random(len(pts)) < 0.2),      # noisy halves
+                       rng.integers(-3, 4, len(pts))], 1).astype(np.int32)
+    dl = 0.12
+    sp, sl, sf, sc = cpp_subsampling.subsample_batch(pts, lens, features=pts, classes=labels, sampleDl=dl)
+    assert sc.dtype == np.int32 and sc.shape == (sp.shape[0], 2) and sf.shape == sp.shape
+    # independent grouping: the reference's voxel key per batch element (grid_subsampling.cpp:40-60), majority by counting
+    lo = 0
+    row = 0
+    for n in lens:
+        p, lab = pts[lo:lo + n], labels[lo:lo + n]
+        origin = np.floor(p.min(0) * np.float32(1.0 / dl)) * np.float32(dl)
+        key = np.floor((p - origin) / np.float32(dl)).astype(np.int64)
+        groups = {}
+        for i, k in enumerate(map(tuple, key)):
+            groups.setdefault(k, []).append(i)
+        bary = {k: p[v].astype(np.float64).mean(0) for k, v in groups.items()}
+        m = int(sl[0] if lo == 0 else sl[1])
+        assert m == len(groups)
+        mine = sp[row:row + m]
+        for k, v in groups.items():
+            j = int(np.argmin(((mine - bary[k]) ** 2).sum(1)))
+            assert np.abs(mine[j] - bary[k]).max() < 1e-5
+            for dcol in range(2):
+                vals, cnt = np.unique(lab[v, dcol], return_counts=True)
+                assert sc[row + j, dcol] == vals[np.argmax(cnt)]          # ties -> smallest label (np.unique is ascending)
+        lo += n
+        row += m
+    one_p, one_c = cpp_subsampling.subsample(pts[:5000], classes=labels[:5000, 0], sampleDl=dl)
+    assert np.array_equal(one_c[:, 0], sc[:sl[0], 0]) and np.array_equal(one_p, sp[:sl[0]])
+    with pytest.raises(RuntimeError):
+        cpp_subsampling.subsample_batch(pts, lens, classes=labels[:-1], sampleDl=dl)
