@@ -377,7 +377,7 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
     poses = []
     for lo in range(0, len(ids), batch):
         chunk = range(lo, min(lo + batch, len(ids)))
-        inps = [upload(stream.prepare(mine[j], cfg, ids[j])) for j in chunk]
+        inps = [upload(x) for x in stream.prepare_batch([mine[j] for j in chunk], cfg, [ids[j] for j in chunk])]
         poses += pipe.register_batch(inps, seeds=[ids[j] for j in chunk])
     local_poses = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
     if world > 1:

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import preprocess
-from .threedmatch import upload  # the same device-sample -> pipeline-input packing
+from .threedmatch import items_batched, upload  # the same device-sample -> pipeline-input packing
 
 TEST_DRIVES = (8, 9, 10)                                            # KITTI/test_kitti.txt
 VELO2CAM = np.vstack((np.hstack([np.array([7.533745e-03, -9.999714e-01, -6.166020e-04, 1.480249e-02, 7.280733e-04, -9.998902e-01,
@@ -113,10 +113,18 @@ class KittiTestSet:
         self.gt_source[index] = 'icp-device'
         return M2
 
+    def raw_pair(self, index):
+        drive, t0, t1 = self.files[index]
+        return self.scan(drive, t0), self.scan(drive, t1)
+
+    def meta(self, index, device=None):
+        drive, t0, t1 = self.files[index]
+        return {'src_id': f'{drive:02d}/{t0:06d}', 'tgt_id': f'{drive:02d}/{t1:06d}', 'relt_pose': self.ground_truth(index, device)}
+
     def item(self, index, device, seed=None):
         """dataset.py:72-178 (test branch) -> sample dict of device tensors (+ relt_pose)."""
         drive, t0, t1 = self.files[index]
-        out = {'src_id': f'{drive:02d}/{t0:06d}', 'tgt_id': f'{drive:02d}/{t1:06d}', 'relt_pose': self.ground_truth(index, device)}
+        out = self.meta(index, device)
         for side, t in (('src', t0), ('tgt', t1)):
             it = preprocess.prepare_fragment(torch.from_numpy(self.scan(drive, t)).to(device), self.downsample,
                                              self.voxel_size_0, self.max_num_pts, seed=2 * index + (side == 'tgt') if seed is None else seed)
@@ -130,7 +138,7 @@ def register_pairs(pipe, dataset, indices, batch=4):
     idx = list(indices)
     for lo in range(0, len(idx), batch):
         chunk = idx[lo:lo + batch]
-        poses += pipe.register_batch([upload(dataset.item(i, dev)) for i in chunk], seeds=chunk)
+        poses += pipe.register_batch([upload(s) for s in items_batched(dataset, chunk, dev)], seeds=chunk)
     return torch.stack(poses) if poses else torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
 
 

@@ -42,9 +42,11 @@ def voxel_down_sample(points, voxel_size, normals=None, max_cells=0):
     return out[:m.value]
 
 
-def estimate_normals(points, knn=30, camera=(0.0, 0.0, 0.0), orient=True, radius=None, ncand=40, grow=1.35):
+def estimate_normals(points, knn=30, camera=(0.0, 0.0, 0.0), orient=True, radius=None, ncand=40, grow=1.35, lengths=None):
     """open3d estimate_normals(KDTreeSearchParamKNN(knn)) [+ orient_normals_towards_camera_location(camera)]:
-    points f32[n,3] (device) -> unit normals f32[n,3].
+    points f32[n,3] (device) -> unit normals f32[n,3].  `lengths` (optional): the rows are several clouds stacked
+    (neighbours are searched inside a point's own cloud) -- one set of launches for all of them; the normals equal those of
+    cloud-by-cloud calls (each point ends with its exact knn nearest neighbours either way).
 
     k-NN through the cell grid of the radius search: candidates = the `ncand` nearest inside a ball (fp32, sorted), re-ranked
     in fp64 by the kernel; rows whose ball held fewer than min(knn, n) points are retried with a `grow` times larger
@@ -55,22 +57,34 @@ def estimate_normals(points, knn=30, camera=(0.0, 0.0, 0.0), orient=True, radius
     out = torch.zeros((n, 3), dtype=torch.float32, device=pts.device)
     if n == 0:
         return out
+    lens = np.array([n], np.int32) if lengths is None else np.asarray(lengths, np.int32)
+    if int(lens.sum()) != n:
+        raise _lib.BufferHipError("estimate_normals: lengths do not sum to the number of points")
+    if len(lens) > 1 and int(lens[lens > 0].min()) <= knn:       # a cloud smaller than the neighbourhood: one by one
+        lo = 0
+        for m in lens:
+            out[lo:lo + m] = estimate_normals(pts[lo:lo + m], knn, camera, orient, radius, ncand, grow)
+            lo += int(m)
+        return out
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     ncand = max(int(ncand), int(knn))
     if radius is None:
-        # pilot: distance to the knn-th neighbour for a few hundred queries (plumbing; sets only the first radius)
+        # pilot: distance to the knn-th neighbour for a few hundred queries of the first cloud (plumbing; sets only the first radius)
+        n0 = int(lens[0]) if int(lens[0]) > knn else n
         g = torch.Generator(device=pts.device).manual_seed(0)
-        sel = torch.randperm(n, generator=g, device=pts.device)[:256]
-        d = torch.cdist(pts[sel].double(), pts.double())
-        kth = torch.topk(d, min(int(knn), n), dim=1, largest=False).values[:, -1]
+        sel = torch.randperm(n0, generator=g, device=pts.device)[:256]
+        d = torch.cdist(pts[:n0][sel].double(), pts[:n0].double())
+        kth = torch.topk(d, min(int(knn), n0), dim=1, largest=False).values[:, -1]
         radius = float(kth.median().item()) * 1.1 + 1e-9
     cam = (C.c_double * 3)(*[float(c) for c in camera])
     todo = None
+    q_lens = lens
     r = float(radius)
     for _ in range(200):
-        grid = ops.CellGrid(pts, [n], r)
+        grid = ops.CellGrid(pts, lens, r)
         q = pts if todo is None else pts[todo.long()].contiguous()
         nq = int(q.shape[0])
-        cand = grid.query(q, [nq], ncand)
+        cand = grid.query(q, q_lens, ncand)
         deficient = torch.empty((nq,), dtype=torch.uint8, device=pts.device)
         check(L.buf_knn_normals(_ptr(pts), n, _ptr(todo), nq, _ptr(cand), ncand, int(knn), cam, 1 if orient else 0,
                                 _ptr(out), _ptr(deficient), _stream()), "buf_knn_normals")
@@ -78,23 +92,46 @@ def estimate_normals(points, knn=30, camera=(0.0, 0.0, 0.0), orient=True, radius
         if bad.numel() == 0:
             return out
         todo = bad if todo is None else todo[bad.long()].contiguous()
+        if len(lens) > 1:                                        # retried rows per cloud (ascending indices)
+            t_host = todo.cpu().numpy()
+            q_lens = np.diff(np.searchsorted(t_host, offs)).astype(np.int32)
+        else:
+            q_lens = np.array([todo.shape[0]], np.int32)
         r *= grow
     raise _lib.BufferHipError("estimate_normals: neighbourhood search did not converge")
 
 
+def prepare_fragments(raws, downsample, voxel_size_0, max_num_pts=30000, seeds=None, with_normals=True):
+    """The test-split branch of ThreeDMatchDataset.__getitem__ (dataset.py:93-95,125-153) for SEVERAL fragments:
+    raws: list of f32[n,3] device tensors -> list of dict(fds_pts f32[N,3] shuffled, sds_pts f32[M,6] = shuffled
+    second-level points + normals).  The two voxel levels and the shuffles run per fragment (second level on the first
+    level's fp64 means, like open3d's chained calls; fragment i shuffles with generator seed seeds[i]); the 30-NN normals of
+    all fragments are estimated in ONE stacked pass.  Fragment by fragment the result is that of prepare_fragment."""
+    seeds = list(range(len(raws))) if seeds is None else list(seeds)
+    out, sds_all = [], []
+    for raw, seed in zip(raws, seeds):
+        dev = raw.device
+        g = torch.Generator(device=dev).manual_seed(int(seed))
+        fds = voxel_down_sample(raw, downsample)
+        sds = voxel_down_sample(fds, voxel_size_0)
+        fds32 = fds[torch.randperm(fds.shape[0], generator=g, device=dev)].float()             # np.random.shuffle
+        sds32 = sds[torch.randperm(sds.shape[0], generator=g, device=dev)].float()
+        if sds32.shape[0] > max_num_pts:                                                       # dataset.py:131-137
+            sds32 = sds32[torch.randperm(sds32.shape[0], generator=g, device=dev)[:max_num_pts]]
+        out.append(dict(fds_pts=fds32.contiguous()))
+        sds_all.append(sds32.contiguous())
+    if with_normals and sds_all:
+        lens = [int(s.shape[0]) for s in sds_all]
+        nrm = estimate_normals(torch.cat(sds_all), lengths=lens)
+        lo = 0
+        for i, s in enumerate(sds_all):
+            sds_all[i] = torch.cat([s, nrm[lo:lo + lens[i]]], dim=1).contiguous()
+            lo += lens[i]
+    for o, s in zip(out, sds_all):
+        o['sds_pts'] = s
+    return out
+
+
 def prepare_fragment(raw_points, downsample, voxel_size_0, max_num_pts=30000, seed=0, with_normals=True):
-    """The test-split branch of ThreeDMatchDataset.__getitem__ for one fragment (dataset.py:93-95,125-153):
-    raw f32[n,3] -> dict(fds_pts f32[N,3] shuffled, sds_pts f32[M,6] = shuffled second-level points + normals).
-    The second voxel level is taken on the first level's fp64 means, like open3d's chained calls."""
-    dev = raw_points.device
-    g = torch.Generator(device=dev).manual_seed(int(seed))
-    fds = voxel_down_sample(raw_points, downsample)
-    sds = voxel_down_sample(fds, voxel_size_0)
-    fds32 = fds[torch.randperm(fds.shape[0], generator=g, device=dev)].float()             # np.random.shuffle
-    sds32 = sds[torch.randperm(sds.shape[0], generator=g, device=dev)].float()
-    if sds32.shape[0] > max_num_pts:                                                       # dataset.py:131-137
-        sds32 = sds32[torch.randperm(sds32.shape[0], generator=g, device=dev)[:max_num_pts]]
-    if with_normals:
-        nrm = estimate_normals(sds32)
-        sds32 = torch.cat([sds32, nrm], dim=1)
-    return dict(fds_pts=fds32.contiguous(), sds_pts=sds32.contiguous())
+    """One fragment of prepare_fragments: raw f32[n,3] -> dict(fds_pts f32[N,3] shuffled, sds_pts f32[M,6])."""
+    return prepare_fragments([raw_points], downsample, voxel_size_0, max_num_pts, [seed], with_normals)[0]

@@ -30,6 +30,14 @@ def prepare(raw, cfg, index):
     return out
 
 
+def prepare_batch(raws, cfg, indices):
+    """prepare() for several raw pairs with the normals of all 2B fragments estimated in one stacked pass (same result)"""
+    frs = preprocess.prepare_fragments([r[f'{side}_raw'] for r in raws for side in ('src', 'tgt')], cfg.downsample,
+                                       cfg.voxel_size_0, cfg.max_num_pts, seeds=[2 * i + j for i in indices for j in range(2)])
+    return [{'relt_pose': r['relt_pose'], 'src_fds_pts': frs[2 * k]['fds_pts'], 'src_sds_pts': frs[2 * k]['sds_pts'],
+             'tgt_fds_pts': frs[2 * k + 1]['fds_pts'], 'tgt_sds_pts': frs[2 * k + 1]['sds_pts']} for k, r in enumerate(raws)]
+
+
 def run(pipe, raws, batch=16, first_index=0):
     """Timed part: pre-processing + registration of every pair, `batch` pairs per set of stacked launches.
     -> (poses f32[n,4,4] device, seconds, seconds spent in pre-processing (device-synchronised only at the end of run))."""
@@ -39,7 +47,7 @@ def run(pipe, raws, batch=16, first_index=0):
     t0 = time.perf_counter()
     for lo in range(0, len(raws), batch):
         ids = range(lo, min(lo + batch, len(raws)))
-        inps = [upload(prepare(raws[i], pipe.cfg, first_index + i)) for i in ids]
+        inps = [upload(s) for s in prepare_batch([raws[i] for i in ids], pipe.cfg, [first_index + i for i in ids])]
         poses += pipe.register_batch(inps, seeds=[first_index + i for i in ids])
     out = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
     torch.cuda.synchronize(dev)

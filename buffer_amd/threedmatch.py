@@ -111,17 +111,44 @@ class ThreeDMatchTestSet:
     def __len__(self):
         return len(self.files)
 
+    def raw_pair(self, index):
+        """the two fragments of pair `index` as read from disk: (f32[n,3], f32[m,3]) numpy"""
+        return tuple(read_ply(os.path.join(self.root, fid + '.ply')) for fid in self.files[index])
+
+    def meta(self, index, device=None):
+        src_id, tgt_id = self.files[index]
+        return {'src_id': src_id, 'tgt_id': tgt_id, 'relt_pose': np.linalg.inv(self.poses[index])}      # dataset.py:122
+
     def item(self, index, device, seed=None):
         """dataset.py:80-162 (test branch): read both fragments, two voxel levels, shuffles, normals -- on the device.
         -> the sample dict of the reference, holding DEVICE tensors (+ src_id, tgt_id)."""
         src_id, tgt_id = self.files[index]
-        out = {'src_id': src_id, 'tgt_id': tgt_id, 'relt_pose': np.linalg.inv(self.poses[index])}      # :122
+        out = self.meta(index)
         for side, fid in (('src', src_id), ('tgt', tgt_id)):
             raw = torch.from_numpy(read_ply(os.path.join(self.root, fid + '.ply'))).to(device)
             it = preprocess.prepare_fragment(raw, self.downsample, self.voxel_size_0, self.max_num_pts,
                                              seed=2 * index + (side == 'tgt') if seed is None else seed)
             out[f'{side}_fds_pts'], out[f'{side}_sds_pts'] = it['fds_pts'], it['sds_pts']
         return out
+
+
+def items_batched(dataset, indices, device):
+    """dataset.item(i, device) for several pairs with the normals of all fragments estimated in ONE stacked pass
+    (preprocess.prepare_fragments); pair by pair the result is that of item()."""
+    idx = list(indices)
+    raws, seeds = [], []
+    for i in idx:
+        for j, raw in enumerate(dataset.raw_pair(i)):
+            raws.append(torch.from_numpy(raw).to(device))
+            seeds.append(2 * i + j)
+    frs = preprocess.prepare_fragments(raws, dataset.downsample, dataset.voxel_size_0, dataset.max_num_pts, seeds)
+    out = []
+    for k, i in enumerate(idx):
+        s = dataset.meta(i, device)
+        s.update(src_fds_pts=frs[2 * k]['fds_pts'], src_sds_pts=frs[2 * k]['sds_pts'],
+                 tgt_fds_pts=frs[2 * k + 1]['fds_pts'], tgt_sds_pts=frs[2 * k + 1]['sds_pts'])
+        out.append(s)
+    return out
 
 
 def upload(sample):
@@ -139,8 +166,7 @@ def register_pairs(pipe, dataset, indices, batch=8):
     idx = list(indices)
     for lo in range(0, len(idx), batch):
         chunk = idx[lo:lo + batch]
-        samples = [dataset.item(i, dev) for i in chunk]
-        poses += pipe.register_batch([upload(s) for s in samples], seeds=chunk)
+        poses += pipe.register_batch([upload(s) for s in items_batched(dataset, chunk, dev)], seeds=chunk)
     return torch.stack(poses) if poses else torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
 
 

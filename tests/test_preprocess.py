@@ -192,3 +192,20 @@ def test_prepare_fragment_kitti_scale(oracle, dev):
     want_n = oracle.o3d_estimate_normals(sds[:, :3].cpu().numpy(), knn=30)
     dots = (n.cpu().numpy() * want_n).sum(1)
     assert np.mean(dots > 1 - 1e-6) > 0.99 and np.all(dots > 1 - 1e-3), (float(np.mean(dots > 1 - 1e-6)), float(dots.min()))
+
+
+@pytest.mark.gpu
+def test_prepare_fragments_stacked_normals_equal_one_by_one(dev):
+    """prepare_fragments (one stacked normal-estimation pass over all fragments) == prepare_fragment fragment by fragment,
+    bit for bit, including a tiny cloud (fewer points than the 30-neighbourhood)"""
+    import torch
+    from buffer_amd import preprocess, stream
+    raws = stream.generate(3, dev, n_raw=120_000)
+    clouds = [r[k] for r in raws for k in ('src_raw', 'tgt_raw')] + [raws[0]['src_raw'][:200].contiguous()]
+    seeds = [7, 8, 9, 10, 11, 12, 13]
+    got = preprocess.prepare_fragments(clouds, 0.02, 0.035, 30000, seeds)
+    for c, s, g in zip(clouds, seeds, got):
+        want = preprocess.prepare_fragment(c, 0.02, 0.035, 30000, s)
+        assert torch.equal(g['fds_pts'], want['fds_pts']) and torch.equal(g['sds_pts'], want['sds_pts'])
+    nrm = got[0]['sds_pts'][:, 3:]
+    assert torch.allclose(nrm.norm(dim=1), torch.ones_like(nrm[:, 0]), atol=1e-5)
