@@ -374,11 +374,9 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
         dist.barrier()
     L.buf_timing_enable(1)
     t0 = time.perf_counter()
-    poses = []
-    for lo in range(0, len(ids), batch):
-        chunk = range(lo, min(lo + batch, len(ids)))
-        inps = [upload(x) for x in stream.prepare_batch([mine[j] for j in chunk], cfg, [ids[j] for j in chunk])]
-        poses += pipe.register_batch(inps, seeds=[ids[j] for j in chunk])
+    chunks = [list(range(lo, min(lo + batch, len(ids)))) for lo in range(0, len(ids), batch)]
+    makers = [(lambda ch=ch: [upload(x) for x in stream.prepare_batch([mine[j] for j in ch], cfg, [ids[j] for j in ch])]) for ch in chunks]
+    poses = [p for ps in pipe.register_batches(makers, seeds=[[ids[j] for j in ch] for ch in chunks]) for p in ps]
     local_poses = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
     if world > 1:
         bdist.gather_poses(ids, local_poses, n, device=cdev)

@@ -94,7 +94,9 @@ class BufferPipeline:
         learner, FPS -- short kernels, FPS latency-bound on 2B of the 256 CUs) is enqueued on a high-priority side stream
         BEFORE the descriptor / matching stage of batch i goes onto the current stream, so it runs beside the chip-filling
         CNN kernels instead of in front of them.  Results are those of register_batch batch by batch.
-        batches: list of lists of upload() dicts; seeds: list of lists -> list of lists of poses."""
+        batches: list of lists of upload() dicts -- or of callables returning such a list, which are then evaluated on the side
+        stream as part of the keypoint stage (device pre-processing of the next batch beside the CNN kernels of this one);
+        seeds: list of lists -> list of lists of poses."""
         dev = self.device
         main = torch.cuda.current_stream(dev)
         if not hasattr(self, '_kp_stream'):
@@ -105,7 +107,10 @@ class BufferPipeline:
 
         def stage1(i):
             with torch.cuda.stream(side):
-                st = self._keypoints(batches[i], seeds[i], None)
+                inps = batches[i]() if callable(batches[i]) else batches[i]
+                st = self._keypoints(inps, seeds[i], None)
+                if callable(batches[i]):                   # inputs made on the side stream are read on the current one too
+                    st['cross'] = tuple(st.get('cross', ())) + tuple(v for x in inps for v in x.values() if isinstance(v, torch.Tensor))
                 ev = torch.cuda.Event()
                 ev.record(side)
             return st, ev

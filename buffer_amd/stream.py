@@ -39,19 +39,20 @@ def prepare_batch(raws, cfg, indices):
 
 
 def run(pipe, raws, batch=16, first_index=0):
-    """Timed part: pre-processing + registration of every pair, `batch` pairs per set of stacked launches.
-    -> (poses f32[n,4,4] device, seconds, seconds spent in pre-processing (device-synchronised only at the end of run))."""
+    """Timed part: pre-processing + registration of every pair, `batch` pairs per set of stacked launches, batches
+    software-pipelined (BufferPipeline.register_batches: pre-processing and keypoint stage of batch i+1 on the side stream
+    beside the CNN kernels of batch i).  -> (poses f32[n,4,4] device, seconds)."""
     dev = pipe.device
-    poses = []
+    chunks = [list(range(lo, min(lo + batch, len(raws)))) for lo in range(0, len(raws), batch)]
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for lo in range(0, len(raws), batch):
-        ids = range(lo, min(lo + batch, len(raws)))
-        inps = [upload(s) for s in prepare_batch([raws[i] for i in ids], pipe.cfg, [first_index + i for i in ids])]
-        poses += pipe.register_batch(inps, seeds=[first_index + i for i in ids])
-    out = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
+    makers = [(lambda ids=ids: [upload(s) for s in prepare_batch([raws[i] for i in ids], pipe.cfg, [first_index + i for i in ids])])
+              for ids in chunks]
+    out = pipe.register_batches(makers, seeds=[[first_index + i for i in ids] for ids in chunks])
+    poses = [p for ps in out for p in ps]
+    res = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
     torch.cuda.synchronize(dev)
-    return out, time.perf_counter() - t0
+    return res, time.perf_counter() - t0
 
 
 def evaluate_stream(raws, poses, first_index=0):
