@@ -8,7 +8,7 @@
  *
  * Pinning: orc_grid_subsample_batch / orc_radius_neighbors are checked against
  * the reference's own compiled cores (oracle/_ref, built from /root/reference
- * in place) by tests/test_oracle_vs_ref.py and against tests/golden/pyramid_*.npz.
+ * in place) by tests/test_oracle_vs_ref.py (3DMatch-size and KITTI-shape pyramids) and against tests/golden/pyramid_*.npz.
  * orc_fps / orc_ball_query / orc_three_nn / orc_knn restate third-party CUDA
  * extensions that are NOT under /root/reference (pointnet2_ops unpinned git,
  * KNN_CUDA 0.2): parity UNPINNED for those four.
