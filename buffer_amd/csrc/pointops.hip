@@ -459,7 +459,7 @@ extern "C" int buf_permute_clouds(const float* const* clouds_host, const int* le
         B.off[0] = 0;
         for (int i = 0; i < cnt; i++) {
             const int n = lengths_host[c0 + i];
-            BUF_REQUIRE(n >= 0 && (n == 0 || clouds_host[c0 + i]), BUF_EINVAL, "buf_permute_clouds: cloud %d", c0 + i);
+            BUF_REQUIRE(n >= 0 && n < (1 << 30) && (n == 0 || clouds_host[c0 + i]), BUF_EINVAL, "buf_permute_clouds: cloud %d (n=%d)", c0 + i, n);
             B.src[i] = clouds_host[c0 + i]; B.key[i] = keys_host[c0 + i]; B.off[i + 1] = B.off[i] + n;
             nmax = n > nmax ? n : nmax;
         }
