@@ -59,7 +59,9 @@ def parse():
     ap.add_argument('--no-pipeline', action='store_true',
                     help='do not overlap the keypoint stage of step i+1 with the descriptor stage of step i (two HIP streams)')
     ap.add_argument('--distinct-pairs', type=int, default=4, help='synthetic pairs generated per rank (cycled)')
-    ap.add_argument('--stream-pairs', type=int, default=1623)
+    ap.add_argument('--stream-pairs', type=int, default=1623, help='1623 = 3DMatch test set, 1781 = 3DLoMatch')
+    ap.add_argument('--stream-overlaps', default=None,
+                    help='overlap classes of the synthetic stream, equal shares (default 0.75,0.6,0.45,0.3; a 3DLoMatch-like set: 0.3,0.25,0.2,0.15)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -364,7 +366,8 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
     pipe = BufferPipeline(cfg, dev)
     n = a.stream_pairs
     ids = list(bdist.shard_indices(n, rank, world))
-    mine = [synth.make_raw_pair_device(20000 + i, stream.OVERLAPS[i % len(stream.OVERLAPS)], dev) for i in ids]
+    overlaps = tuple(float(x) for x in a.stream_overlaps.split(',')) if a.stream_overlaps else stream.OVERLAPS
+    mine = [synth.make_raw_pair_device(20000 + i, overlaps[i % len(overlaps)], dev) for i in ids]
     first = stream.prepare(synth.make_raw_pair_device(20000, stream.OVERLAPS[0], dev), cfg, 0)     # same pair on every rank
     limits = pipe.calibrate([{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in first.items()}])
     batch = a.pairs_per_step or 16
@@ -399,7 +402,7 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
             'ms_per_step': elapsed * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': f'{n} synthetic 3DMatch-shape pairs streamed from raw clouds, pre-processing included '
-                                   f'(BASELINE configs[2]); overlaps {list(stream.OVERLAPS)} in equal shares',
+                                   f'(BASELINE configs[2]); overlaps {list(overlaps)} in equal shares',
                        'keypoints_per_fragment': cfg.num_keypts, 'pairs_per_launch': batch, 'neighbor_limits': limits,
                        'parallelism': f'pair-sharded x{world}'},
             'quality': quality, 'roofline': main_roof, 'roofline_other': other}), flush=True)

@@ -9,6 +9,7 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 python bench.py --workload stream > $O/stream.json 2>> $O/bench.err
+python bench.py --workload stream --stream-pairs 1781 --stream-overlaps 0.3,0.25,0.2,0.15 > $O/stream_lomatch.json 2>> $O/bench.err
 python bench.py --workload kitti --steps 6 --warmup 2 --no-cpu-baseline > $O/kitti.json 2>> $O/bench.err
 python bench.py --pairs-per-step 64 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_64pairs.json 2>> $O/bench.err
 tools/prof.sh ${tag}_stats stats -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline
