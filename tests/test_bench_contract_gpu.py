@@ -65,3 +65,32 @@ def test_bench_kitti_and_stream_workloads(dev):
     s = _run(['--workload', 'stream', '--stream-pairs', '24', '--pairs-per-step', '8', '--keypts', '600'])
     assert 'configs[2]' in s['config']['workload'] and s['quality']['pairs'] == 24 and len(s['quality']['per_scene']) == 8
     assert s['quality']['dgr_recall'] >= 0.8 and s['value'] > 0
+
+
+def test_rccl_collectives_of_the_multi_gpu_path_run_on_this_box(dev):
+    """The collectives bench.py / dist.py issue at N > 1 (backend 'nccl' = RCCL: barrier, all_gather of f32 poses, all_reduce MAX
+    of an f64 time, broadcast of int64 limits) on a world of ONE rank over the real RCCL backend -- what a 1-GPU box can check
+    of the RCCL side; rank arithmetic and gathers are covered over gloo with two ranks."""
+    code = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from buffer_amd import dist as bd
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+dist.barrier()
+mine = torch.eye(4, device=dev).repeat(5, 1, 1)
+out = [torch.empty_like(mine)]
+dist.all_gather(out, mine)
+assert torch.equal(out[0], mine)
+t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.item() == 1.25
+assert bd.broadcast_limits([17, 20, 24], device=dev) == [17, 20, 24]
+allp = bd.gather_poses([0, 1, 2], torch.eye(4, device=dev).repeat(3, 1, 1) * 2, 3, device=dev)
+assert allp.shape == (3, 4, 4) and float(allp[2, 0, 0]) == 2.0
+dist.destroy_process_group()
+print("rccl ok")
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and 'rccl ok' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
