@@ -101,6 +101,19 @@ def test_c_abi_error_codes(dev):
     assert rc == -1
     rc = L.buf_vn_gather_block(None, None, None, None, 10, 10, 4, 2, 4, 3, 1.0, None, None, None, None, 0.2, None, s)
     assert rc == -1 and b"mode" in L.buf_last_error()
+    # round-2 entry points: batched patch selection (workspace, lengths), keyed cloud permutation (null cloud)
+    pat = torch.empty(8, 16, 3, device=dev)
+    rc = L.buf_select_patches_batched(t.data_ptr(), lens, 1, t.data_ptr(), 8, 0.1, 16, pat.data_ptr(), ws.data_ptr(), 1024, s)
+    assert rc == -3 and b"workspace" in L.buf_last_error()
+    neg = (C.c_int * 1)(-5)
+    rc = L.buf_select_patches_batched(t.data_ptr(), neg, 1, t.data_ptr(), 8, 0.1, 16, pat.data_ptr(), big.data_ptr(), big.numel(), s)
+    assert rc == -1
+    rc = L.buf_select_patches_batched(t.data_ptr(), lens, 1, t.data_ptr(), 8, -1.0, 16, pat.data_ptr(), big.data_ptr(), big.numel(), s)
+    assert rc == -1 and b"radius" in L.buf_last_error()
+    ptrs, keys = (C.c_void_p * 1)(None), (C.c_ulonglong * 1)(1)
+    rc = L.buf_permute_clouds(ptrs, lens, keys, 1, t.data_ptr(), s)
+    assert rc == -1 and b"cloud 0" in L.buf_last_error()
+    assert L.buf_permute_clouds(ptrs, lens, keys, 0, None, s) == 0          # nothing to do
     torch.cuda.synchronize()
 
 
