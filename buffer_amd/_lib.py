@@ -84,6 +84,8 @@ _SIGNATURES = {
     "buf_ransac_masked_ws_bytes": (_sz, [_i, _i]),
     "buf_ransac_kabsch_masked": (_i, [_vp, _vp, _vp, _i, _i, C.c_uint64, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "buf_post_refine": (_i, [_vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
+    "buf_recover_poses_ws_bytes": (_sz, [_i, _i, _i]),
+    "buf_recover_poses_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _i, _f, _f, _f, _i, _vp, _vp, _sz, _vp]),
 }
 
 

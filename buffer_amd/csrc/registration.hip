@@ -497,3 +497,340 @@ extern "C" int buf_post_refine(const float* T_init, const float* src, const floa
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
+
+// ------------------------------------------------------------------------------------------ A14-A16, batched
+// The pose recovery of EVERY pair of a step in one set of launches (round 1: seven launches per pair on side streams).
+// The matches of the pairs are stacked; seg[p] .. seg[p+1] are the rows of pair p (device int32[nb+1]).  Per pair the
+// arithmetic -- thread assignment, reduction order, sampler -- is that of the single-pair kernels above, so the poses are
+// bit-identical to buf_hypotheses_score + buf_ransac_kabsch_masked + buf_post_refine pair by pair.
+#define RB_MAXB 64
+struct RecoverSeeds { unsigned long long s[RB_MAXB]; };
+
+__global__ void __launch_bounds__(256) k_score_b(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ ss,
+                                               const float* __restrict__ tt, const int* __restrict__ seg, int nb, float azi_n,
+                                               float inlier_th, int* __restrict__ inlier_num)
+{
+    const int h = blockIdx.x;                                     // hypothesis = stacked match row (wave-uniform)
+    const int p = find_elem(seg, nb, h);
+    const int lo = seg[p], hi = seg[p + 1];
+    float r[9], tv[3];
+    for (int k = 0; k < 9; k++) r[k] = R[9 * (size_t)h + k];
+    for (int k = 0; k < 3; k++) tv[k] = t[3 * (size_t)h + k];
+    int cnt = 0;
+    for (int j = lo + threadIdx.x; j < hi; j += 256) {
+        float x = ss[3 * (size_t)j], y = ss[3 * (size_t)j + 1], z = ss[3 * (size_t)j + 2];
+        float dx = r[0] * x + r[1] * y + r[2] * z + tv[0] - tt[3 * (size_t)j];
+        float dy = r[3] * x + r[4] * y + r[5] * z + tv[1] - tt[3 * (size_t)j + 1];
+        float dz = r[6] * x + r[7] * y + r[8] * z + tv[2] - tt[3 * (size_t)j + 2];
+        float diff = sqrtf(dx * dx + dy * dy + dz * dz);
+        float thr = sqrtf(x * x + y * y + z * z) * 3.14159265358979323846f / azi_n * inlier_th;
+        cnt += diff < thr ? 1 : 0;
+    }
+    __shared__ int sc[4];
+    for (int d = WAVE / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) sc[threadIdx.x / WAVE] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) inlier_num[h] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+
+// per pair: argmax of the inlier counts (first maximum), the winner's inlier mask, and its ascending index list + count
+__global__ void __launch_bounds__(1024) k_best_mask_b(const int* __restrict__ inlier_num, const float* __restrict__ R, const float* __restrict__ t,
+                                                    const float* __restrict__ ss, const float* __restrict__ tt, const int* __restrict__ seg,
+                                                    float azi_n, float inlier_th, int* __restrict__ best_out, unsigned char* __restrict__ mask)
+{
+    __shared__ unsigned long long sk[16];
+    const int p = blockIdx.x, lo = seg[p], m = seg[p + 1] - lo;
+    unsigned long long best = 0;
+    for (int i = threadIdx.x; i < m; i += 1024) {
+        unsigned long long key = ((unsigned long long)(unsigned int)(inlier_num[lo + i] + 1) << 32) | (unsigned int)(0x7fffffff - i);
+        best = key > best ? key : best;
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        unsigned int l = __shfl_xor((unsigned int)best, d, WAVE), hgh = __shfl_xor((unsigned int)(best >> 32), d, WAVE);
+        unsigned long long o = ((unsigned long long)hgh << 32) | l;
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) sk[threadIdx.x / WAVE] = best;
+    __syncthreads();
+    best = 0;
+    for (int i = 0; i < 16; i++) best = sk[i] > best ? sk[i] : best;
+    if (m == 0) { if (threadIdx.x == 0) best_out[p] = 0; return; }
+    const int h = 0x7fffffff - (int)(unsigned int)(best & 0xffffffffu);
+    if (threadIdx.x == 0) best_out[p] = h;
+    float r[9], tv[3];
+    for (int k = 0; k < 9; k++) r[k] = R[9 * (size_t)(lo + h) + k];
+    for (int k = 0; k < 3; k++) tv[k] = t[3 * (size_t)(lo + h) + k];
+    for (int j = threadIdx.x; j < m; j += 1024) {
+        const size_t g = (size_t)lo + j;
+        float x = ss[3 * g], y = ss[3 * g + 1], z = ss[3 * g + 2];
+        float dx = r[0] * x + r[1] * y + r[2] * z + tv[0] - tt[3 * g];
+        float dy = r[3] * x + r[4] * y + r[5] * z + tv[1] - tt[3 * g + 1];
+        float dz = r[6] * x + r[7] * y + r[8] * z + tv[2] - tt[3 * g + 2];
+        float diff = sqrtf(dx * dx + dy * dy + dz * dz);
+        float thr = sqrtf(x * x + y * y + z * z) * 3.14159265358979323846f / azi_n * inlier_th;
+        mask[g] = diff < thr ? 1 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_mask_compact_b(const unsigned char* __restrict__ mask, const int* __restrict__ seg, int* __restrict__ idx,
+                                                      int* __restrict__ count)
+{
+    const int p = blockIdx.x, lo = seg[p], m = seg[p + 1] - lo, lane = threadIdx.x;
+    int cnt = 0;
+    for (int base = 0; base < m; base += WAVE) {
+        const int i = base + lane;
+        const bool hit = i < m && mask[lo + i] != 0;
+        const unsigned long long b = __ballot(hit);
+        if (hit) idx[lo + cnt + lane_prefix(b, lane)] = i;          // indices local to the pair
+        cnt += __popcll(b);
+    }
+    if (lane == 0) count[p] = cnt;
+}
+
+// blockIdx.y = pair: the single-pair sampler / checks / scoring on the pair's own rows
+__global__ void __launch_bounds__(WAVE) k_ransac_b(const float* __restrict__ src_all, const float* __restrict__ tgt_all, const int* __restrict__ idx_all,
+                                                const int* __restrict__ count, const int* __restrict__ seg, int nhyp, RecoverSeeds seeds,
+                                                float max_dist, float edge_sim, unsigned long long* __restrict__ keys_all, float* __restrict__ Ts_all)
+{
+    const int p = blockIdx.y, lo = seg[p];
+    const int h = blockIdx.x * WAVE + threadIdx.x;
+    if (h >= nhyp) return;
+    const float* src = src_all + 3 * (size_t)lo;
+    const float* tgt = tgt_all + 3 * (size_t)lo;
+    const int* corr = idx_all + lo;
+    unsigned long long* keys = keys_all + (size_t)p * nhyp;
+    float* Ts = Ts_all + 12 * (size_t)p * nhyp;
+    const int ncorr = count[p];
+    const unsigned long long seed = seeds.s[p];
+    unsigned long long key = 0;
+    float T[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    if (ncorr < 3) {
+        keys[h] = 0;
+        for (int k = 0; k < 12; k++) Ts[12 * (size_t)h + k] = T[k];
+        return;
+    }
+    int i0 = (int)(splitmix64(seed + 3ull * h) % (unsigned long long)ncorr);
+    int i1 = (int)(splitmix64(seed + 3ull * h + 1) % (unsigned long long)(ncorr - 1));
+    int i2 = (int)(splitmix64(seed + 3ull * h + 2) % (unsigned long long)(ncorr - 2));
+    if (i1 >= i0) i1++;
+    int lo2 = min(i0, i1), hi2 = max(i0, i1);
+    if (i2 >= lo2) i2++;
+    if (i2 >= hi2) i2++;
+    int id[3] = { corr[i0], corr[i1], corr[i2] };
+    float a[3][3], b[3][3];
+    for (int k = 0; k < 3; k++)
+        for (int c = 0; c < 3; c++) { a[k][c] = src[3 * (size_t)id[k] + c]; b[k][c] = tgt[3 * (size_t)id[k] + c]; }
+    bool ok = true;
+    for (int q0 = 0; q0 < 3 && ok; q0++) {
+        int q = (q0 + 1) % 3;
+        float ds = sqrtf(sqdist3(a[q0][0], a[q0][1], a[q0][2], a[q][0], a[q][1], a[q][2]));
+        float dt = sqrtf(sqdist3(b[q0][0], b[q0][1], b[q0][2], b[q][0], b[q][1], b[q][2]));
+        ok = ds >= dt * edge_sim && dt >= ds * edge_sim;
+    }
+    if (ok) {
+        float ca[3], cb[3];
+        for (int c = 0; c < 3; c++) { ca[c] = (a[0][c] + a[1][c] + a[2][c]) / 3.f; cb[c] = (b[0][c] + b[1][c] + b[2][c]) / 3.f; }
+        float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int k = 0; k < 3; k++)
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) H[3 * r + c] += (a[k][r] - ca[r]) * (b[k][c] - cb[c]);
+        float R[9];
+        kabsch_rotation(H, R);
+        for (int r = 0; r < 3; r++) {
+            T[4 * r] = R[3 * r]; T[4 * r + 1] = R[3 * r + 1]; T[4 * r + 2] = R[3 * r + 2];
+            T[4 * r + 3] = cb[r] - (R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]);
+        }
+        for (int k = 0; k < 3 && ok; k++) {
+            float x = T[0] * a[k][0] + T[1] * a[k][1] + T[2] * a[k][2] + T[3] - b[k][0];
+            float y = T[4] * a[k][0] + T[5] * a[k][1] + T[6] * a[k][2] + T[7] - b[k][1];
+            float z = T[8] * a[k][0] + T[9] * a[k][1] + T[10] * a[k][2] + T[11] - b[k][2];
+            ok = sqrtf(x * x + y * y + z * z) <= max_dist;
+        }
+    }
+    if (ok) {
+        int cnt = 0;
+        float err2 = 0.f;
+        for (int j = 0; j < ncorr; j++) {
+            int k = corr[j];
+            float sx = src[3 * (size_t)k], sy = src[3 * (size_t)k + 1], sz = src[3 * (size_t)k + 2];
+            float x = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - tgt[3 * (size_t)k];
+            float y = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - tgt[3 * (size_t)k + 1];
+            float z = T[8] * sx + T[9] * sy + T[10] * sz + T[11] - tgt[3 * (size_t)k + 2];
+            float d2 = x * x + y * y + z * z;
+            if (sqrtf(d2) < max_dist) { cnt++; err2 += d2; }
+        }
+        if (cnt > 0) key = ((unsigned long long)(unsigned int)cnt << 32) | (unsigned int)~__float_as_uint(err2 / (float)cnt);
+    }
+    keys[h] = key;
+    for (int k = 0; k < 12; k++) Ts[12 * (size_t)h + k] = T[k];
+}
+
+__global__ void __launch_bounds__(1024) k_ransac_pick_b(const unsigned long long* __restrict__ keys_all, const float* __restrict__ Ts_all, int nhyp,
+                                                      float* __restrict__ T_out_all)
+{
+    const int p = blockIdx.x;
+    const unsigned long long* keys = keys_all + (size_t)p * nhyp;
+    const float* Ts = Ts_all + 12 * (size_t)p * nhyp;
+    __shared__ unsigned long long sk[16];
+    __shared__ int si[16];
+    unsigned long long best = 0;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nhyp; i += 1024) {
+        unsigned long long k = keys[i];
+        if (k > best || (k == best && i < bi)) { best = k; bi = i; }
+    }
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        unsigned int l = __shfl_xor((unsigned int)best, d, WAVE), hgh = __shfl_xor((unsigned int)(best >> 32), d, WAVE);
+        int oi = __shfl_xor(bi, d, WAVE);
+        unsigned long long o = ((unsigned long long)hgh << 32) | l;
+        if (o > best || (o == best && oi < bi)) { best = o; bi = oi; }
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) { sk[threadIdx.x / WAVE] = best; si[threadIdx.x / WAVE] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = 0; bi = 0x7fffffff;
+        for (int i = 0; i < 16; i++) if (sk[i] > best || (sk[i] == best && si[i] < bi)) { best = sk[i]; bi = si[i]; }
+        float T[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+        if (best != 0) for (int k = 0; k < 12; k++) T[k] = Ts[12 * (size_t)bi + k];
+        for (int k = 0; k < 16; k++) T_out_all[16 * (size_t)p + k] = T[k];
+    }
+}
+
+// one workgroup per pair: k_post_refine on the pair's rows (iters == 0: the RANSAC pose is copied); pairs with fewer than three
+// matches get the identity (ThreeDMatch/test.py:242-245)
+__global__ void __launch_bounds__(REF_THREADS) k_post_refine_b(const float* __restrict__ T_init_all, const float* __restrict__ src_all,
+                                                             const float* __restrict__ tgt_all, const int* __restrict__ seg, float thr, int iters,
+                                                             float* __restrict__ T_out_all)
+{
+    __shared__ float sh[REF_THREADS / WAVE];
+    __shared__ float Ts[12];
+    const int p = blockIdx.x, lo = seg[p], m = seg[p + 1] - lo;
+    const float* src = src_all + 3 * (size_t)lo;
+    const float* tgt = tgt_all + 3 * (size_t)lo;
+    float* T_out = T_out_all + 16 * (size_t)p;
+    if (m < 3) {
+        if (threadIdx.x < 16) T_out[threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.f : 0.f;
+        return;
+    }
+    if (threadIdx.x < 12) Ts[threadIdx.x] = T_init_all[16 * (size_t)p + threadIdx.x];
+    __syncthreads();
+    int prev = 0;
+    for (int it = 0; it < iters; it++) {
+        float T[12];
+        for (int k = 0; k < 12; k++) T[k] = Ts[k];
+        float cnt = 0.f, sw = 0.f, sa[3] = { 0, 0, 0 }, sb[3] = { 0, 0, 0 };
+        for (int j = threadIdx.x; j < m; j += REF_THREADS) {
+            float x = src[3 * (size_t)j], y = src[3 * (size_t)j + 1], z = src[3 * (size_t)j + 2];
+            float bx = tgt[3 * (size_t)j], by = tgt[3 * (size_t)j + 1], bz = tgt[3 * (size_t)j + 2];
+            float dx = T[0] * x + T[1] * y + T[2] * z + T[3] - bx;
+            float dy = T[4] * x + T[5] * y + T[6] * z + T[7] - by;
+            float dz = T[8] * x + T[9] * y + T[10] * z + T[11] - bz;
+            float dis = sqrtf(dx * dx + dy * dy + dz * dz);
+            if (dis < thr) {
+                float q = dis / thr;
+                float w = 1.f / (1.f + q * q);
+                cnt += 1.f; sw += w;
+                sa[0] += w * x; sa[1] += w * y; sa[2] += w * z;
+                sb[0] += w * bx; sb[1] += w * by; sb[2] += w * bz;
+            }
+        }
+        int num = (int)(block_sum(cnt, sh) + 0.5f);
+        if (abs(num - prev) < 1) break;
+        prev = num;
+        sw = block_sum(sw, sh);
+        float ca[3], cb[3];
+        for (int c = 0; c < 3; c++) { ca[c] = block_sum(sa[c], sh) / (sw + 1e-6f); cb[c] = block_sum(sb[c], sh) / (sw + 1e-6f); }
+        float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int j = threadIdx.x; j < m; j += REF_THREADS) {
+            float x = src[3 * (size_t)j], y = src[3 * (size_t)j + 1], z = src[3 * (size_t)j + 2];
+            float bx = tgt[3 * (size_t)j], by = tgt[3 * (size_t)j + 1], bz = tgt[3 * (size_t)j + 2];
+            float dx = T[0] * x + T[1] * y + T[2] * z + T[3] - bx;
+            float dy = T[4] * x + T[5] * y + T[6] * z + T[7] - by;
+            float dz = T[8] * x + T[9] * y + T[10] * z + T[11] - bz;
+            float dis = sqrtf(dx * dx + dy * dy + dz * dz);
+            if (dis < thr) {
+                float q = dis / thr;
+                float w = 1.f / (1.f + q * q);
+                float am[3] = { x - ca[0], y - ca[1], z - ca[2] }, bm[3] = { bx - cb[0], by - cb[1], bz - cb[2] };
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) H[3 * r + c] += am[r] * w * bm[c];
+            }
+        }
+        float Hs[9];
+        for (int k = 0; k < 9; k++) Hs[k] = block_sum(H[k], sh);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float R[9];
+            kabsch_rotation(Hs, R);
+            for (int r = 0; r < 3; r++) {
+                Ts[4 * r] = R[3 * r]; Ts[4 * r + 1] = R[3 * r + 1]; Ts[4 * r + 2] = R[3 * r + 2];
+                Ts[4 * r + 3] = cb[r] - (R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 12) T_out[threadIdx.x] = Ts[threadIdx.x];
+    if (threadIdx.x >= 12 && threadIdx.x < 16) T_out[threadIdx.x] = threadIdx.x == 15 ? 1.f : 0.f;
+}
+
+extern "C" size_t buf_recover_poses_ws_bytes(int m_total, int nb, int nhyp)
+{
+    WsCarver w(nullptr, 0);
+    const size_t m = (size_t)(m_total > 0 ? m_total : 1), b = (size_t)(nb > 0 ? nb : 1);
+    w.take<int>(b + 1); w.take<float>(9 * m); w.take<float>(3 * m); w.take<int>(m); w.take<int>(b); w.take<unsigned char>(m);
+    w.take<int>(m); w.take<int>(b); w.take<unsigned long long>(b * nhyp); w.take<float>(12 * b * nhyp); w.take<float>(16 * b);
+    return w.used();
+}
+
+// ind f32[M], ss/tt f32[M,3], ss_R/tt_R f32[M,9]: the matches of nb pairs stacked (pair p owns seg_host[p] rows); seeds_host
+// u64[nb]; refine_iters 0 = no post-refinement (KITTI) -> poses f32[nb,4,4].
+extern "C" int buf_recover_poses_batched(const float* ind, const float* ss_kpts, const float* tt_kpts, const float* ss_R, const float* tt_R,
+                                         const int* seg_host, int nb, const unsigned long long* seeds_host, int azi_n, float inlier_th,
+                                         int nhyp, float max_dist, float edge_similarity, float refine_threshold, int refine_iters,
+                                         float* poses_out, void* ws, size_t ws_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    BUF_REQUIRE(nb >= 0 && nhyp > 0 && azi_n > 0 && refine_iters >= 0, BUF_EINVAL, "buf_recover_poses_batched: nb=%d nhyp=%d", nb, nhyp);
+    if (nb == 0) return BUF_OK;
+    BUF_REQUIRE(seg_host && seeds_host && poses_out && ws, BUF_EINVAL, "buf_recover_poses_batched: null argument");
+    long long mt = 0;
+    for (int p = 0; p < nb; p++) { BUF_REQUIRE(seg_host[p] >= 0, BUF_EINVAL, "buf_recover_poses_batched: negative segment"); mt += seg_host[p]; }
+    BUF_REQUIRE(mt < 0x7fffffffLL, BUF_EINVAL, "buf_recover_poses_batched: too many matches");
+    const int M = (int)mt;
+    BUF_REQUIRE(M == 0 || (ind && ss_kpts && tt_kpts && ss_R && tt_R), BUF_EINVAL, "buf_recover_poses_batched: null argument");
+    BUF_REQUIRE(ws_bytes >= buf_recover_poses_ws_bytes(M, nb, nhyp), BUF_EWORKSPACE, "buf_recover_poses_batched: workspace %zu < %zu",
+                ws_bytes, buf_recover_poses_ws_bytes(M, nb, nhyp));
+    WsCarver w(ws, ws_bytes);
+    const size_t m = (size_t)(M > 0 ? M : 1);
+    int* seg = w.take<int>((size_t)nb + 1);
+    float* R = w.take<float>(9 * m);
+    float* t = w.take<float>(3 * m);
+    int* num = w.take<int>(m);
+    int* best = w.take<int>((size_t)nb);
+    unsigned char* mask = w.take<unsigned char>(m);
+    int* idx = w.take<int>(m);
+    int* count = w.take<int>((size_t)nb);
+    unsigned long long* keys = w.take<unsigned long long>((size_t)nb * nhyp);
+    float* Ts = w.take<float>(12 * (size_t)nb * nhyp);
+    float* Tr = w.take<float>(16 * (size_t)nb);
+    int rc = upload_offsets(seg, seg_host, nb, M, "buf_recover_poses_batched", s);
+    if (rc) return rc;
+    if (M > 0) {
+        k_hypotheses<<<cdiv(M, 256), 256, 0, s>>>(ind, ss_kpts, tt_kpts, ss_R, tt_R, M, (float)azi_n, R, t);
+        k_score_b<<<M, 256, 0, s>>>(R, t, ss_kpts, tt_kpts, seg, nb, (float)azi_n, inlier_th, num);
+    }
+    k_best_mask_b<<<nb, 1024, 0, s>>>(num, R, t, ss_kpts, tt_kpts, seg, (float)azi_n, inlier_th, best, mask);
+    k_mask_compact_b<<<nb, WAVE, 0, s>>>(mask, seg, idx, count);
+    float* ransac_out = refine_iters > 0 ? Tr : poses_out;
+    for (int p0 = 0; p0 < nb; p0 += RB_MAXB) {
+        RecoverSeeds sd;
+        const int cnt = nb - p0 < RB_MAXB ? nb - p0 : RB_MAXB;
+        for (int i = 0; i < cnt; i++) sd.s[i] = seeds_host[p0 + i];
+        k_ransac_b<<<dim3(cdiv(nhyp, WAVE), cnt), WAVE, 0, s>>>(ss_kpts, tt_kpts, idx, count + p0, seg + p0, nhyp, sd, max_dist, edge_similarity,
+                                                            keys + (size_t)p0 * nhyp, Ts + 12 * (size_t)p0 * nhyp);
+    }
+    k_ransac_pick_b<<<nb, 1024, 0, s>>>(keys, Ts, nhyp, ransac_out);
+    k_post_refine_b<<<nb, REF_THREADS, 0, s>>>(ransac_out, ss_kpts, tt_kpts, seg, refine_threshold, refine_iters, poses_out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

@@ -474,6 +474,27 @@ def post_refine(T_init, src, tgt, thr=0.10, iters=20):
     return T, info
 
 
+def recover_poses_batched(ind, ss_kpts, tt_kpts, ss_R, tt_R, seg_lengths, seeds, cfg):
+    """hypotheses + scoring + RANSAC + refinement of every pair of a step in one set of launches: the matches of the pairs are
+    stacked, pair p owns seg_lengths[p] consecutive rows -> poses f32[nb,4,4] (identity for pairs with fewer than 3 matches)."""
+    L = _lib.lib()
+    seg = _host_i32(seg_lengths)
+    nb, M = int(seg.shape[0]), int(seg.sum())
+    dev = ss_kpts.device
+    poses = torch.empty((nb, 4, 4), dtype=torch.float32, device=dev)
+    if nb == 0:
+        return poses
+    nbytes = L.buf_recover_poses_ws_bytes(M, nb, int(cfg.ransac_hypotheses))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    sd = (C.c_ulonglong * nb)(*[int(x) & _MASK64 for x in seeds])
+    check(L.buf_recover_poses_batched(_ptr(ind.contiguous()), _ptr(ss_kpts.contiguous()), _ptr(tt_kpts.contiguous()),
+                                      _ptr(ss_R.contiguous()), _ptr(tt_R.contiguous()), _hptr(seg), nb, sd, int(cfg.azi_n),
+                                      float(cfg.inlier_th), int(cfg.ransac_hypotheses), float(cfg.dist_th), float(cfg.similar_th),
+                                      float(cfg.refine_threshold), 20 if cfg.pose_refine else 0, _ptr(poses), _ptr(ws), nbytes,
+                                      _stream()), "buf_recover_poses_batched")
+    return poses
+
+
 # ----------------------------------------------------------------------------- fused descriptor CNN
 def mfma_tile_weights(wt, lk_major=False):
     """[K, Cout] (K, Cout multiples of 16) -> the B-operand tiling of the fused MFMA kernels: blocks [K/16][Cout/16] of

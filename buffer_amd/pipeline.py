@@ -213,32 +213,10 @@ class BufferPipeline:
         ind = self.inlier(emb['equi'][src_row][:, :, 1:e - 1].contiguous(), emb['equi'][tgt_row][:, :, 1:e - 1].contiguous())
         ss_all, tt_all = kp[src_row].contiguous(), kp[tgt_row].contiguous()
         sR_all, tR_all = emb['R'][src_row].contiguous(), emb['R'][tgt_row].contiguous()
-        # The per-pair recoveries are independent, short (a few 10-200 us kernels that fill a fraction of the chip) and
-        # free of host round trips: they go round-robin onto a few side streams so that several pairs are in flight.
-        main = torch.cuda.current_stream(dev)
-        side = self._pose_streams(min(B, 4))
-        for s in side:
-            s.wait_stream(main)
-        lo = 0
-        for b in range(B):
-            m = int(m_counts[b])
-            if m < 3:
-                poses[b] = torch.eye(4, device=dev)
-            else:
-                sl = slice(lo, lo + m)
-                with torch.cuda.stream(side[b % len(side)]):
-                    poses[b], _ = registration.recover_pose(ind[sl].contiguous(), ss_all[sl], tt_all[sl], sR_all[sl],
-                                                            tR_all[sl], cfg, seeds[b])
-                    poses[b].record_stream(main)
-            lo += m
-        for s in side:
-            main.wait_stream(s)
-        return poses
-
-    def _pose_streams(self, n):
-        if len(getattr(self, '_side_streams', [])) < n:
-            self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
-        return self._side_streams[:n]
+        # hypotheses, all-vs-all scoring, RANSAC and refinement of all B pairs: one set of launches (csrc/registration.hip,
+        # batched section), bit-identical to the pair-by-pair recover_pose of register()
+        all_poses = ops.recover_poses_batched(ind, ss_all, tt_all, sR_all, tR_all, m_counts, seeds, cfg)
+        return [all_poses[b] for b in range(B)]
 
     def _identity(self, out, detail):
         pose = torch.eye(4, device=self.device)       # ThreeDMatch/test.py:242-245: failed pair -> identity

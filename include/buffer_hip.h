@@ -288,6 +288,15 @@ int     buf_ransac_kabsch_masked(const float* src, const float* tgt, const unsig
  * T_init,T_out f32[4,4]; src,tgt f32[m,3]; info_out (nullable) int32[2] = {last inlier count, rounds run}. */
 int     buf_post_refine(const float* T_init, const float* src, const float* tgt, int m, float inlier_threshold,
                         int iters, float* T_out, int* info_out, void* stream);
+/* A14 + A15 + A16 for every pair of a step in one set of launches: the matches of nb pairs stacked (pair p owns seg_host[p]
+ * consecutive rows of ind f32[M], ss/tt_kpts f32[M,3], ss/tt_R f32[M,9]); seeds_host u64[nb] (RANSAC sampler seed per pair);
+ * refine_iters = 0 skips the post-refinement (KITTI) -> poses f32[nb,4,4] (identity for pairs with fewer than 3 matches).
+ * Pair by pair bit-identical to buf_hypotheses_score + buf_ransac_kabsch_masked + buf_post_refine. */
+size_t  buf_recover_poses_ws_bytes(int m_total, int nb, int nhyp);
+int     buf_recover_poses_batched(const float* ind, const float* ss_kpts, const float* tt_kpts, const float* ss_R, const float* tt_R,
+                                  const int* seg_host, int nb, const unsigned long long* seeds_host, int azi_n, float inlier_th,
+                                  int nhyp, float max_dist, float edge_similarity, float refine_threshold, int refine_iters,
+                                  float* poses_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * N1  pre-processing that feeds the path (ThreeDMatch/dataset.py:93,104,125-153; KITTI/dataset.py): the open3d
