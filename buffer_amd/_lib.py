@@ -78,6 +78,7 @@ _SIGNATURES = {
     "buf_segment_instance_norm": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     "buf_descriptor_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "buf_cost_volume_net": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "buf_cost_volume_net_gather": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "buf_hypotheses_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_ransac_ws_bytes": (_sz, [_i]),
     "buf_ransac_kabsch": (_i, [_vp, _vp, _vp, _i, _i, C.c_uint64, _f, _f, _vp, _vp, _vp, _sz, _vp]),

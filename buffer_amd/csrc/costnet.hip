@@ -46,6 +46,11 @@ typedef const __attribute__((address_space(1))) cvx4* cv_gptr;     // global (no
 struct CostNetParams {
     const float* wt[CV_LAYERS];    // [K][Cout] in the MFMA tiling described at cv_gemm_static; K ordering per layer below
     const float* bias[CV_LAYERS];
+    // gathered form (buf_cost_volume_net_gather): match i reads rows s_rows[i] / t_rows[i] of a full [rows,32,ele_n,20] map and
+    // takes its elevation rows 1..5 (models/BUFFER.py:291-292) inside the kernel; null rows = dense [m,32,5,20] inputs
+    const long long* s_rows;
+    const long long* t_rows;
+    int row_floats, chan_floats, skip_floats;
 };
 
 // ---- tile GEMM: acc[t][u] += sum over groups of 4 k-steps ---------------------------------------------------------
@@ -261,11 +266,12 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     const int match = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE, li = lane & 15, lk = lane >> 4;
     {   // both maps, transposed on the way in: global [c][k][l] -> LDS [k][l][c]; S with its two wrap-around columns per side
-        const cvx4* a = reinterpret_cast<const cvx4*>(s_eq + (size_t)match * 3200);
-        const cvx4* b = reinterpret_cast<const cvx4*>(t_eq + (size_t)match * 3200);
+        const float* a = s_eq + (P.s_rows ? (size_t)P.s_rows[match] * P.row_floats + P.skip_floats : (size_t)match * 3200);
+        const float* b = t_eq + (P.t_rows ? (size_t)P.t_rows[match] * P.row_floats + P.skip_floats : (size_t)match * 3200);
         for (int i = tid; i < 800; i += CV_THREADS) {
             const int c = i / 25, rem = i - c * 25, k = rem / 5, l0 = (rem - k * 5) * 4;
-            const cvx4 sv = a[i], tv = b[i];
+            const cvx4 sv = *reinterpret_cast<const cvx4*>(a + c * P.chan_floats + rem * 4);      // 100 contiguous floats per channel
+            const cvx4 tv = *reinterpret_cast<const cvx4*>(b + c * P.chan_floats + rem * 4);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int l = l0 + q;
@@ -376,18 +382,18 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
     }
 }
 
-// s_eq, t_eq f32[m,32,5,20] (elevation rows 1..5 of the equivariant maps) -> ind f32[m]
-extern "C" int buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
-                                   const float* const* bias_host, float* ind_out, void* stream)
+static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const float* const* wt_host, const float* const* bias_host,
+                           const long long* s_rows, const long long* t_rows, int ele_n, float* ind_out, void* stream, const char* who)
 {
-    BUF_REQUIRE(m >= 0, BUF_EINVAL, "buf_cost_volume_net: m=%d", m);
-    if (m == 0) return BUF_OK;
-    BUF_REQUIRE(s_eq && t_eq && wt_host && bias_host && ind_out, BUF_EINVAL, "buf_cost_volume_net: null argument");
     CostNetParams P;
     for (int l = 0; l < CV_LAYERS; l++) {
         P.wt[l] = wt_host[l]; P.bias[l] = bias_host[l];
-        BUF_REQUIRE(P.wt[l] && P.bias[l], BUF_EINVAL, "buf_cost_volume_net: null weights for layer %d", l);
+        BUF_REQUIRE(P.wt[l] && P.bias[l], BUF_EINVAL, "%s: null weights for layer %d", who, l);
     }
+    P.s_rows = s_rows; P.t_rows = t_rows;
+    P.chan_floats = s_rows ? ele_n * 20 : 100;
+    P.row_floats = 32 * P.chan_floats;
+    P.skip_floats = s_rows ? 20 : 0;                         // elevation row 0 of every channel is not part of the cost volume
     size_t lds = sizeof(float) * 2 * CV_BUF;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
@@ -404,4 +410,25 @@ extern "C" int buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, 
     if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;
+}
+
+// s_eq, t_eq f32[m,32,5,20] (elevation rows 1..5 of the equivariant maps) -> ind f32[m]
+extern "C" int buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
+                                   const float* const* bias_host, float* ind_out, void* stream)
+{
+    BUF_REQUIRE(m >= 0, BUF_EINVAL, "buf_cost_volume_net: m=%d", m);
+    if (m == 0) return BUF_OK;
+    BUF_REQUIRE(s_eq && t_eq && wt_host && bias_host && ind_out, BUF_EINVAL, "buf_cost_volume_net: null argument");
+    return cost_net_launch(s_eq, t_eq, m, wt_host, bias_host, nullptr, nullptr, 7, ind_out, stream, "buf_cost_volume_net");
+}
+
+// The same with the gather fused in: equi f32[rows,32,ele_n,20] holds the FULL equivariant maps of all keypoints, match i pairs
+// row s_rows[i] with row t_rows[i] (int64, device) and the kernel reads elevation rows 1..5 of each (ele_n = 7) directly.
+extern "C" int buf_cost_volume_net_gather(const float* equi, int ele_n, const long long* s_rows, const long long* t_rows, int m,
+                                          const float* const* wt_host, const float* const* bias_host, float* ind_out, void* stream)
+{
+    BUF_REQUIRE(m >= 0 && ele_n == 7, BUF_EINVAL, "buf_cost_volume_net_gather: m=%d ele_n=%d (the kernel is built for ele_n = 7)", m, ele_n);
+    if (m == 0) return BUF_OK;
+    BUF_REQUIRE(equi && s_rows && t_rows && wt_host && bias_host && ind_out, BUF_EINVAL, "buf_cost_volume_net_gather: null argument");
+    return cost_net_launch(equi, equi, m, wt_host, bias_host, s_rows, t_rows, ele_n, ind_out, stream, "buf_cost_volume_net_gather");
 }

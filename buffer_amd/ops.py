@@ -609,3 +609,17 @@ class CostVolumeNet:
         check(L.buf_cost_volume_net(_ptr(s_eq), _ptr(t_eq), m, self._wp, self._bp, _ptr(out), _stream()),
               "buf_cost_volume_net")
         return out
+
+    def gathered(self, equi, s_rows, t_rows):
+        """equi f32[rows,32,7,20] (full maps of all keypoints), s_rows / t_rows int64[M] -> f32[M]: the row gather and the
+        elevation slice 1..5 (BUFFER.py:291-292) happen inside the kernel."""
+        L = _lib.lib()
+        equi = _dev(equi, torch.float32, "CostVolumeNet.gathered")
+        if equi.dim() != 4 or tuple(equi.shape[1:]) != (32, 7, 20):
+            raise _lib.BufferHipError(f"CostVolumeNet.gathered: expected [rows,32,7,20] maps, got {tuple(equi.shape)}")
+        s_rows, t_rows = _dev(s_rows, torch.int64, "s_rows"), _dev(t_rows, torch.int64, "t_rows")
+        m = int(s_rows.shape[0])
+        out = torch.empty((m,), dtype=torch.float32, device=equi.device)
+        check(L.buf_cost_volume_net_gather(_ptr(equi), 7, _ptr(s_rows), _ptr(t_rows), m, self._wp, self._bp, _ptr(out), _stream()),
+              "buf_cost_volume_net_gather")
+        return out

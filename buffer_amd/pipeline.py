@@ -209,8 +209,7 @@ class BufferPipeline:
         m_counts = torch.bincount(pair_of, minlength=B).cpu().numpy()
         src_row = (2 * pair_of) * P + s_mid
         tgt_row = (2 * pair_of + 1) * P + t_mid
-        e = cfg.ele_n
-        ind = self.inlier(emb['equi'][src_row][:, :, 1:e - 1].contiguous(), emb['equi'][tgt_row][:, :, 1:e - 1].contiguous())
+        ind = self.inlier.gathered(emb['equi'], src_row, tgt_row)      # BUFFER.py:291-292 rows 1..ele_n-2, gathered in-kernel
         ss_all, tt_all = kp[src_row].contiguous(), kp[tgt_row].contiguous()
         sR_all, tR_all = emb['R'][src_row].contiguous(), emb['R'][tgt_row].contiguous()
         # hypotheses, all-vs-all scoring, RANSAC and refinement of all B pairs: one set of launches (csrc/registration.hip,

@@ -39,6 +39,10 @@ class CostVolume:
             raise ValueError(f'CostVolume: expected two [M,32,5,20] maps, got {tuple(d1.shape)} and {tuple(d2.shape)}')
         return self.fused(d1, d2)
 
+    def gathered(self, equi, s_rows, t_rows):
+        """full maps equi f32[rows,32,7,20] + matched row ids -> expected azimuth shift f32[M] (gather and elevation slice fused)."""
+        return self.fused.gathered(equi, s_rows, t_rows)
+
 
 def recover_pose(ind, ss_kpts, tt_kpts, ss_R, tt_R, cfg, seed=0):
     """BUFFER.py:295-333: hypotheses, all-vs-all scoring, RANSAC on the winner's inliers, refinement.

@@ -264,6 +264,10 @@ int     buf_descriptor_head(const float* y, int npatch, const float* params, flo
  * (buffer_amd.ops.mfma_tile_weights(w, lk_major=True) is the host-side re-layout). */
 int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
                             const float* const* bias_host, float* ind_out, void* stream);
+/* The same with the row gather fused in: equi f32[rows,32,ele_n,20] = the full equivariant maps of all keypoints (ele_n = 7),
+ * match i pairs row s_rows[i] with row t_rows[i] (DEVICE int64[m]); elevation rows 1..ele_n-2 are read inside the kernel. */
+int     buf_cost_volume_net_gather(const float* equi, int ele_n, const long long* s_rows, const long long* t_rows, int m,
+                                   const float* const* wt_host, const float* const* bias_host, float* ind_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A14  hypotheses + all-vs-all scoring (models/BUFFER.py:295-311): ind f32[m] -> R f32[m,3,3], t f32[m,3],

@@ -247,3 +247,17 @@ def test_point_learner_honours_test_scale(W, dev):
             sc = np.abs(truth[k]).max()
             assert np.abs(v.cpu().numpy() - truth[k]).max() <= 1e-4 * sc, (scale, k)
         assert np.abs(axis.cpu().numpy() - f['axis']).max() > 1e-3          # and it is not the scale = 1 answer
+
+
+def test_cost_volume_gather_form_equals_dense_form(W, dev):
+    """buf_cost_volume_net_gather (row gather + elevation rows 1..5 read inside the kernel) == gathering and slicing first"""
+    from buffer_amd import registration
+    cv = registration.CostVolume(W, dev)
+    g = torch.Generator(device='cpu').manual_seed(4)
+    equi = torch.nn.functional.normalize(torch.rand((300, 32, 7, 20), generator=g), dim=1).to(dev)
+    s_rows = torch.randint(0, 300, (157,), generator=g).to(dev)
+    t_rows = torch.randint(0, 300, (157,), generator=g).to(dev)
+    want = cv(equi[s_rows][:, :, 1:6].contiguous(), equi[t_rows][:, :, 1:6].contiguous())
+    got = cv.gathered(equi, s_rows, t_rows)
+    assert torch.equal(got, want)
+    assert cv.gathered(equi, s_rows[:0], t_rows[:0]).shape == (0,)
