@@ -156,7 +156,7 @@ int     buf_three_nn(const float* unknown, const float* known, int b, int n, int
  * kpts f32[m,3] -> patches f32[m,nsample,3] with the keypoint in every unused slot and in the last slot. */
 int     buf_select_patches(const float* pts, const float* kpts, int n, int m, float radius, int nsample,
                            float* patches, void* stream);
-/* The same for every cloud of a step in one launch: pts f32[sum n_c,3] = the (already permuted) support clouds stacked,
+/* The same (models/patch_embedder.py:93-121) for every cloud of a step in one launch: pts f32[sum n_c,3] = the (already permuted) support clouds stacked,
  * lengths_host int[nc], kpts f32[nc*m,3] (m keypoints per cloud) -> patches f32[nc*m,nsample,3].  Builds an A2 cell grid
  * over the stacked clouds in `ws` and walks a per-query bitmask of in-ball points in index order (identical results to
  * buf_select_patches cloud by cloud). */
@@ -264,7 +264,8 @@ int     buf_descriptor_head(const float* y, int npatch, const float* params, flo
  * (buffer_amd.ops.mfma_tile_weights(w, lk_major=True) is the host-side re-layout). */
 int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
                             const float* const* bias_host, float* ind_out, void* stream);
-/* The same with the row gather fused in: equi f32[rows,32,ele_n,20] = the full equivariant maps of all keypoints (ele_n = 7),
+/* The same with the row gather of models/BUFFER.py:285-292 (ss_equi = src_equi[s_mids], [:, :, 1:ele_n-1]) fused in:
+ * equi f32[rows,32,ele_n,20] = the full equivariant maps of all keypoints (ele_n = 7),
  * match i pairs row s_rows[i] with row t_rows[i] (DEVICE int64[m]); elevation rows 1..ele_n-2 are read inside the kernel. */
 int     buf_cost_volume_net_gather(const float* equi, int ele_n, const long long* s_rows, const long long* t_rows, int m,
                                    const float* const* wt_host, const float* const* bias_host, float* ind_out, void* stream);
@@ -292,7 +293,8 @@ int     buf_ransac_kabsch_masked(const float* src, const float* tgt, const unsig
  * T_init,T_out f32[4,4]; src,tgt f32[m,3]; info_out (nullable) int32[2] = {last inlier count, rounds run}. */
 int     buf_post_refine(const float* T_init, const float* src, const float* tgt, int m, float inlier_threshold,
                         int iters, float* T_out, int* info_out, void* stream);
-/* A14 + A15 + A16 for every pair of a step in one set of launches: the matches of nb pairs stacked (pair p owns seg_host[p]
+/* A14 + A15 + A16 (models/BUFFER.py:295-311 hypotheses and scoring, :314-326 RANSAC, :382-464 post_refinement) for every pair of
+ * a step in one set of launches: the matches of nb pairs stacked (pair p owns seg_host[p]
  * consecutive rows of ind f32[M], ss/tt_kpts f32[M,3], ss/tt_R f32[M,9]); seeds_host u64[nb] (RANSAC sampler seed per pair);
  * refine_iters = 0 skips the post-refinement (KITTI) -> poses f32[nb,4,4] (identity for pairs with fewer than 3 matches).
  * Pair by pair bit-identical to buf_hypotheses_score + buf_ransac_kabsch_masked + buf_post_refine. */
