@@ -7,9 +7,9 @@
 //   1. point-parallel: every point looks up the voxel balls that can contain it (a 16^3 lookup grid over the
 //      unit ball, cell -> candidate centres, built once per call) and sets its bit in the hit mask of each
 //      ball that does (exact d^2 test, LDS atomicOr) -- ~19 tests per point instead of 420;
-//   2. centre-parallel: one lane per voxel centre reads its mask in index order and notes its first 10 hits
-//      (= pointnet2 ball_query's "first nsample in index order");
-//   3. all centre lanes run the azimuth de-rotation, the 3->16 MLP, BN, ReLU and the running max slot by slot.
+//   2. centre-parallel: one lane per voxel centre walks its mask in index order (= pointnet2 ball_query's "first nsample
+//      in index order") and runs each hit through the azimuth de-rotation, the 3->16 MLP, BN, ReLU and the running max,
+//      all lanes slot by slot.
 // HBM traffic: 6 KB in, 26.9 KB out per patch; [P,420,10,3] never exists.
 #include "common.h"
 
@@ -37,11 +37,11 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
                                                              float* __restrict__ out_x, float* __restrict__ out_R,
                                                              float* __restrict__ out_rand, float* __restrict__ out_patches)
 {
-    // dynamic LDS, sized by the launch (52.8 KB at 512 points x 10 samples -> three workgroups per CU):
+    // dynamic LDS, sized by the launch (36.9 KB + the 7 KB centre copy at 512 points -> three workgroups per CU; the hit lists
+    // never leave the registers.  Reading the centres from L1/L2 instead would admit a fourth workgroup but measured slower):
     extern __shared__ float4 pts[];                              // [npts] aligned, normalised patch
     const int W = (npts + 31) >> 5;                              // mask words per centre
     unsigned* mask = reinterpret_cast<unsigned*>(pts + npts);    // [W][VOX_THREADS] hit bits
-    unsigned short* hits = reinterpret_cast<unsigned short*>(mask + W * VOX_THREADS);   // [nsample][VOX_THREADS]
     __shared__ float4 cen[VOX_THREADS];
     __shared__ float Rs[9];
     const int p = blockIdx.x, tid = threadIdx.x;
@@ -154,34 +154,37 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
         }
     }
     __syncthreads();
-    // Phase 2: every centre lane lists its first `nsample` hits in index order.
-    int cnt = 0, nreal = 0;                                      // accepted samples / samples kept in the list
+    // Phases 2 + 3: every centre lane walks its hit mask in index order (= ball_query's "first nsample in index order") and
+    // feeds each hit straight through de-rotation -> 3->16 MLP -> BN -> ReLU -> running max; all lanes advance slot by slot.
+    // `nz` = the mask words that hold a hit; a word is fetched from LDS only when the previous one is used up.
+    int cnt = 0;                                                 // accepted samples (incl. a zeroed hit on point 0)
     bool zero_slot = false;
-    if (active) {
-        for (int w = 0; w < W && cnt < nsample; w++) {
-            unsigned word = mask[w * VOX_THREADS + tid];
-            while (word && cnt < nsample) {
-                const int k = w * 32 + __ffs(word) - 1;
-                word &= word - 1;
-                if (k != 0) hits[(nreal++) * VOX_THREADS + tid] = (unsigned short)k;   // utils/common.py:447-449: a hit on point 0 is zeroed
-                else zero_slot = true;
-                cnt++;
-            }
-        }
-    }
-    // Phase 3: slot by slot, all centre lanes evaluate de-rotation -> 3->16 MLP -> BN -> ReLU -> running max together.
+    unsigned nz = 0, bits = 0;
+    int wcur = 0;
+    if (active)
+        for (int w = 0; w < W; w++) nz |= (mask[w * VOX_THREADS + tid] != 0u ? 1u : 0u) << w;
     float acc[VOX_CH];
 #pragma unroll
     for (int ch = 0; ch < VOX_CH; ch++) acc[ch] = -3.4e38f;
-    for (int sidx = 0; __any(sidx < nreal); sidx++) {
-        if (sidx < nreal) {
-            float4 q = pts[hits[sidx * VOX_THREADS + tid]];
-            float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz = q.z;
+    for (int sidx = 0; sidx < nsample && __any(bits != 0u || nz != 0u); sidx++) {
+        if (bits == 0u && nz != 0u) {
+            wcur = __ffs(nz) - 1;
+            nz &= nz - 1u;
+            bits = mask[wcur * VOX_THREADS + tid];
+        }
+        if (bits != 0u) {
+            const int k = wcur * 32 + __ffs(bits) - 1;
+            bits &= bits - 1u;
+            cnt++;
+            if (k != 0) {                                        // utils/common.py:447-449: a hit on point 0 is zeroed
+                const float4 q = pts[k];
+                const float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz_ = q.z;
 #pragma unroll
-            for (int ch = 0; ch < VOX_CH; ch++) {
-                const float h = fmaf(M.w[ch][2], nz, fmaf(M.w[ch][1], ny, fmaf(M.w[ch][0], nx, M.b[ch])));
-                acc[ch] = fmaxf(fmaxf(acc[ch], h), 0.f);         // v_max3: ReLU and the running max
-            }
+                for (int ch = 0; ch < VOX_CH; ch++) {
+                    const float h = fmaf(M.w[ch][2], nz_, fmaf(M.w[ch][1], ny, fmaf(M.w[ch][0], nx, M.b[ch])));
+                    acc[ch] = fmaxf(fmaxf(acc[ch], h), 0.f);     // v_max3: ReLU and the running max
+                }
+            } else zero_slot = true;
         }
     }
     if (active) {
@@ -262,8 +265,7 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
         for (int j = 0; j < 3; j++) M.w[ch][j] = bn_scale[ch] * mlp_w[3 * ch + j];
         M.b[ch] = bn_scale[ch] * mlp_b[ch] + bn_shift[ch];
     }
-    const size_t lds = sizeof(float4) * (size_t)npts + sizeof(unsigned) * (size_t)((npts + 31) / 32) * VOX_THREADS +
-                       sizeof(unsigned short) * (size_t)nsample * VOX_THREADS;
+    const size_t lds = sizeof(float4) * (size_t)npts + sizeof(unsigned) * (size_t)((npts + 31) / 32) * VOX_THREADS;
     static LdsGrant grant;
     if (lds > 48 * 1024)
         if (int rc = grant_dynamic_lds((const void*)k_patch_voxelize, lds, grant)) return rc;
