@@ -147,17 +147,17 @@ __global__ void __launch_bounds__(256) k_hypotheses(const float* __restrict__ in
     for (int r = 0; r < 3; r++) t_out[3 * (size_t)i + r] = tt[3 * (size_t)i + r] - (R[3 * r] * sx + R[3 * r + 1] * sy + R[3 * r + 2] * sz);
 }
 
-// one workgroup per hypothesis h: count j with ||R_h ss_j + t_h - tt_j|| < ||ss_j|| * pi/azi_n * inlier_th
-__global__ void __launch_bounds__(256) k_score(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ ss,
-                                             const float* __restrict__ tt, int m, float azi_n, float inlier_th,
-                                             int* __restrict__ inlier_num)
+// one workgroup per hypothesis h (stacked row h, pair rows [lo, hi)): count j with
+//   ||R_h ss_j + t_h - tt_j|| < ||ss_j|| * pi/azi_n * inlier_th                       (models/BUFFER.py:302-309)
+__device__ __forceinline__ void score_hypothesis(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ ss,
+                                                 const float* __restrict__ tt, int h, int lo, int hi, float azi_n, float inlier_th,
+                                                 int* __restrict__ inlier_num)
 {
-    int h = blockIdx.x;
     float r[9], tv[3];
     for (int k = 0; k < 9; k++) r[k] = R[9 * (size_t)h + k];
     for (int k = 0; k < 3; k++) tv[k] = t[3 * (size_t)h + k];
     int cnt = 0;
-    for (int j = threadIdx.x; j < m; j += 256) {
+    for (int j = lo + threadIdx.x; j < hi; j += 256) {
         float x = ss[3 * (size_t)j], y = ss[3 * (size_t)j + 1], z = ss[3 * (size_t)j + 2];
         float dx = r[0] * x + r[1] * y + r[2] * z + tv[0] - tt[3 * (size_t)j];
         float dy = r[3] * x + r[4] * y + r[5] * z + tv[1] - tt[3 * (size_t)j + 1];
@@ -173,40 +173,56 @@ __global__ void __launch_bounds__(256) k_score(const float* __restrict__ R, cons
     if (threadIdx.x == 0) inlier_num[h] = sc[0] + sc[1] + sc[2] + sc[3];
 }
 
-// argmax (first maximum, torch.argmax) + inlier mask of the winner
-__global__ void __launch_bounds__(1024) k_best_mask(const int* __restrict__ inlier_num, const float* __restrict__ R, const float* __restrict__ t,
-                                                  const float* __restrict__ ss, const float* __restrict__ tt, int m, float azi_n,
-                                                  float inlier_th, int* __restrict__ best_out, unsigned char* __restrict__ mask)
+__global__ void __launch_bounds__(256) k_score(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ ss,
+                                             const float* __restrict__ tt, int m, float azi_n, float inlier_th,
+                                             int* __restrict__ inlier_num)
+{
+    score_hypothesis(R, t, ss, tt, blockIdx.x, 0, m, azi_n, inlier_th, inlier_num);
+}
+
+// argmax (first maximum, torch.argmax) over the m hypotheses of rows [lo, lo+m) + inlier mask of the winner (1024 threads)
+__device__ __forceinline__ void best_and_mask(const int* __restrict__ inlier_num, const float* __restrict__ R, const float* __restrict__ t,
+                                              const float* __restrict__ ss, const float* __restrict__ tt, int lo, int m, float azi_n,
+                                              float inlier_th, int* __restrict__ best_out, unsigned char* __restrict__ mask)
 {
     __shared__ unsigned long long sk[16];
     unsigned long long best = 0;
     for (int i = threadIdx.x; i < m; i += 1024) {
-        unsigned long long key = ((unsigned long long)(unsigned int)(inlier_num[i] + 1) << 32) | (unsigned int)(0x7fffffff - i);
+        unsigned long long key = ((unsigned long long)(unsigned int)(inlier_num[lo + i] + 1) << 32) | (unsigned int)(0x7fffffff - i);
         best = key > best ? key : best;
     }
     for (int d = WAVE / 2; d > 0; d >>= 1) {
-        unsigned int lo = __shfl_xor((unsigned int)best, d, WAVE), hi = __shfl_xor((unsigned int)(best >> 32), d, WAVE);
-        unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        unsigned int l = __shfl_xor((unsigned int)best, d, WAVE), hgh = __shfl_xor((unsigned int)(best >> 32), d, WAVE);
+        unsigned long long o = ((unsigned long long)hgh << 32) | l;
         best = o > best ? o : best;
     }
     if ((threadIdx.x & (WAVE - 1)) == 0) sk[threadIdx.x / WAVE] = best;
     __syncthreads();
     best = 0;
     for (int i = 0; i < 16; i++) best = sk[i] > best ? sk[i] : best;
-    int h = 0x7fffffff - (int)(unsigned int)(best & 0xffffffffu);
-    if (threadIdx.x == 0) *best_out = h;
+    if (m == 0) { if (threadIdx.x == 0) *best_out = 0; return; }
+    const int h = 0x7fffffff - (int)(unsigned int)(best & 0xffffffffu);
+    if (threadIdx.x == 0) *best_out = h;                         // index inside the pair
     float r[9], tv[3];
-    for (int k = 0; k < 9; k++) r[k] = R[9 * (size_t)h + k];
-    for (int k = 0; k < 3; k++) tv[k] = t[3 * (size_t)h + k];
+    for (int k = 0; k < 9; k++) r[k] = R[9 * (size_t)(lo + h) + k];
+    for (int k = 0; k < 3; k++) tv[k] = t[3 * (size_t)(lo + h) + k];
     for (int j = threadIdx.x; j < m; j += 1024) {
-        float x = ss[3 * (size_t)j], y = ss[3 * (size_t)j + 1], z = ss[3 * (size_t)j + 2];
-        float dx = r[0] * x + r[1] * y + r[2] * z + tv[0] - tt[3 * (size_t)j];
-        float dy = r[3] * x + r[4] * y + r[5] * z + tv[1] - tt[3 * (size_t)j + 1];
-        float dz = r[6] * x + r[7] * y + r[8] * z + tv[2] - tt[3 * (size_t)j + 2];
+        const size_t g = (size_t)lo + j;
+        float x = ss[3 * g], y = ss[3 * g + 1], z = ss[3 * g + 2];
+        float dx = r[0] * x + r[1] * y + r[2] * z + tv[0] - tt[3 * g];
+        float dy = r[3] * x + r[4] * y + r[5] * z + tv[1] - tt[3 * g + 1];
+        float dz = r[6] * x + r[7] * y + r[8] * z + tv[2] - tt[3 * g + 2];
         float diff = sqrtf(dx * dx + dy * dy + dz * dz);
         float thr = sqrtf(x * x + y * y + z * z) * 3.14159265358979323846f / azi_n * inlier_th;
-        mask[j] = diff < thr ? 1 : 0;
+        mask[g] = diff < thr ? 1 : 0;
     }
+}
+
+__global__ void __launch_bounds__(1024) k_best_mask(const int* __restrict__ inlier_num, const float* __restrict__ R, const float* __restrict__ t,
+                                                  const float* __restrict__ ss, const float* __restrict__ tt, int m, float azi_n,
+                                                  float inlier_th, int* __restrict__ best_out, unsigned char* __restrict__ mask)
+{
+    best_and_mask(inlier_num, R, t, ss, tt, 0, m, azi_n, inlier_th, best_out, mask);
 }
 
 extern "C" int buf_hypotheses_score(const float* ind, const float* ss_kpts, const float* tt_kpts, const float* ss_R,
@@ -239,13 +255,11 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
 // all candidates.  key = (count << 32) | ~bits(mean squared error): larger is better.
 // ncorr_dev (nullable): the candidate count lives on the device (buf_ransac_kabsch_masked: no host round trip); fewer
 // than 3 candidates leave every key 0, which k_ransac_pick turns into the identity (open3d's result in that case).
-__global__ void __launch_bounds__(WAVE) k_ransac(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
-                                              int ncorr, const int* __restrict__ ncorr_dev, int nhyp, unsigned long long seed,
-                                              float max_dist, float edge_sim, unsigned long long* __restrict__ keys, float* __restrict__ Ts)
+__device__ __forceinline__ void ransac_hypothesis(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
+                                                  int ncorr, int nhyp, unsigned long long seed, float max_dist, float edge_sim, int h,
+                                                  unsigned long long* __restrict__ keys, float* __restrict__ Ts)
 {
-    int h = blockIdx.x * WAVE + threadIdx.x;       // one wavefront per workgroup: 4096 hypotheses spread over 64 CUs
     if (h >= nhyp) return;
-    if (ncorr_dev) ncorr = *ncorr_dev;
     unsigned long long key = 0;
     float T[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
     if (ncorr < 3) {
@@ -309,8 +323,16 @@ __global__ void __launch_bounds__(WAVE) k_ransac(const float* __restrict__ src, 
     for (int k = 0; k < 12; k++) Ts[12 * (size_t)h + k] = T[k];
 }
 
-__global__ void __launch_bounds__(1024) k_ransac_pick(const unsigned long long* __restrict__ keys, const float* __restrict__ Ts, int nhyp,
-                                                    float* __restrict__ T_out, int* __restrict__ info)
+__global__ void __launch_bounds__(WAVE) k_ransac(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
+                                              int ncorr, const int* __restrict__ ncorr_dev, int nhyp, unsigned long long seed,
+                                              float max_dist, float edge_sim, unsigned long long* __restrict__ keys, float* __restrict__ Ts)
+{
+    // one wavefront per workgroup: 4096 hypotheses spread over 64 CUs
+    ransac_hypothesis(src, tgt, corr, ncorr_dev ? *ncorr_dev : ncorr, nhyp, seed, max_dist, edge_sim, blockIdx.x * WAVE + threadIdx.x, keys, Ts);
+}
+
+__device__ __forceinline__ void ransac_pick(const unsigned long long* __restrict__ keys, const float* __restrict__ Ts, int nhyp,
+                                            float* __restrict__ T_out, int* __restrict__ info)
 {
     __shared__ unsigned long long sk[16];
     __shared__ int si[16];
@@ -338,6 +360,12 @@ __global__ void __launch_bounds__(1024) k_ransac_pick(const unsigned long long* 
     }
 }
 
+__global__ void __launch_bounds__(1024) k_ransac_pick(const unsigned long long* __restrict__ keys, const float* __restrict__ Ts, int nhyp,
+                                                    float* __restrict__ T_out, int* __restrict__ info)
+{
+    ransac_pick(keys, Ts, nhyp, T_out, info);
+}
+
 extern "C" size_t buf_ransac_ws_bytes(int nhyp) { return 256 + (size_t)nhyp * (8 + 48) + 512; }
 
 extern "C" int buf_ransac_kabsch(const float* src, const float* tgt, const int* corr, int ncorr, int nhyp,
@@ -363,8 +391,7 @@ extern "C" int buf_ransac_kabsch(const float* src, const float* tgt, const int* 
 }
 
 // ascending indices of the set bytes of mask[0..m) and their count: one wavefront, ballot + popcount per 64 entries
-__global__ void __launch_bounds__(WAVE) k_mask_compact(const unsigned char* __restrict__ mask, int m, int* __restrict__ idx,
-                                                    int* __restrict__ count)
+__device__ __forceinline__ void mask_compact(const unsigned char* __restrict__ mask, int m, int* __restrict__ idx, int* __restrict__ count)
 {
     const int lane = threadIdx.x;
     int cnt = 0;
@@ -376,6 +403,12 @@ __global__ void __launch_bounds__(WAVE) k_mask_compact(const unsigned char* __re
         cnt += __popcll(b);
     }
     if (lane == 0) *count = cnt;
+}
+
+__global__ void __launch_bounds__(WAVE) k_mask_compact(const unsigned char* __restrict__ mask, int m, int* __restrict__ idx,
+                                                    int* __restrict__ count)
+{
+    mask_compact(mask, m, idx, count);
 }
 
 extern "C" size_t buf_ransac_masked_ws_bytes(int m, int nhyp) { return buf_ransac_ws_bytes(nhyp) + sizeof(int) * ((size_t)(m > 0 ? m : 0) + 64); }
@@ -417,9 +450,8 @@ __device__ __forceinline__ float block_sum(float v, float* sh)
 }
 
 // post_refinement (BUFFER.py:382-418) + rigid_transform_3d (:424-464) for one pair per workgroup.
-__global__ void __launch_bounds__(REF_THREADS) k_post_refine(const float* __restrict__ T_init, const float* __restrict__ src,
-                                                           const float* __restrict__ tgt, int m, float thr, int iters,
-                                                           float* __restrict__ T_out, int* __restrict__ info)
+__device__ __forceinline__ void post_refine(const float* __restrict__ T_init, const float* __restrict__ src, const float* __restrict__ tgt,
+                                            int m, float thr, int iters, float* __restrict__ T_out, int* __restrict__ info)
 {
     __shared__ float sh[REF_THREADS / WAVE];
     __shared__ float Ts[12];
@@ -488,6 +520,13 @@ __global__ void __launch_bounds__(REF_THREADS) k_post_refine(const float* __rest
     if (threadIdx.x == 0 && info) { info[0] = prev; info[1] = rounds; }
 }
 
+__global__ void __launch_bounds__(REF_THREADS) k_post_refine(const float* __restrict__ T_init, const float* __restrict__ src,
+                                                           const float* __restrict__ tgt, int m, float thr, int iters,
+                                                           float* __restrict__ T_out, int* __restrict__ info)
+{
+    post_refine(T_init, src, tgt, m, thr, iters, T_out, info);
+}
+
 extern "C" int buf_post_refine(const float* T_init, const float* src, const float* tgt, int m, float inlier_threshold,
                                int iters, float* T_out, int* info_out, void* stream)
 {
@@ -512,79 +551,24 @@ __global__ void __launch_bounds__(256) k_score_b(const float* __restrict__ R, co
 {
     const int h = blockIdx.x;                                     // hypothesis = stacked match row (wave-uniform)
     const int p = find_elem(seg, nb, h);
-    const int lo = seg[p], hi = seg[p + 1];
-    float r[9], tv[3];
-    for (int k = 0; k < 9; k++) r[k] = R[9 * (size_t)h + k];
-    for (int k = 0; k < 3; k++) tv[k] = t[3 * (size_t)h + k];
-    int cnt = 0;
-    for (int j = lo + threadIdx.x; j < hi; j += 256) {
-        float x = ss[3 * (size_t)j], y = ss[3 * (size_t)j + 1], z = ss[3 * (size_t)j + 2];
-        float dx = r[0] * x + r[1] * y + r[2] * z + tv[0] - tt[3 * (size_t)j];
-        float dy = r[3] * x + r[4] * y + r[5] * z + tv[1] - tt[3 * (size_t)j + 1];
-        float dz = r[6] * x + r[7] * y + r[8] * z + tv[2] - tt[3 * (size_t)j + 2];
-        float diff = sqrtf(dx * dx + dy * dy + dz * dz);
-        float thr = sqrtf(x * x + y * y + z * z) * 3.14159265358979323846f / azi_n * inlier_th;
-        cnt += diff < thr ? 1 : 0;
-    }
-    __shared__ int sc[4];
-    for (int d = WAVE / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, WAVE);
-    if ((threadIdx.x & (WAVE - 1)) == 0) sc[threadIdx.x / WAVE] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) inlier_num[h] = sc[0] + sc[1] + sc[2] + sc[3];
+    score_hypothesis(R, t, ss, tt, h, seg[p], seg[p + 1], azi_n, inlier_th, inlier_num);
 }
 
-// per pair: argmax of the inlier counts (first maximum), the winner's inlier mask, and its ascending index list + count
+// per pair: argmax of the inlier counts (first maximum) and the winner's inlier mask
 __global__ void __launch_bounds__(1024) k_best_mask_b(const int* __restrict__ inlier_num, const float* __restrict__ R, const float* __restrict__ t,
                                                     const float* __restrict__ ss, const float* __restrict__ tt, const int* __restrict__ seg,
                                                     float azi_n, float inlier_th, int* __restrict__ best_out, unsigned char* __restrict__ mask)
 {
-    __shared__ unsigned long long sk[16];
-    const int p = blockIdx.x, lo = seg[p], m = seg[p + 1] - lo;
-    unsigned long long best = 0;
-    for (int i = threadIdx.x; i < m; i += 1024) {
-        unsigned long long key = ((unsigned long long)(unsigned int)(inlier_num[lo + i] + 1) << 32) | (unsigned int)(0x7fffffff - i);
-        best = key > best ? key : best;
-    }
-    for (int d = WAVE / 2; d > 0; d >>= 1) {
-        unsigned int l = __shfl_xor((unsigned int)best, d, WAVE), hgh = __shfl_xor((unsigned int)(best >> 32), d, WAVE);
-        unsigned long long o = ((unsigned long long)hgh << 32) | l;
-        best = o > best ? o : best;
-    }
-    if ((threadIdx.x & (WAVE - 1)) == 0) sk[threadIdx.x / WAVE] = best;
-    __syncthreads();
-    best = 0;
-    for (int i = 0; i < 16; i++) best = sk[i] > best ? sk[i] : best;
-    if (m == 0) { if (threadIdx.x == 0) best_out[p] = 0; return; }
-    const int h = 0x7fffffff - (int)(unsigned int)(best & 0xffffffffu);
-    if (threadIdx.x == 0) best_out[p] = h;
-    float r[9], tv[3];
-    for (int k = 0; k < 9; k++) r[k] = R[9 * (size_t)(lo + h) + k];
-    for (int k = 0; k < 3; k++) tv[k] = t[3 * (size_t)(lo + h) + k];
-    for (int j = threadIdx.x; j < m; j += 1024) {
-        const size_t g = (size_t)lo + j;
-        float x = ss[3 * g], y = ss[3 * g + 1], z = ss[3 * g + 2];
-        float dx = r[0] * x + r[1] * y + r[2] * z + tv[0] - tt[3 * g];
-        float dy = r[3] * x + r[4] * y + r[5] * z + tv[1] - tt[3 * g + 1];
-        float dz = r[6] * x + r[7] * y + r[8] * z + tv[2] - tt[3 * g + 2];
-        float diff = sqrtf(dx * dx + dy * dy + dz * dz);
-        float thr = sqrtf(x * x + y * y + z * z) * 3.14159265358979323846f / azi_n * inlier_th;
-        mask[g] = diff < thr ? 1 : 0;
-    }
+    const int p = blockIdx.x, lo = seg[p];
+    best_and_mask(inlier_num, R, t, ss, tt, lo, seg[p + 1] - lo, azi_n, inlier_th, best_out + p, mask);
 }
 
+// per pair: ascending indices (local to the pair) of the winner's inliers, and their count
 __global__ void __launch_bounds__(WAVE) k_mask_compact_b(const unsigned char* __restrict__ mask, const int* __restrict__ seg, int* __restrict__ idx,
                                                       int* __restrict__ count)
 {
-    const int p = blockIdx.x, lo = seg[p], m = seg[p + 1] - lo, lane = threadIdx.x;
-    int cnt = 0;
-    for (int base = 0; base < m; base += WAVE) {
-        const int i = base + lane;
-        const bool hit = i < m && mask[lo + i] != 0;
-        const unsigned long long b = __ballot(hit);
-        if (hit) idx[lo + cnt + lane_prefix(b, lane)] = i;          // indices local to the pair
-        cnt += __popcll(b);
-    }
-    if (lane == 0) count[p] = cnt;
+    const int p = blockIdx.x, lo = seg[p];
+    mask_compact(mask + lo, seg[p + 1] - lo, idx + lo, count + p);
 }
 
 // blockIdx.y = pair: the single-pair sampler / checks / scoring on the pair's own rows
@@ -593,184 +577,30 @@ __global__ void __launch_bounds__(WAVE) k_ransac_b(const float* __restrict__ src
                                                 float max_dist, float edge_sim, unsigned long long* __restrict__ keys_all, float* __restrict__ Ts_all)
 {
     const int p = blockIdx.y, lo = seg[p];
-    const int h = blockIdx.x * WAVE + threadIdx.x;
-    if (h >= nhyp) return;
-    const float* src = src_all + 3 * (size_t)lo;
-    const float* tgt = tgt_all + 3 * (size_t)lo;
-    const int* corr = idx_all + lo;
-    unsigned long long* keys = keys_all + (size_t)p * nhyp;
-    float* Ts = Ts_all + 12 * (size_t)p * nhyp;
-    const int ncorr = count[p];
-    const unsigned long long seed = seeds.s[p];
-    unsigned long long key = 0;
-    float T[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-    if (ncorr < 3) {
-        keys[h] = 0;
-        for (int k = 0; k < 12; k++) Ts[12 * (size_t)h + k] = T[k];
-        return;
-    }
-    int i0 = (int)(splitmix64(seed + 3ull * h) % (unsigned long long)ncorr);
-    int i1 = (int)(splitmix64(seed + 3ull * h + 1) % (unsigned long long)(ncorr - 1));
-    int i2 = (int)(splitmix64(seed + 3ull * h + 2) % (unsigned long long)(ncorr - 2));
-    if (i1 >= i0) i1++;
-    int lo2 = min(i0, i1), hi2 = max(i0, i1);
-    if (i2 >= lo2) i2++;
-    if (i2 >= hi2) i2++;
-    int id[3] = { corr[i0], corr[i1], corr[i2] };
-    float a[3][3], b[3][3];
-    for (int k = 0; k < 3; k++)
-        for (int c = 0; c < 3; c++) { a[k][c] = src[3 * (size_t)id[k] + c]; b[k][c] = tgt[3 * (size_t)id[k] + c]; }
-    bool ok = true;
-    for (int q0 = 0; q0 < 3 && ok; q0++) {
-        int q = (q0 + 1) % 3;
-        float ds = sqrtf(sqdist3(a[q0][0], a[q0][1], a[q0][2], a[q][0], a[q][1], a[q][2]));
-        float dt = sqrtf(sqdist3(b[q0][0], b[q0][1], b[q0][2], b[q][0], b[q][1], b[q][2]));
-        ok = ds >= dt * edge_sim && dt >= ds * edge_sim;
-    }
-    if (ok) {
-        float ca[3], cb[3];
-        for (int c = 0; c < 3; c++) { ca[c] = (a[0][c] + a[1][c] + a[2][c]) / 3.f; cb[c] = (b[0][c] + b[1][c] + b[2][c]) / 3.f; }
-        float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int k = 0; k < 3; k++)
-            for (int r = 0; r < 3; r++)
-                for (int c = 0; c < 3; c++) H[3 * r + c] += (a[k][r] - ca[r]) * (b[k][c] - cb[c]);
-        float R[9];
-        kabsch_rotation(H, R);
-        for (int r = 0; r < 3; r++) {
-            T[4 * r] = R[3 * r]; T[4 * r + 1] = R[3 * r + 1]; T[4 * r + 2] = R[3 * r + 2];
-            T[4 * r + 3] = cb[r] - (R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]);
-        }
-        for (int k = 0; k < 3 && ok; k++) {
-            float x = T[0] * a[k][0] + T[1] * a[k][1] + T[2] * a[k][2] + T[3] - b[k][0];
-            float y = T[4] * a[k][0] + T[5] * a[k][1] + T[6] * a[k][2] + T[7] - b[k][1];
-            float z = T[8] * a[k][0] + T[9] * a[k][1] + T[10] * a[k][2] + T[11] - b[k][2];
-            ok = sqrtf(x * x + y * y + z * z) <= max_dist;
-        }
-    }
-    if (ok) {
-        int cnt = 0;
-        float err2 = 0.f;
-        for (int j = 0; j < ncorr; j++) {
-            int k = corr[j];
-            float sx = src[3 * (size_t)k], sy = src[3 * (size_t)k + 1], sz = src[3 * (size_t)k + 2];
-            float x = T[0] * sx + T[1] * sy + T[2] * sz + T[3] - tgt[3 * (size_t)k];
-            float y = T[4] * sx + T[5] * sy + T[6] * sz + T[7] - tgt[3 * (size_t)k + 1];
-            float z = T[8] * sx + T[9] * sy + T[10] * sz + T[11] - tgt[3 * (size_t)k + 2];
-            float d2 = x * x + y * y + z * z;
-            if (sqrtf(d2) < max_dist) { cnt++; err2 += d2; }
-        }
-        if (cnt > 0) key = ((unsigned long long)(unsigned int)cnt << 32) | (unsigned int)~__float_as_uint(err2 / (float)cnt);
-    }
-    keys[h] = key;
-    for (int k = 0; k < 12; k++) Ts[12 * (size_t)h + k] = T[k];
+    ransac_hypothesis(src_all + 3 * (size_t)lo, tgt_all + 3 * (size_t)lo, idx_all + lo, count[p], nhyp, seeds.s[p], max_dist, edge_sim,
+                      blockIdx.x * WAVE + threadIdx.x, keys_all + (size_t)p * nhyp, Ts_all + 12 * (size_t)p * nhyp);
 }
 
 __global__ void __launch_bounds__(1024) k_ransac_pick_b(const unsigned long long* __restrict__ keys_all, const float* __restrict__ Ts_all, int nhyp,
                                                       float* __restrict__ T_out_all)
 {
     const int p = blockIdx.x;
-    const unsigned long long* keys = keys_all + (size_t)p * nhyp;
-    const float* Ts = Ts_all + 12 * (size_t)p * nhyp;
-    __shared__ unsigned long long sk[16];
-    __shared__ int si[16];
-    unsigned long long best = 0;
-    int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < nhyp; i += 1024) {
-        unsigned long long k = keys[i];
-        if (k > best || (k == best && i < bi)) { best = k; bi = i; }
-    }
-    for (int d = WAVE / 2; d > 0; d >>= 1) {
-        unsigned int l = __shfl_xor((unsigned int)best, d, WAVE), hgh = __shfl_xor((unsigned int)(best >> 32), d, WAVE);
-        int oi = __shfl_xor(bi, d, WAVE);
-        unsigned long long o = ((unsigned long long)hgh << 32) | l;
-        if (o > best || (o == best && oi < bi)) { best = o; bi = oi; }
-    }
-    if ((threadIdx.x & (WAVE - 1)) == 0) { sk[threadIdx.x / WAVE] = best; si[threadIdx.x / WAVE] = bi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        best = 0; bi = 0x7fffffff;
-        for (int i = 0; i < 16; i++) if (sk[i] > best || (sk[i] == best && si[i] < bi)) { best = sk[i]; bi = si[i]; }
-        float T[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
-        if (best != 0) for (int k = 0; k < 12; k++) T[k] = Ts[12 * (size_t)bi + k];
-        for (int k = 0; k < 16; k++) T_out_all[16 * (size_t)p + k] = T[k];
-    }
+    ransac_pick(keys_all + (size_t)p * nhyp, Ts_all + 12 * (size_t)p * nhyp, nhyp, T_out_all + 16 * (size_t)p, nullptr);
 }
 
-// one workgroup per pair: k_post_refine on the pair's rows (iters == 0: the RANSAC pose is copied); pairs with fewer than three
+// one workgroup per pair: post_refine on the pair's rows (iters == 0: the RANSAC pose is copied); pairs with fewer than three
 // matches get the identity (ThreeDMatch/test.py:242-245)
 __global__ void __launch_bounds__(REF_THREADS) k_post_refine_b(const float* __restrict__ T_init_all, const float* __restrict__ src_all,
                                                              const float* __restrict__ tgt_all, const int* __restrict__ seg, float thr, int iters,
                                                              float* __restrict__ T_out_all)
 {
-    __shared__ float sh[REF_THREADS / WAVE];
-    __shared__ float Ts[12];
     const int p = blockIdx.x, lo = seg[p], m = seg[p + 1] - lo;
-    const float* src = src_all + 3 * (size_t)lo;
-    const float* tgt = tgt_all + 3 * (size_t)lo;
     float* T_out = T_out_all + 16 * (size_t)p;
     if (m < 3) {
         if (threadIdx.x < 16) T_out[threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.f : 0.f;
         return;
     }
-    if (threadIdx.x < 12) Ts[threadIdx.x] = T_init_all[16 * (size_t)p + threadIdx.x];
-    __syncthreads();
-    int prev = 0;
-    for (int it = 0; it < iters; it++) {
-        float T[12];
-        for (int k = 0; k < 12; k++) T[k] = Ts[k];
-        float cnt = 0.f, sw = 0.f, sa[3] = { 0, 0, 0 }, sb[3] = { 0, 0, 0 };
-        for (int j = threadIdx.x; j < m; j += REF_THREADS) {
-            float x = src[3 * (size_t)j], y = src[3 * (size_t)j + 1], z = src[3 * (size_t)j + 2];
-            float bx = tgt[3 * (size_t)j], by = tgt[3 * (size_t)j + 1], bz = tgt[3 * (size_t)j + 2];
-            float dx = T[0] * x + T[1] * y + T[2] * z + T[3] - bx;
-            float dy = T[4] * x + T[5] * y + T[6] * z + T[7] - by;
-            float dz = T[8] * x + T[9] * y + T[10] * z + T[11] - bz;
-            float dis = sqrtf(dx * dx + dy * dy + dz * dz);
-            if (dis < thr) {
-                float q = dis / thr;
-                float w = 1.f / (1.f + q * q);
-                cnt += 1.f; sw += w;
-                sa[0] += w * x; sa[1] += w * y; sa[2] += w * z;
-                sb[0] += w * bx; sb[1] += w * by; sb[2] += w * bz;
-            }
-        }
-        int num = (int)(block_sum(cnt, sh) + 0.5f);
-        if (abs(num - prev) < 1) break;
-        prev = num;
-        sw = block_sum(sw, sh);
-        float ca[3], cb[3];
-        for (int c = 0; c < 3; c++) { ca[c] = block_sum(sa[c], sh) / (sw + 1e-6f); cb[c] = block_sum(sb[c], sh) / (sw + 1e-6f); }
-        float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int j = threadIdx.x; j < m; j += REF_THREADS) {
-            float x = src[3 * (size_t)j], y = src[3 * (size_t)j + 1], z = src[3 * (size_t)j + 2];
-            float bx = tgt[3 * (size_t)j], by = tgt[3 * (size_t)j + 1], bz = tgt[3 * (size_t)j + 2];
-            float dx = T[0] * x + T[1] * y + T[2] * z + T[3] - bx;
-            float dy = T[4] * x + T[5] * y + T[6] * z + T[7] - by;
-            float dz = T[8] * x + T[9] * y + T[10] * z + T[11] - bz;
-            float dis = sqrtf(dx * dx + dy * dy + dz * dz);
-            if (dis < thr) {
-                float q = dis / thr;
-                float w = 1.f / (1.f + q * q);
-                float am[3] = { x - ca[0], y - ca[1], z - ca[2] }, bm[3] = { bx - cb[0], by - cb[1], bz - cb[2] };
-                for (int r = 0; r < 3; r++)
-                    for (int c = 0; c < 3; c++) H[3 * r + c] += am[r] * w * bm[c];
-            }
-        }
-        float Hs[9];
-        for (int k = 0; k < 9; k++) Hs[k] = block_sum(H[k], sh);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float R[9];
-            kabsch_rotation(Hs, R);
-            for (int r = 0; r < 3; r++) {
-                Ts[4 * r] = R[3 * r]; Ts[4 * r + 1] = R[3 * r + 1]; Ts[4 * r + 2] = R[3 * r + 2];
-                Ts[4 * r + 3] = cb[r] - (R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]);
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 12) T_out[threadIdx.x] = Ts[threadIdx.x];
-    if (threadIdx.x >= 12 && threadIdx.x < 16) T_out[threadIdx.x] = threadIdx.x == 15 ? 1.f : 0.f;
+    post_refine(T_init_all + 16 * (size_t)p, src_all + 3 * (size_t)lo, tgt_all + 3 * (size_t)lo, m, thr, iters, T_out, nullptr);
 }
 
 extern "C" size_t buf_recover_poses_ws_bytes(int m_total, int nb, int nhyp)
