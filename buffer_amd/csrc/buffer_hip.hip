@@ -9,5 +9,6 @@
 #include "voxelize.hip"
 #include "registration.hip"
 #include "convnet.hip"
+#include "convnet_wg.hip"
 #include "costnet.hip"
 #include "preprocess.hip"

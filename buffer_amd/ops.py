@@ -508,16 +508,29 @@ def mfma_tile_weights(wt, lk_major=False):
     return np.ascontiguousarray(np.transpose(t, perm), dtype=np.float32).reshape(-1)              # [g, n, lk, li, p]
 
 
-class CylindricalNet:
-    """Device weights of Cylindrical_Net re-laid for csrc/convnet.hip: per layer Wt[(ky*3+kx)*Cin + c][Cout], MFMA-tiled."""
+def winograd_tile_weights(w):
+    """[Cout, Cin, 3, 3] -> the F(2x2, 3x3) filter transform U = G g G^T (fp64, rounded once to fp32) in the B-operand tiling
+    of csrc/convnet_wg.hip: [i][k-step][N-tile][lk][li][j] = U[i][j][16 n + li][4 ks + lk]."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin % 4 == 0 and cout % 16 == 0
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    U = np.einsum('ia,ocab,jb->ijoc', G, np.asarray(w, np.float64), G)                 # [i, j, Cout, Cin]
+    U = U.reshape(4, 4, cout // 16, 16, cin // 4, 4)                                   # [i, j, n, li, ks, lk]
+    return np.ascontiguousarray(np.transpose(U, (0, 4, 2, 5, 3, 1)), dtype=np.float32).reshape(-1)
 
-    def __init__(self, layers, device):
+
+class CylindricalNet:
+    """Device weights of Cylindrical_Net re-laid for csrc/convnet.hip: per layer Wt[(ky*3+kx)*Cin + c][Cout], MFMA-tiled
+    (winograd=True: the Winograd-domain tiling of csrc/convnet_wg.hip)."""
+
+    def __init__(self, layers, device, winograd=False):
         """layers: list of 8 (w [Cout,Cin,3,3] np.float32 with BN folded, b [Cout], relu)"""
         self.wt, self.bias, self.cin, self.cout, self.relu = [], [], [], [], []
+        self.entry = "buf_cylindrical_net_wg" if winograd else "buf_cylindrical_net"
         for w, b, relu in layers:
             cout, cin = w.shape[0], w.shape[1]
             wt = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)).reshape(9 * cin, cout), dtype=np.float32)
-            self.wt.append(torch.from_numpy(mfma_tile_weights(wt)).to(device))
+            self.wt.append(torch.from_numpy(winograd_tile_weights(w) if winograd else mfma_tile_weights(wt)).to(device))
             self.bias.append(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(device))
             self.cin.append(cin); self.cout.append(cout); self.relu.append(1 if relu else 0)
         n = len(layers)
@@ -533,8 +546,7 @@ class CylindricalNet:
         x = x.contiguous()
         P = x.shape[0]
         y = torch.empty((P, self.cout[-1], 7, 20), dtype=torch.float32, device=x.device)
-        check(L.buf_cylindrical_net(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(y), _stream()),
-              "buf_cylindrical_net")
+        check(getattr(L, self.entry)(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(y), _stream()), self.entry)
         return y
 
 

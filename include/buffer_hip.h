@@ -245,6 +245,11 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
 int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                             const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
 
+/* A11 (dense), Winograd F(2x2,3x3) form of the same stack (csrc/convnet_wg.hip): same x / y, weights in the
+ * Winograd-domain tiling [i][k-step][N-tile][lane][j] of ops.winograd_tile_weights. */
+int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
+                               const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
+
 /* A11 (head)  attention pooling + normalisation (models/patch_embedder.py:66-72,81-84): pool_layer
  * (Conv2d 1x1 32->16 + BN + ReLU, Conv2d 1x1 16->1 + BN + ReLU), desc = normalize(mean(y * w)),
  * equi = normalize(y, channel).  y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].

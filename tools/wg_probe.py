@@ -1,0 +1,71 @@
+"""Development probe: Winograd-form Cylindrical_Net against the direct-form kernel (accuracy vs an fp64 torch stack, speed)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from buffer_amd import ops
+from buffer_amd.config import THREEDMATCH
+from buffer_amd.patch_embedder import PatchEmbedder, _fold_bn
+from buffer_amd.weights import load_weights
+
+dev = torch.device('cuda:0')
+W = load_weights('3dmatch')
+pe = PatchEmbedder(W, dev, THREEDMATCH)
+layers = pe.layers
+direct = ops.CylindricalNet(layers, dev)
+wino = ops.CylindricalNet(layers, dev, winograd=True)
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+if len(sys.argv) > 2:                      # an ablation build of the Winograd kernel (tools/wg_variants.sh): speed only
+    import ctypes as C
+    alt = C.CDLL(os.path.abspath(sys.argv[2]))
+    alt.buf_cylindrical_net_wg.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    alt.buf_cylindrical_net_wg.restype = C.c_int
+
+    class Alt:
+        def __call__(self, x):
+            y = torch.empty((x.shape[0], 32, 7, 20), dtype=torch.float32, device=x.device)
+            rc = alt.buf_cylindrical_net_wg(x.data_ptr(), x.shape[0], wino._wp, wino._bp, wino._ci, wino._co, wino._re, y.data_ptr(),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            return y
+names = [('direct', direct), ('winograd', wino)] + ([(os.path.basename(sys.argv[2]), Alt())] if len(sys.argv) > 2 else [])
+g = torch.Generator(device='cpu').manual_seed(0)
+x = torch.relu(torch.randn((P, 48, 140), generator=g)).to(dev)
+
+
+def ref64(x):
+    h = x.double().reshape(-1, 48, 7, 20)
+    for w, b, relu in layers:
+        h = torch.cat([h[..., -1:], h, h[..., :1]], -1)
+        h = torch.nn.functional.pad(h, (0, 0, 1, 1))
+        h = torch.nn.functional.conv2d(h, torch.from_numpy(w).double().to(dev), torch.from_numpy(b).double().to(dev))
+        if relu:
+            h = torch.relu(h)
+    return h
+
+
+n = min(P, 64)
+r = ref64(x[:n])
+for name, net in names:
+    y = net(x[:n]).double()
+    e = (y - r).abs().max().item() / r.abs().max().item()
+    print(f'{name}: max err / max |y| = {e:.3e}   (|y|max {r.abs().max().item():.3f})', flush=True)
+for name, net in names:
+    for _ in range(2):
+        net(x)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        net(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+    print(f'{name}: {P} patches {dt*1e3:.2f} ms  {P*0.1187/dt/1e3:.1f} dense-equivalent TFLOP/s')
+
+if len(sys.argv) > 2 and hasattr(alt, 'buf_debug_wg_prof'):
+    buf = (C.c_ulonglong * 16)()
+    alt.buf_debug_wg_prof(buf, 1)
+    Alt()(x)
+    alt.buf_debug_wg_prof(buf, 0)
+    tot = buf[0]
+    names = ['total', 'K loops', 'pass prologue', 'output transform', 'barrier 1', 'stores', 'barrier 2', 'input staging']
+    for i, nme in enumerate(names):
+        print(f'   {nme:18s} {buf[i] / (4 * P):12.0f} cycles per wave-patch  {100 * buf[i] / tot:5.1f} %')
