@@ -37,8 +37,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 COST_NET_DENSE_FLOPS_PER_MATCH = 159994880.0      # 0.160 GFLOP/match, every layer as a dense convolution
 COST_NET_FLOPS_PER_MATCH = 109085696.0            # executed by csrc/costnet.hip: layer 0 separated into its S- and T-terms
-CYL_NET_SKIPPED_FRACTION = 0.0679        # share of the dense (algorithmic) FLOPs k_cyl_net does not execute: 6 of 81
-#                                          (tap, tile) pairs read only zero elevation padding
+CYL_NET_EXECUTED_FRACTION = 44 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs the stack in the Winograd F(2x2,3x3) domain:
+#                                          44 MFMAs of 16x16x4 per (4 input channels, 16 output channels) instead of the
+#                                          9 x 140 x 4 x 16 MACs of the direct form = 0.559 of the dense count
 
 # library timing ids (include/buffer_hip.h BUF_TIMED_*)
 TIMED = {'grid_query': 0, 'cyl_net': 1, 'cost_net': 2, 'select_patches': 3, 'patch_voxelize': 4, 'fps': 5, 'nn1': 6,
@@ -140,10 +141,15 @@ def traffic_of(pmc, kernel, units):
 
 def rooflines(timed, pmc, fps_bytes_per_launch, units):
     """`roofline` (dominant kernel) + `roofline_other` (every other kernel with a roofline class in SURVEY 8d)."""
-    main = roof_entry(timed, 'cyl_net', 'k_cyl_net (A11 Cylindrical_Net, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
-                      traffic_of(pmc, 'k_cyl_net', units.get('patches')),
-                      flops='dense algorithmic count (SURVEY 8d: 0.1187 GFLOP/patch); the kernel skips the (tap, tile) pairs '
-                            'that only read zero elevation padding', executed_fraction_of_dense=1 - CYL_NET_SKIPPED_FRACTION)
+    main = roof_entry(timed, 'cyl_net', 'k_cyl_net_wg (A11 Cylindrical_Net, fused fp32 MFMA, Winograd F(2x2,3x3))', 'mfma', MFMA_F32_PEAK_TFLOPS,
+                      'TFLOP/s', 1e12, traffic_of(pmc, 'k_cyl_net_wg', units.get('patches')),
+                      flops='achieved = dense algorithmic count of the reference convolutions (SURVEY 8d: 0.1187 GFLOP/patch) / time; the '
+                            'kernel evaluates them in the Winograd F(2x2,3x3) domain in fp32 and executes 0.559 of that count on the '
+                            'matrix pipe, so frac can exceed 1: executed_frac is the matrix-pipe utilisation',
+                      executed_fraction_of_dense=CYL_NET_EXECUTED_FRACTION)
+    if main:
+        main['executed_tflops'] = main['achieved'] * CYL_NET_EXECUTED_FRACTION
+        main['executed_frac'] = main['frac'] * CYL_NET_EXECUTED_FRACTION
     matches = timed['cost_net'][2] / max(timed['cost_net'][0], 1) / COST_NET_FLOPS_PER_MATCH
     other = [
         roof_entry(timed, 'cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,

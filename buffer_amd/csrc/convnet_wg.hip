@@ -288,9 +288,6 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
     float* act = lds;
     const int patch = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-#ifdef WG_STAGGER
-    if (blockIdx.x >= 256 && blockIdx.x < 512) for (int i = 0; i < WG_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
-#endif
     {   // input [48][140] -> rows of 22 with the halo columns
         const float* src = x + (size_t)patch * P.cin[0] * 140;
         for (int i = threadIdx.x; i < P.cin[0] * 140; i += WG_THREADS) {
@@ -350,14 +347,9 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net_wg: layer %d width mismatch", l);
     }
     BUF_REQUIRE(P.cout[WG_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_wg: the last layer must have 32 channels");
-    size_t lds = sizeof(float) * WG_BUF + (getenv("BUF_WG_LDS_PAD") ? atoi(getenv("BUF_WG_LDS_PAD")) : 0);
+    size_t lds = sizeof(float) * WG_BUF;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cyl_net_wg, lds, grant)) return rc;
-    if (getenv("BUF_DEBUG_OCC")) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_cyl_net_wg, WG_THREADS, lds);
-        fprintf(stderr, "k_cyl_net_wg: %d workgroups per CU at %zu B LDS\n", nb, lds);
-    }
     double macs = 0;
     for (int l = 0; l < WG_LAYERS; l++) macs += 9.0 * P.cin[l] * P.cout[l];
     TimedSpan span;

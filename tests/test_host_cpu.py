@@ -165,3 +165,31 @@ def test_mfma_tile_weights_layout():
         for g, n, lk, li, p in [(0, 0, 0, 0, 0), (2, 1, 3, 15, 2), (1, 0, 2, 7, 3), (2, 1, 0, 9, 1)]:
             k = 16 * g + (4 * lk + p if lk_major else 4 * p + lk)
             assert t[g, n, lk, li, p] == w[k, 16 * n + li]
+
+
+def test_winograd_filter_tiling_reproduces_the_convolution():
+    """ops.winograd_tile_weights (host side of csrc/convnet_wg.hip): un-tiling gives U = G g G^T, and the F(2x2,3x3) identity
+    A^T [U (.) B^T d B] A on the 4 x 10 tile grid reproduces the circular-azimuth / zero-elevation 3x3 correlation."""
+    from buffer_amd import ops
+    rng = np.random.default_rng(3)
+    cin, cout = 8, 16
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    x = rng.standard_normal((cin, 7, 20))
+    U = ops.winograd_tile_weights(w).reshape(4, cin // 4, cout // 16, 4, 16, 4)          # [i, ks, n, lk, li, j]
+    U = np.transpose(U, (0, 5, 2, 4, 1, 3)).reshape(4, 4, cout, cin).astype(np.float64)   # [i, j, Cout, Cin]
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    assert np.abs(U - np.einsum('ia,ocab,jb->ijoc', G, w.astype(np.float64), G)).max() < 1e-6
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    xp = np.zeros((cin, 10, 22))
+    xp[:, 1:8, 1:21] = x; xp[:, 1:8, 0] = x[:, :, 19]; xp[:, 1:8, 21] = x[:, :, 0]
+    ref = np.zeros((cout, 7, 20))
+    for ky in range(3):
+        for kx in range(3):
+            ref += np.einsum('oc,cyx->oyx', w[:, :, ky, kx].astype(np.float64), xp[:, ky:ky + 7, kx:kx + 20])
+    out = np.zeros((cout, 8, 20))
+    for ty in range(4):
+        for tx in range(10):
+            V = np.einsum('ia,cab,jb->ijc', BT, xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4], BT)
+            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum('ui,ijo,vj->ouv', AT, np.einsum('ijoc,ijc->ijo', U, V), AT)
+    assert np.abs(out[:, :7] - ref).max() < 1e-5 * np.abs(ref).max()

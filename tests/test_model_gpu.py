@@ -147,6 +147,37 @@ def test_fused_cylindrical_net_vs_library_convs(W, dev):
     assert (got - want).abs().max().item() < 2e-5 * max(scale, 1.0)
 
 
+def test_winograd_and_direct_forms_against_float64(W, dev):
+    """csrc/convnet_wg.hip (Winograd F(2x2,3x3), the product's form) and csrc/convnet.hip (direct form) against the stack in
+    float64: both stay within 1e-5 of the output scale on the released weights, on non-negative (post-ReLU-like) and on signed
+    inputs, and agree with each other; a patch's result does not depend on its position in the batch."""
+    from buffer_amd import ops
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    pe = PatchEmbedder(W, dev, THREEDMATCH)
+    assert pe.fused.entry == "buf_cylindrical_net_wg"
+    direct = ops.CylindricalNet(pe.layers, dev)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for signed in (False, True):
+        x = torch.rand((70, 16, 420), generator=g)
+        if signed:
+            x = x * 2 - 1
+        x = x.to(dev)
+        h = x.double().reshape(-1, 48, 7, 20)
+        for w, b, relu in pe.layers:                                         # circular azimuth, zero elevation, float64
+            h = torch.cat([h[..., -1:], h, h[..., :1]], -1)
+            h = torch.nn.functional.pad(h, (0, 0, 1, 1))
+            h = torch.nn.functional.conv2d(h, torch.from_numpy(w).double().to(dev), torch.from_numpy(b).double().to(dev))
+            h = torch.relu(h) if relu else h
+        scale = h.abs().max().item()
+        yw, yd = pe.fused(x), direct(x)
+        assert (yw.double() - h).abs().max().item() < 1e-5 * scale
+        assert (yd.double() - h).abs().max().item() < 1e-5 * scale
+        assert (yw - yd).abs().max().item() < 1e-5 * scale
+        perm = torch.randperm(70, generator=g).to(dev)
+        assert torch.equal(pe.fused(x[perm]), yw[perm])
+
+
 def test_fused_descriptor_head_vs_library(W, dev):
     """k_desc_head (attention pooling + both normalisations in one launch) == the torch restatement
     (patch_embedder.py:81-84) on conv-net outputs, on an all-zero map (eps clamps) and on P = 0."""

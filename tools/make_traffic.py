@@ -34,7 +34,7 @@ cost = [o for o in bench['roofline_other'] if o['kernel'].startswith('k_cost_net
 matches = cost['avg_algorithmic_flops'] / 109085696.0
 # unit of work per launch and the algorithmic bytes per unit (SURVEY 8d formulas)
 units = {
-    'k_cyl_net': (patches, 'patch', 48 * 140 * 4 + 32 * 140 * 4),
+    'k_cyl_net_wg': (patches, 'patch', 48 * 140 * 4 + 32 * 140 * 4),
     'k_desc_head': (patches, 'patch', 2 * 32 * 140 * 4 + 128),
     'k_patch_voxelize': (patches, 'patch', 12 * 512 + 4 * 16 * 420),
     'k_select_patches_grid': (patches, 'patch', 12 * 512 + 12),
