@@ -248,37 +248,49 @@ __device__ __forceinline__ void wg_store(const wgf4 (&Y)[3][2][2], int nt, int r
 }
 
 // One layer for the calling wavefront.  NTW N-tiles per wavefront (2 for 128 output channels), M-tiles [T0, T1).
-template <int NTW, int T0, int T1, bool GLB>
-__device__ __forceinline__ void wg_layer(float* __restrict__ act, unsigned (&RA)[3][4], float* __restrict__ out_glb, const float* __restrict__ wt,
+// The layer is written in place, so a wavefront keeps its outputs in registers until every wavefront has finished reading
+// the input.  With 128 output channels it owns two N-tiles: the upper one (channels >= 64) first -- when the layer has 64
+// input channels its rows are free and it is stored at once (EARLY), otherwise it is held while the lower one is computed.
+template <int NTW, int T0, int T1, bool GLB, bool EARLY>
+__device__ __forceinline__ void wg_layer(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
                                          const float* __restrict__ bias, int cin, int cout, int relu, int nt_first)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
+    int lane = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane));                   // lane-derived values are formed per layer: kept across the layers they are spilled
     const int li = lane & 15, lk = lane >> 4;
+    unsigned RA[3][4];                               // window-row addresses of the lane: 3 M-tiles x 4 rows, channel lk of k-step 0
+    {
+        const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)act;
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) RA[t][a] = wg_row_addr(act_addr, t, a, li, lk);
+    }
     const int k4 = cin >> 2, wstride = (cout >> 4) * 256;
-    wgf4 Y[NTW][3][2][2];
     wgf4 Ba[2], Bb[2];                               // weights of four k-steps: every pass hands the next one its first four
     wgf2 D[2][4];                                    // window rows of two steps, handed over the same way
-    bool early = false;
-    // the upper N-tile first: when its channel rows lie above the layer's input they are free to be written at once
-    const int nts[2] = { NTW == 2 ? nt_first + 4 : nt_first, nt_first };
-    const float* wp0 = wt + ((size_t)nts[0] * 64 + lane) * 4;
-    Ba[0] = *reinterpret_cast<const wgf4*>(wp0);
-    Ba[1] = *reinterpret_cast<const wgf4*>(wp0 + wstride);
-    Bb[0] = *reinterpret_cast<const wgf4*>(wp0 + 2 * wstride);
-    Bb[1] = *reinterpret_cast<const wgf4*>(wp0 + 3 * wstride);
+    const int nt_hi = NTW == 2 ? nt_first + 4 : nt_first, nt_lo = nt_first;
+    const float* wp_hi = wt + ((size_t)nt_hi * 64 + lane) * 4;
+    const float* wp_lo = wt + ((size_t)nt_lo * 64 + lane) * 4;
+    Ba[0] = *reinterpret_cast<const wgf4*>(wp_hi);
+    Ba[1] = *reinterpret_cast<const wgf4*>(wp_hi + wstride);
+    Bb[0] = *reinterpret_cast<const wgf4*>(wp_hi + 2 * wstride);
+    Bb[1] = *reinterpret_cast<const wgf4*>(wp_hi + 3 * wstride);
     wg_first_steps<0, T0, T1>(RA, D);
-#pragma unroll
-    for (int q = 0; q < NTW; q++) {
-        const float* wp = wt + ((size_t)nts[q] * 64 + lane) * 4;
-        const float* wp_after = wt + ((size_t)nts[q + 1 < NTW ? q + 1 : q] * 64 + lane) * 4;
-        wg_ntile<T0, T1>(RA, wp, wp_after, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nts[q] * 16 + lk * 4), Ba, Bb, D, Y[q]);
-        if (NTW == 2 && q == 0 && !GLB && nts[0] * 16 >= cin) { wg_store<T0, T1, false>(Y[0], nts[0], relu, act, nullptr, li, lk); early = true; }
+    wgf4 Y[NTW][3][2][2];
+    wg_ntile<T0, T1>(RA, wp_hi, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_hi * 16 + lk * 4), Ba, Bb, D, Y[0]);
+    // EARLY: known at compile time for the 64 -> 128 layer; the instantiation of the 128 -> 128 layer tests it at run time (always
+    // false there) -- with the test compiled out the register allocator parks every partial result in scratch
+    const bool early = NTW == 2 && !GLB && (EARLY || nt_hi * 16 >= cin);
+    if constexpr (NTW == 2) {
+        if (early) wg_store<T0, T1, false>(Y[0], nt_hi, relu, act, nullptr, li, lk);
+        wg_ntile<T0, T1>(RA, wp_lo, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_lo * 16 + lk * 4), Ba, Bb, D, Y[1]);
     }
     __syncthreads();                                 // every wavefront has finished reading the layer's input
 #pragma unroll
     for (int q = 0; q < NTW; q++) {
         if (NTW == 2 && q == 0 && early) continue;
-        wg_store<T0, T1, GLB>(Y[q], nts[q], relu, act, out_glb, li, lk);
+        wg_store<T0, T1, GLB>(Y[q], q == 0 ? nt_hi : nt_lo, relu, act, out_glb, li, lk);
     }
 }
 
@@ -301,29 +313,21 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
         }
     }
     for (int i = threadIdx.x; i < WG_MAXC * 6; i += WG_THREADS) act[(i / 6) * WG_CS + WG_ZERO + i % 6] = 0.f;
-    // the lane's twelve window-row addresses (3 M-tiles x 4 rows, channel lk of k-step 0): the same for every layer
-    unsigned RA[3][4];
-    {
-        const int lane = threadIdx.x & (WAVE - 1);
-        const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)act;
-#pragma unroll
-        for (int t = 0; t < 3; t++)
-#pragma unroll
-            for (int a = 0; a < 4; a++) RA[t][a] = wg_row_addr(act_addr, t, a, lane & 15, lane >> 4);
-    }
     __syncthreads();
 #pragma unroll 1
     for (int l = 0; l < WG_LAYERS; l++) {
         const int cin = P.cin[l], cout = P.cout[l];
-        if (cout == 128)     wg_layer<2, 0, 3, false>(act, RA, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-        else if (cout == 64) wg_layer<1, 0, 3, false>(act, RA, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        if (cout == 128) {
+            if (cin <= 64)   wg_layer<2, 0, 3, false, true>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+            else             wg_layer<2, 0, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        } else if (cout == 64) wg_layer<1, 0, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (l < WG_LAYERS - 1) {
-            if (w & 1)       wg_layer<1, 2, 3, false>(act, RA, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer<1, 0, 2, false>(act, RA, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer<1, 2, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer<1, 0, 2, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         } else {
             float* glb = y + (size_t)patch * cout * 140;
-            if (w & 1)       wg_layer<1, 2, 3, true>(act, RA, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer<1, 0, 2, true>(act, RA, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer<1, 2, 3, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer<1, 0, 2, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         }
         __syncthreads();
     }
