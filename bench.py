@@ -10,7 +10,7 @@ registration pairs/sec; default workload = configs[1], one 3DMatch-shape fragmen
 A step registers `--pairs-per-step` device-resident synthetic pairs on every rank through ONE set of stacked launches
 per stage.  Pairs are sharded over the ranks with no data-path collective; one all_gather of the poses ends the timed
 region (barrier + synchronize on both sides, max over ranks).  Rank 0 prints ONE JSON line: whole-job pairs/s, the
-`roofline` object of the dominant hand-written kernel (k_cyl_net; HIP events on its launch stream inside the library),
+`roofline` object of the dominant hand-written kernel (k_cyl_net_wg; HIP events on its launch stream inside the library),
 `roofline_other` for every other kernel SURVEY 8(d) assigns a roofline class to, and, at N=1, `cpu_baseline`: the
 reference's cpp_wrappers cores (oracle/_ref) + the torch-CPU restatement of the model timed on this box's host cores on
 the SAME pair at the SAME keypoint count (no extrapolation).

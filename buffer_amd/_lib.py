@@ -71,6 +71,7 @@ _SIGNATURES = {
                                 _vp, _vp, _sz, _vp]),
     "buf_cylindrical_net": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_cylindrical_net_wg": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_winograd_tile_weights": (_i, [_vp, _i, _i, _vp]),
     "buf_voxel_downsample_ws_bytes": (_sz, [_i, _i64]),
     "buf_voxel_downsample": (_i, [_vp, _vp, _i, _i, C.c_double, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "buf_knn_normals": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),

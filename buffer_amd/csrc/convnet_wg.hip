@@ -334,6 +334,29 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
 }
 
 
+// Host helper: filters w [Cout][Cin][3][3] (BN folded) -> U = G g G^T in fp64, rounded once, in the kernel's B-operand tiling
+// out[16 * Cout * Cin] = [i][k-step][N-tile][lk][li][j] = U[i][j][16 n + li][4 ks + lk].  No device work.
+extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host)
+{
+    BUF_REQUIRE(w_host && out_host, BUF_EINVAL, "buf_winograd_tile_weights: null argument");
+    BUF_REQUIRE(cout > 0 && cin > 0 && cout % 16 == 0 && cin % 4 == 0, BUF_EINVAL, "buf_winograd_tile_weights: widths %d -> %d", cin, cout);
+    static const double G[4][3] = { { 1, 0, 0 }, { .5, .5, .5 }, { .5, -.5, .5 }, { 0, 0, 1 } };
+    const int k4 = cin / 4, nt = cout / 16;
+    for (int o = 0; o < cout; o++)
+        for (int c = 0; c < cin; c++) {
+            const float* g = w_host + ((size_t)o * cin + c) * 9;
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    double u = 0;
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++) u += G[i][a] * (double)g[3 * a + b] * G[j][b];
+                    const size_t idx = ((((size_t)i * k4 + c / 4) * nt + o / 16) * 4 + c % 4) * 16 + o % 16;
+                    out_host[idx * 4 + j] = (float)u;
+                }
+        }
+    return BUF_OK;
+}
+
 // x f32[np,48,140] -> y f32[np,32,140]; weights in the Winograd-domain tiling (see CylWgParams).
 extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                       const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream)

@@ -245,8 +245,13 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
 int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                             const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
 
-/* A11 (dense), Winograd F(2x2,3x3) form of the same stack (csrc/convnet_wg.hip): same x / y, weights in the
- * Winograd-domain tiling [i][k-step][N-tile][lane][j] of ops.winograd_tile_weights. */
+/* A11 (dense), the form the pipeline runs: the same stack evaluated in the Winograd F(2x2,3x3) domain, all fp32
+ * (csrc/convnet_wg.hip: 44 instead of 75 matrix instructions per 4 input x 16 output channels; a different fp32 summation
+ * order, within 1e-6 of the output scale of the direct form).  Same x / y as buf_cylindrical_net.
+ * wt_host[l]: DEVICE pointers to U = G g G^T of the BN-folded filters ([Cout,Cin,3,3]; layer 0: Cin = c16*3 + depth) in the
+ * tiling [i][k-step][N-tile][lk][li][j] = U[i][j][16 n + li][4 ks + lk] (buf_winograd_tile_weights, fp64 on the host); Cin a multiple of 16,
+ * Cout in {32, 64, 128}, last layer 32. */
+int     buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host);   /* host only: [Cout,Cin,3,3] -> 16*Cout*Cin floats */
 int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
 

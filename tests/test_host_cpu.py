@@ -193,3 +193,11 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
             V = np.einsum('ia,cab,jb->ijc', BT, xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4], BT)
             out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum('ui,ijo,vj->ouv', AT, np.einsum('ijoc,ijc->ijo', U, V), AT)
     assert np.abs(out[:, :7] - ref).max() < 1e-5 * np.abs(ref).max()
+    # the C-ABI host helper produces the same tiling, bit for bit
+    import ctypes as C
+    from buffer_amd import _lib
+    w2 = np.ascontiguousarray(rng.standard_normal((32, 16, 3, 3)).astype(np.float32))
+    got = np.empty(16 * 32 * 16, np.float32)
+    rc = _lib.lib().buf_winograd_tile_weights(w2.ctypes.data_as(C.c_void_p), 32, 16, got.ctypes.data_as(C.c_void_p))
+    assert rc == 0 and np.array_equal(got, ops.winograd_tile_weights(w2))
+    assert _lib.lib().buf_winograd_tile_weights(w2.ctypes.data_as(C.c_void_p), 30, 16, got.ctypes.data_as(C.c_void_p)) == -1

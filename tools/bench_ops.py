@@ -34,7 +34,7 @@ if which == 'cyl':
         pe.fused(x)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 5
-    print(f'cyl_net 5000 patches: {dt*1e3:.2f} ms  {5000*0.1187/dt/1e3:.1f} TFLOP/s  ({5000*0.1187/dt/1e3/157.3*100:.0f}% of fp32 MFMA peak)')
+    print(f'cyl_net_wg 5000 patches: {dt*1e3:.2f} ms  {5000*0.1187/dt/1e3:.1f} dense-equivalent TFLOP/s  (matrix pipe {5000*0.1187*0.5587/dt/1e3/157.3*100:.0f}% busy)')
 if which == 'radius':
     npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20

@@ -44,15 +44,15 @@ static void run(float* out, int wgs_per_cu)
 {
     const int iters = 4000, ncu = 256;
     size_t lds = wgs_per_cu == 1 ? 100 * 1024 : 32 * 1024;
-    hipFuncSetAttribute((const void*)k_mix<K, L, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_mix<K, L, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k_mix<K, L, PK><<<ncu * wgs_per_cu, 256, lds>>>(out, 10);
-    hipEventRecord(e0);
+    (void)hipEventRecord(e0);
     k_mix<K, L, PK><<<ncu * wgs_per_cu, 256, lds>>>(out, iters);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     double mfma_per_simd = (double)iters * 16 * wgs_per_cu;
     double cyc = ms * 1e-3 * 2.4e9 / mfma_per_simd;
     printf("VALU/MFMA %d (%s)  ds_read_b64/MFMA %d  waves/SIMD %d : %.1f cycles per MFMA at 2.4 GHz (%.0f %% of the matrix pipe)\n", K,
@@ -61,7 +61,7 @@ static void run(float* out, int wgs_per_cu)
 
 int main()
 {
-    float* out; hipMalloc(&out, 1 << 22);
+    float* out; (void)hipMalloc(&out, 1 << 22);
     for (int w = 1; w <= 2; w++) {
         run<0, 0, 0>(out, w); run<1, 0, 0>(out, w); run<2, 0, 0>(out, w); run<3, 0, 0>(out, w); run<4, 0, 0>(out, w); run<6, 0, 0>(out, w);
         run<2, 0, 1>(out, w); run<4, 0, 1>(out, w);

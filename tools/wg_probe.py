@@ -1,4 +1,5 @@
-"""Development probe: Winograd-form Cylindrical_Net against the direct-form kernel (accuracy vs an fp64 torch stack, speed)."""
+"""Development probe: the Winograd-form Cylindrical_Net kernel (csrc/convnet_wg.hip) against the direct-form one
+(csrc/convnet.hip): accuracy vs the stack in float64, speed.   python tools/wg_probe.py [patches]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,20 +15,7 @@ layers = pe.layers
 direct = ops.CylindricalNet(layers, dev)
 wino = ops.CylindricalNet(layers, dev, winograd=True)
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-if len(sys.argv) > 2:                      # an ablation build of the Winograd kernel (tools/wg_variants.sh): speed only
-    import ctypes as C
-    alt = C.CDLL(os.path.abspath(sys.argv[2]))
-    alt.buf_cylindrical_net_wg.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
-    alt.buf_cylindrical_net_wg.restype = C.c_int
-
-    class Alt:
-        def __call__(self, x):
-            y = torch.empty((x.shape[0], 32, 7, 20), dtype=torch.float32, device=x.device)
-            rc = alt.buf_cylindrical_net_wg(x.data_ptr(), x.shape[0], wino._wp, wino._bp, wino._ci, wino._co, wino._re, y.data_ptr(),
-                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            assert rc == 0
-            return y
-names = [('direct', direct), ('winograd', wino)] + ([(os.path.basename(sys.argv[2]), Alt())] if len(sys.argv) > 2 else [])
+names = [('direct', direct), ('winograd', wino)]
 g = torch.Generator(device='cpu').manual_seed(0)
 x = torch.relu(torch.randn((P, 48, 140), generator=g)).to(dev)
 
@@ -60,12 +48,3 @@ for name, net in names:
     dt = (time.perf_counter() - t) / 5
     print(f'{name}: {P} patches {dt*1e3:.2f} ms  {P*0.1187/dt/1e3:.1f} dense-equivalent TFLOP/s')
 
-if len(sys.argv) > 2 and hasattr(alt, 'buf_debug_wg_prof'):
-    buf = (C.c_ulonglong * 16)()
-    alt.buf_debug_wg_prof(buf, 1)
-    Alt()(x)
-    alt.buf_debug_wg_prof(buf, 0)
-    tot = buf[0]
-    names = ['total', 'K loops', 'pass prologue', 'output transform', 'barrier 1', 'stores', 'barrier 2', 'input staging']
-    for i, nme in enumerate(names):
-        print(f'   {nme:18s} {buf[i] / (4 * P):12.0f} cycles per wave-patch  {100 * buf[i] / tot:5.1f} %')
