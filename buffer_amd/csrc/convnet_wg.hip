@@ -191,15 +191,17 @@ __device__ __forceinline__ void wg_ntile(unsigned (&RA)[3][4], const float* __re
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[t][j] = (wgf4){ 0.f, 0.f, 0.f, 0.f };
+            for (int j = 0; j < 4; j++) acc[t][j] = (I == 1 && j == 1) ? bv : (wgf4){ 0.f, 0.f, 0.f, 0.f };
         wg_pass<I, INEXT, T0, T1>(RA, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, k4, wstride, Ba, Bb, D, acc);
 #pragma unroll
         for (int t = T0; t < T1; t++) {
             if (I == 3 && t == 2) continue;
             const wgf4 s0 = acc[t][0] + acc[t][1] + acc[t][2];
             const wgf4 s1 = acc[t][1] - acc[t][2] - acc[t][3];
-            if constexpr (I == 0) { Y[t][0][0] = s0 + bv; Y[t][0][1] = s1 + bv; }
-            else if constexpr (I == 1) { Y[t][0][0] += s0; Y[t][0][1] += s1; Y[t][1][0] = s0 + bv; Y[t][1][1] = s1 + bv; }
+            // the bias rides in component (1, 1)'s accumulator: it is the one term both column sums of row component 1 contain once,
+            // and row component 1 enters both output rows once
+            if constexpr (I == 0) { Y[t][0][0] = s0; Y[t][0][1] = s1; }
+            else if constexpr (I == 1) { Y[t][0][0] += s0; Y[t][0][1] += s1; Y[t][1][0] = s0; Y[t][1][1] = s1; }
             else if constexpr (I == 2) { Y[t][0][0] += s0; Y[t][0][1] += s1; Y[t][1][0] -= s0; Y[t][1][1] -= s1; }
             else { Y[t][1][0] -= s0; Y[t][1][1] -= s1; }
         }
@@ -322,12 +324,12 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
             else             wg_layer<2, 0, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         } else if (cout == 64) wg_layer<1, 0, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (l < WG_LAYERS - 1) {
-            if (w & 1)       wg_layer<1, 2, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer<1, 0, 2, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer<1, 1, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer<1, 0, 1, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         } else {
             float* glb = y + (size_t)patch * cout * 140;
-            if (w & 1)       wg_layer<1, 2, 3, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer<1, 0, 2, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer<1, 1, 3, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer<1, 0, 1, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         }
         __syncthreads();
     }
