@@ -39,6 +39,44 @@ __global__ void __launch_bounds__(256, 2) k_mix(float* out, int iters)
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// VALU issue rate alone: 64 independent v_add_f32 / v_fma_f32 / v_pk_add_f32 per loop iteration, W wavefronts per SIMD
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) k_valu(float* out, int iters)
+{
+    float v[8];
+    for (int i = 0; i < 8; i++) v[i] = threadIdx.x * 1e-3f + i;
+    f2 p[4] = { { v[0], v[1] }, { v[2], v[3] }, { v[4], v[5] }, { v[6], v[7] } };
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[k & 7]) : "v"(v[(k + 3) & 7]));
+            else if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[k & 7]) : "v"(v[(k + 3) & 7]));
+            else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k & 3]) : "v"(p[(k + 1) & 3]));
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; i++) s += v[i];
+    for (int i = 0; i < 4; i++) s += p[i].x + p[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int KIND>
+static void run_valu(float* out, int wgs_per_cu)
+{
+    const int iters = 4000, ncu = 256;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k_valu<KIND><<<ncu * wgs_per_cu, 256>>>(out, 10);
+    (void)hipEventRecord(e0);
+    k_valu<KIND><<<ncu * wgs_per_cu, 256>>>(out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double per_simd = (double)iters * 64 * wgs_per_cu;
+    printf("%s alone, waves/SIMD %d : %.2f cycles per wave-instruction per SIMD at 2.4 GHz\n",
+           KIND == 0 ? "v_add_f32" : KIND == 1 ? "v_fma_f32" : "v_pk_add_f32", wgs_per_cu, ms * 1e-3 * 2.4e9 / per_simd);
+}
+
 template <int K, int L, int PK>
 static void run(float* out, int wgs_per_cu)
 {
@@ -62,6 +100,7 @@ static void run(float* out, int wgs_per_cu)
 int main()
 {
     float* out; (void)hipMalloc(&out, 1 << 22);
+    for (int w = 1; w <= 4; w *= 2) { run_valu<0>(out, w); run_valu<1>(out, w); run_valu<2>(out, w); }
     for (int w = 1; w <= 2; w++) {
         run<0, 0, 0>(out, w); run<1, 0, 0>(out, w); run<2, 0, 0>(out, w); run<3, 0, 0>(out, w); run<4, 0, 0>(out, w); run<6, 0, 0>(out, w);
         run<2, 0, 1>(out, w); run<4, 0, 1>(out, w);
