@@ -13,12 +13,13 @@
 // Reuses the bucketed counting sort of subsample.hip: every voxel's run is contiguous and in INPUT order.
 struct O3dGrid { double o[3]; double voxel; };
 
+#define O3D_BBOX_BLOCKS 256
+// bounding box in two steps: O3D_BBOX_BLOCKS partial boxes (grid-stride), then one workgroup folds them and derives the grid
 template <typename T>
-__global__ void __launch_bounds__(1024) k_o3d_bbox(const T* __restrict__ pts, int n, double voxel, VoxGrid* __restrict__ grid,
-                                                 O3dGrid* __restrict__ og)
+__global__ void __launch_bounds__(256) k_o3d_bbox_partial(const T* __restrict__ pts, int n, double* __restrict__ part)
 {
     double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += 256 * O3D_BBOX_BLOCKS) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             double v = (double)pts[3 * (size_t)i + c];
@@ -26,11 +27,33 @@ __global__ void __launch_bounds__(1024) k_o3d_bbox(const T* __restrict__ pts, in
             mx[c] = v > mx[c] ? v : mx[c];
         }
     }
-    __shared__ double smn[3][16], smx[3][16];
+    __shared__ double smn[3][4], smx[3][4];
     int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         double a = mn[c], z = mx[c];
+        for (int d = WAVE / 2; d > 0; d >>= 1) {
+            a = fmin(a, __shfl_xor(a, d, WAVE));
+            z = fmax(z, __shfl_xor(z, d, WAVE));
+        }
+        if (lane == 0) { smn[c][w] = a; smx[c][w] = z; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        part[6 * blockIdx.x + c] = fmin(fmin(smn[c][0], smn[c][1]), fmin(smn[c][2], smn[c][3]));
+        part[6 * blockIdx.x + 3 + c] = fmax(fmax(smx[c][0], smx[c][1]), fmax(smx[c][2], smx[c][3]));
+    }
+}
+
+__global__ void __launch_bounds__(O3D_BBOX_BLOCKS) k_o3d_bbox(const double* __restrict__ part, int n, double voxel, VoxGrid* __restrict__ grid,
+                                                            O3dGrid* __restrict__ og)
+{
+    __shared__ double smn[3][O3D_BBOX_BLOCKS / WAVE], smx[3][O3D_BBOX_BLOCKS / WAVE];
+    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double a = part[6 * threadIdx.x + c], z = part[6 * threadIdx.x + 3 + c];
         for (int d = WAVE / 2; d > 0; d >>= 1) {
             a = fmin(a, __shfl_xor(a, d, WAVE));
             z = fmax(z, __shfl_xor(z, d, WAVE));
@@ -45,7 +68,7 @@ __global__ void __launch_bounds__(1024) k_o3d_bbox(const T* __restrict__ pts, in
         double N[3];
         for (int c = 0; c < 3; c++) {
             double a = smn[c][0], z = smx[c][0];
-            for (int i = 1; i < 16; i++) { a = fmin(a, smn[c][i]); z = fmax(z, smx[c][i]); }
+            for (int i = 1; i < O3D_BBOX_BLOCKS / WAVE; i++) { a = fmin(a, smn[c][i]); z = fmax(z, smx[c][i]); }
             if (n <= 0) { a = 0.0; z = 0.0; }
             o.o[c] = a - voxel * 0.5;                               // voxel_min_bound
             N[c] = floor((z - o.o[c]) / voxel) + 1.0;
@@ -119,6 +142,7 @@ extern "C" size_t buf_voxel_downsample_ws_bytes(int n, int64_t max_cells)
     WsCarver w(nullptr, 0);
     carve_vox(w, n, 1, max_cells, 0);
     w.take<O3dGrid>(1);
+    w.take<double>(6 * O3D_BBOX_BLOCKS);
     return w.used();
 }
 
@@ -129,9 +153,11 @@ static int voxel_downsample_impl(const T* pts, const T* normals, int n, double v
     WsCarver w(ws, ws_bytes);
     VoxWs v = carve_vox(w, n, 1, max_cells, 0);
     O3dGrid* og = w.take<O3dGrid>(1);
+    double* part = w.take<double>(6 * O3D_BBOX_BLOCKS);
     BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_voxel_downsample: workspace %zu < %zu bytes", ws_bytes, w.used());
     BUF_CHECK_HIP(hipMemsetAsync(v.table, 0, sizeof(int) * (size_t)max_cells, s));
-    k_o3d_bbox<T><<<1, 1024, 0, s>>>(pts, n, voxel, v.grids, og);
+    k_o3d_bbox_partial<T><<<O3D_BBOX_BLOCKS, 256, 0, s>>>(pts, n, part);
+    k_o3d_bbox<<<1, O3D_BBOX_BLOCKS, 0, s>>>(part, n, voxel, v.grids, og);
     k_vox_offsets<<<1, 1, 0, s>>>(v.grids, 1, (long long)max_cells, v.st);
     int blocks = cdiv(n, 256);
     k_o3d_count<T><<<blocks, 256, 0, s>>>(pts, n, v.grids, og, v.st, v.table, v.cell_of, v.keys);

@@ -28,7 +28,7 @@ def voxel_down_sample(points, voxel_size, normals=None, max_cells=0):
         normals = _dev(normals, dt, "voxel_down_sample.normals")
     n = int(points.shape[0])
     if max_cells <= 0:
-        max_cells = max(1 << 22, 64 * n)
+        max_cells = max(1 << 16, 4 * n)          # bucket table of the counting sort: the result does not depend on it, the scan over it costs
     nbytes = L.buf_voxel_downsample_ws_bytes(n, max_cells)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
     out = torch.empty((max(n, 1), 3), dtype=torch.float64, device=points.device)
@@ -105,19 +105,28 @@ def prepare_fragments(raws, downsample, voxel_size_0, max_num_pts=30000, seeds=N
     """The test-split branch of ThreeDMatchDataset.__getitem__ (dataset.py:93-95,125-153) for SEVERAL fragments:
     raws: list of f32[n,3] device tensors -> list of dict(fds_pts f32[N,3] shuffled, sds_pts f32[M,6] = shuffled
     second-level points + normals).  The two voxel levels and the shuffles run per fragment (second level on the first
-    level's fp64 means, like open3d's chained calls; fragment i shuffles with generator seed seeds[i]); the 30-NN normals of
+    level's fp64 means, like open3d's chained calls; fragment i shuffles with the keyed permutation of seeds[i]); the 30-NN normals of
     all fragments are estimated in ONE stacked pass.  Fragment by fragment the result is that of prepare_fragment."""
     seeds = list(range(len(raws))) if seeds is None else list(seeds)
     out, sds_all = [], []
+    if not raws:
+        return out
+    levels, keys = [], []
     for raw, seed in zip(raws, seeds):
-        dev = raw.device
-        g = torch.Generator(device=dev).manual_seed(int(seed))
         fds = voxel_down_sample(raw, downsample)
-        sds = voxel_down_sample(fds, voxel_size_0)
-        fds32 = fds[torch.randperm(fds.shape[0], generator=g, device=dev)].float()             # np.random.shuffle
-        sds32 = sds[torch.randperm(sds.shape[0], generator=g, device=dev)].float()
+        sds = voxel_down_sample(fds, voxel_size_0)                  # on the first level's fp64 means (chained open3d calls)
+        levels += [fds.float(), sds.float()]
+        keys += [ops.perm_key(seed, 0), ops.perm_key(seed, 1)]
+    # np.random.shuffle of both levels (dataset.py:95,112): a keyed pseudo-random permutation per cloud, ONE launch for all of
+    # them (torch.randperm is a radix sort per call)
+    stacked, lens = ops.permute_clouds(levels, keys)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    for i, seed in enumerate(seeds):
+        fds32 = stacked[offs[2 * i]:offs[2 * i + 1]]
+        sds32 = stacked[offs[2 * i + 1]:offs[2 * i + 2]]
         if sds32.shape[0] > max_num_pts:                                                       # dataset.py:131-137
-            sds32 = sds32[torch.randperm(sds32.shape[0], generator=g, device=dev)[:max_num_pts]]
+            g = torch.Generator(device=sds32.device).manual_seed(int(seed))
+            sds32 = sds32[torch.randperm(sds32.shape[0], generator=g, device=sds32.device)[:max_num_pts]]
         out.append(dict(fds_pts=fds32.contiguous()))
         sds_all.append(sds32.contiguous())
     if with_normals and sds_all:
