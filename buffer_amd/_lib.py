@@ -74,6 +74,8 @@ _SIGNATURES = {
     "buf_winograd_tile_weights": (_i, [_vp, _i, _i, _vp]),
     "buf_voxel_downsample_ws_bytes": (_sz, [_i, _i64]),
     "buf_voxel_downsample": (_i, [_vp, _vp, _i, _i, C.c_double, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "buf_voxel_downsample_batch_ws_bytes": (_sz, [_i, _i, _i64]),
+    "buf_voxel_downsample_batch": (_i, [_vp, _i, _i, _vp, _i, C.c_double, _vp, _vp, _i64, _vp, _sz, _vp]),
     "buf_knn_normals": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "buf_row_linear": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "buf_segment_instance_norm_ws_bytes": (_sz, [_i, _i]),

@@ -5,6 +5,7 @@
 // VoxelDownSample, EstimateNormals.cpp ComputeCovariance/FastEigen3x3 = D. Eberly, "A Robust Eigensolver for 3x3
 // Symmetric Matrices"), all arithmetic in fp64 like open3d's Eigen::Vector3d clouds.  PARITY UNPINNED.
 #include "common.h"
+#include <vector>
 
 // ---------------------------------------------------------------------------------- voxel_down_sample
 // voxel_min_bound = min - voxel/2; index = floor((p - voxel_min_bound) / voxel) per axis; one output row per
@@ -13,13 +14,15 @@
 // Reuses the bucketed counting sort of subsample.hip: every voxel's run is contiguous and in INPUT order.
 struct O3dGrid { double o[3]; double voxel; };
 
-#define O3D_BBOX_BLOCKS 256
-// bounding box in two steps: O3D_BBOX_BLOCKS partial boxes (grid-stride), then one workgroup folds them and derives the grid
+#define O3D_BBOX_BLOCKS 64
+// bounding box of every batch element in two steps: O3D_BBOX_BLOCKS partial boxes per element (grid-stride inside its point
+// range), then one workgroup per element folds them and derives the element's grid
 template <typename T>
-__global__ void __launch_bounds__(256) k_o3d_bbox_partial(const T* __restrict__ pts, int n, double* __restrict__ part)
+__global__ void __launch_bounds__(256) k_o3d_bbox_partial(const T* __restrict__ pts, const int* __restrict__ off, double* __restrict__ part)
 {
+    const int b = blockIdx.y, lo = off[b], hi = off[b + 1];
     double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += 256 * O3D_BBOX_BLOCKS) {
+    for (int i = lo + blockIdx.x * 256 + threadIdx.x; i < hi; i += 256 * O3D_BBOX_BLOCKS) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             double v = (double)pts[3 * (size_t)i + c];
@@ -41,59 +44,61 @@ __global__ void __launch_bounds__(256) k_o3d_bbox_partial(const T* __restrict__ 
     __syncthreads();
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
-        part[6 * blockIdx.x + c] = fmin(fmin(smn[c][0], smn[c][1]), fmin(smn[c][2], smn[c][3]));
-        part[6 * blockIdx.x + 3 + c] = fmax(fmax(smx[c][0], smx[c][1]), fmax(smx[c][2], smx[c][3]));
+        double* dst = part + 6 * ((size_t)b * O3D_BBOX_BLOCKS + blockIdx.x);
+        dst[c] = fmin(fmin(smn[c][0], smn[c][1]), fmin(smn[c][2], smn[c][3]));
+        dst[3 + c] = fmax(fmax(smx[c][0], smx[c][1]), fmax(smx[c][2], smx[c][3]));
     }
 }
 
-__global__ void __launch_bounds__(O3D_BBOX_BLOCKS) k_o3d_bbox(const double* __restrict__ part, int n, double voxel, VoxGrid* __restrict__ grid,
-                                                            O3dGrid* __restrict__ og)
+__global__ void __launch_bounds__(O3D_BBOX_BLOCKS) k_o3d_bbox(const double* __restrict__ part, const int* __restrict__ off, double voxel,
+                                                            VoxGrid* __restrict__ grid, O3dGrid* __restrict__ og)
 {
-    __shared__ double smn[3][O3D_BBOX_BLOCKS / WAVE], smx[3][O3D_BBOX_BLOCKS / WAVE];
-    int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int b = blockIdx.x, lo = off[b], hi = off[b + 1];
+    const double* src = part + 6 * ((size_t)b * O3D_BBOX_BLOCKS + threadIdx.x);
+    double bb[6];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        double a = part[6 * threadIdx.x + c], z = part[6 * threadIdx.x + 3 + c];
+        double a = src[c], z = src[3 + c];
         for (int d = WAVE / 2; d > 0; d >>= 1) {
             a = fmin(a, __shfl_xor(a, d, WAVE));
             z = fmax(z, __shfl_xor(z, d, WAVE));
         }
-        if (lane == 0) { smn[c][w] = a; smx[c][w] = z; }
+        bb[c] = a; bb[3 + c] = z;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {                                          // O3D_BBOX_BLOCKS == WAVE: one wavefront holds all partials
         VoxGrid g;
         O3dGrid o;
         o.voxel = voxel;
         double N[3];
         for (int c = 0; c < 3; c++) {
-            double a = smn[c][0], z = smx[c][0];
-            for (int i = 1; i < O3D_BBOX_BLOCKS / WAVE; i++) { a = fmin(a, smn[c][i]); z = fmax(z, smx[c][i]); }
-            if (n <= 0) { a = 0.0; z = 0.0; }
+            double a = bb[c], z = bb[3 + c];
+            if (hi <= lo) { a = 0.0; z = 0.0; }
             o.o[c] = a - voxel * 0.5;                               // voxel_min_bound
             N[c] = floor((z - o.o[c]) / voxel) + 1.0;
             g.o[c] = (float)o.o[c];
         }
         g.dl = (float)voxel;
-        g.lo = 0; g.hi = n;
+        g.lo = lo; g.hi = hi;
         g.NX = (unsigned long long)(long long)N[0];
         g.NY = (unsigned long long)(long long)N[1];
         g.cells = fmax(N[0], 1.0) * fmax(N[1], 1.0) * fmax(N[2], 1.0);
         g.nbuckets = 1; g.table_off = 0;
-        grid[0] = g;
-        og[0] = o;
+        grid[b] = g;
+        og[b] = o;
     }
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_o3d_count(const T* __restrict__ pts, int n, const VoxGrid* __restrict__ grid,
-                                                 const O3dGrid* __restrict__ og, const VoxStatus* __restrict__ st,
-                                                 int* __restrict__ table, int* __restrict__ cell_of, unsigned long long* __restrict__ keys)
+__global__ void __launch_bounds__(256) k_o3d_count(const T* __restrict__ pts, int n, const int* __restrict__ off, int nb,
+                                                 const VoxGrid* __restrict__ grid, const O3dGrid* __restrict__ og,
+                                                 const VoxStatus* __restrict__ st, int* __restrict__ table, int* __restrict__ cell_of,
+                                                 unsigned long long* __restrict__ keys)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || st->error) return;
-    const VoxGrid g = grid[0];
-    const O3dGrid o = og[0];
+    const int b = nb > 1 ? find_elem(off, nb, i) : 0;
+    const VoxGrid g = grid[b];
+    const O3dGrid o = og[b];
     unsigned long long ix = (unsigned long long)(long long)floor(((double)pts[3 * (size_t)i] - o.o[0]) / o.voxel);
     unsigned long long iy = (unsigned long long)(long long)floor(((double)pts[3 * (size_t)i + 1] - o.o[1]) / o.voxel);
     unsigned long long iz = (unsigned long long)(long long)floor(((double)pts[3 * (size_t)i + 2] - o.o[2]) / o.voxel);
@@ -137,31 +142,42 @@ __global__ void __launch_bounds__(256) k_o3d_emit(const T* __restrict__ pts, con
     }
 }
 
-extern "C" size_t buf_voxel_downsample_ws_bytes(int n, int64_t max_cells)
+static VoxWs carve_o3d(WsCarver& w, int n, int nb, int64_t max_cells, O3dGrid** og, double** part)
+{
+    VoxWs v = carve_vox(w, n, nb, max_cells, 0);
+    *og = w.take<O3dGrid>((size_t)nb);
+    *part = w.take<double>(6 * (size_t)O3D_BBOX_BLOCKS * nb);
+    return v;
+}
+
+extern "C" size_t buf_voxel_downsample_batch_ws_bytes(int n, int nb, int64_t max_cells)
 {
     WsCarver w(nullptr, 0);
-    carve_vox(w, n, 1, max_cells, 0);
-    w.take<O3dGrid>(1);
-    w.take<double>(6 * O3D_BBOX_BLOCKS);
+    O3dGrid* og; double* part;
+    carve_o3d(w, n, nb > 0 ? nb : 1, max_cells, &og, &part);
     return w.used();
 }
 
+extern "C" size_t buf_voxel_downsample_ws_bytes(int n, int64_t max_cells) { return buf_voxel_downsample_batch_ws_bytes(n, 1, max_cells); }
+
+// nb clouds stacked in pts (lengths_host); output rows of cloud b start at the sum of the earlier clouds' counts
 template <typename T>
-static int voxel_downsample_impl(const T* pts, const T* normals, int n, double voxel, double* out_pts, double* out_normals,
-                                 int* out_m_host, int64_t max_cells, void* ws, size_t ws_bytes, hipStream_t s)
+static int voxel_downsample_impl(const T* pts, const T* normals, int n, const int* lengths_host, int nb, double voxel, double* out_pts,
+                                 double* out_normals, int* out_lengths_host, int64_t max_cells, void* ws, size_t ws_bytes, hipStream_t s)
 {
     WsCarver w(ws, ws_bytes);
-    VoxWs v = carve_vox(w, n, 1, max_cells, 0);
-    O3dGrid* og = w.take<O3dGrid>(1);
-    double* part = w.take<double>(6 * O3D_BBOX_BLOCKS);
+    O3dGrid* og; double* part;
+    VoxWs v = carve_o3d(w, n, nb, max_cells, &og, &part);
     BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_voxel_downsample: workspace %zu < %zu bytes", ws_bytes, w.used());
+    int rc = upload_offsets(v.off, lengths_host, nb, n, "buf_voxel_downsample", s);
+    if (rc) return rc;
     BUF_CHECK_HIP(hipMemsetAsync(v.table, 0, sizeof(int) * (size_t)max_cells, s));
-    k_o3d_bbox_partial<T><<<O3D_BBOX_BLOCKS, 256, 0, s>>>(pts, n, part);
-    k_o3d_bbox<<<1, O3D_BBOX_BLOCKS, 0, s>>>(part, n, voxel, v.grids, og);
-    k_vox_offsets<<<1, 1, 0, s>>>(v.grids, 1, (long long)max_cells, v.st);
+    k_o3d_bbox_partial<T><<<dim3(O3D_BBOX_BLOCKS, nb), 256, 0, s>>>(pts, v.off, part);
+    k_o3d_bbox<<<nb, O3D_BBOX_BLOCKS, 0, s>>>(part, v.off, voxel, v.grids, og);
+    k_vox_offsets<<<1, 1, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
     int blocks = cdiv(n, 256);
-    k_o3d_count<T><<<blocks, 256, 0, s>>>(pts, n, v.grids, og, v.st, v.table, v.cell_of, v.keys);
-    int rc = exclusive_scan_i32(v.table, (long long)max_cells, v.scan_tmp, nullptr, s);
+    k_o3d_count<T><<<blocks, 256, 0, s>>>(pts, n, v.off, nb, v.grids, og, v.st, v.table, v.cell_of, v.keys);
+    rc = exclusive_scan_i32(v.table, (long long)max_cells, v.scan_tmp, nullptr, s);
     if (rc) return rc;
     // only the input index (.w) of the scattered rows is used afterwards: the coordinates are re-read in fp64
     k_cell_scatter<<<blocks, 256, 0, s>>>((const float*)pts, n, v.cell_of, &v.st->error, v.table, v.sorted_tmp);
@@ -170,15 +186,31 @@ static int voxel_downsample_impl(const T* pts, const T* normals, int n, double v
     rc = exclusive_scan_i32(v.head, n, v.scan_tmp, v.total, s);
     if (rc) return rc;
     k_o3d_emit<T><<<blocks, 256, 0, s>>>(pts, normals, v.sorted, v.key_sorted, v.cell_sorted, v.head, n, v.st, out_pts, out_normals);
+    k_vox_counts<<<cdiv(nb + 1, 64), 64, 0, s>>>(v.head, v.off, nb, n, 0, v.total, v.st, v.counts);
     BUF_LAUNCH_CHECK();
-    int hc[2] = { 0, 0 };
-    hipError_t e = hipMemcpyAsync(&hc[0], &v.st->error, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&hc[1], v.total, sizeof(int), hipMemcpyDeviceToHost, s);
+    std::vector<int> hc((size_t)nb + 2);
+    hipError_t e = hipMemcpyAsync(hc.data(), v.counts, sizeof(int) * hc.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     BUF_CHECK_HIP(e);
-    BUF_REQUIRE(!hc[0], BUF_ECAPACITY, "buf_voxel_downsample: bucket table does not fit max_cells=%lld", (long long)max_cells);
-    *out_m_host = hc[1];
+    BUF_REQUIRE(!hc[nb], BUF_ECAPACITY, "buf_voxel_downsample: bucket table does not fit max_cells=%lld", (long long)max_cells);
+    for (int b2 = 0; b2 < nb; b2++) out_lengths_host[b2] = hc[b2];
     return BUF_OK;
+}
+
+extern "C" int buf_voxel_downsample_batch(const void* pts, int is_f64, int n, const int* lengths_host, int nb, double voxel_size,
+                                          double* out_pts, int* out_lengths_host, int64_t max_cells, void* ws, size_t ws_bytes, void* stream)
+{
+    BUF_REQUIRE(lengths_host && out_lengths_host && ws, BUF_EINVAL, "buf_voxel_downsample_batch: null argument");
+    BUF_REQUIRE(n >= 0 && nb > 0, BUF_EINVAL, "buf_voxel_downsample_batch: n=%d nb=%d", n, nb);
+    BUF_REQUIRE(voxel_size > 0.0, BUF_EINVAL, "buf_voxel_downsample_batch: voxel_size=%g must be > 0", voxel_size);
+    BUF_REQUIRE(max_cells >= 2LL * nb && max_cells < 0x7fffffffLL, BUF_EINVAL, "buf_voxel_downsample_batch: max_cells=%lld", (long long)max_cells);
+    if (n == 0) { for (int b = 0; b < nb; b++) out_lengths_host[b] = 0; return BUF_OK; }
+    BUF_REQUIRE(pts && out_pts, BUF_EINVAL, "buf_voxel_downsample_batch: null points");
+    if (is_f64)
+        return voxel_downsample_impl<double>((const double*)pts, nullptr, n, lengths_host, nb, voxel_size, out_pts, nullptr, out_lengths_host,
+                                             max_cells, ws, ws_bytes, (hipStream_t)stream);
+    return voxel_downsample_impl<float>((const float*)pts, nullptr, n, lengths_host, nb, voxel_size, out_pts, nullptr, out_lengths_host,
+                                        max_cells, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int buf_voxel_downsample(const void* pts, const void* normals, int is_f64, int n, double voxel_size, double* out_pts,
@@ -192,9 +224,9 @@ extern "C" int buf_voxel_downsample(const void* pts, const void* normals, int is
     BUF_REQUIRE(pts && out_pts && (!normals || out_normals), BUF_EINVAL, "buf_voxel_downsample: null points");
     // k_cell_scatter reads 3 floats per point from the input viewed as float: fine for both element types
     if (is_f64)
-        return voxel_downsample_impl<double>((const double*)pts, (const double*)normals, n, voxel_size, out_pts, out_normals, out_m_host,
+        return voxel_downsample_impl<double>((const double*)pts, (const double*)normals, n, &n, 1, voxel_size, out_pts, out_normals, out_m_host,
                                              max_cells, ws, ws_bytes, (hipStream_t)stream);
-    return voxel_downsample_impl<float>((const float*)pts, (const float*)normals, n, voxel_size, out_pts, out_normals, out_m_host,
+    return voxel_downsample_impl<float>((const float*)pts, (const float*)normals, n, &n, 1, voxel_size, out_pts, out_normals, out_m_host,
                                         max_cells, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -42,6 +42,33 @@ def voxel_down_sample(points, voxel_size, normals=None, max_cells=0):
     return out[:m.value]
 
 
+def voxel_down_sample_batch(points, lengths, voxel_size, max_cells=0):
+    """voxel_down_sample for several clouds stacked in `points` (f32|f64[sum n_c,3], lengths int[nc]) in one set of launches and
+    one host round trip -> (f64[sum m_c,3] voxel means cloud after cloud, int32[nc] row counts); cloud by cloud the rows are
+    those of voxel_down_sample."""
+    L = _lib.lib()
+    if not isinstance(points, torch.Tensor) or not points.is_cuda:
+        raise _lib.BufferHipError("voxel_down_sample_batch: expected a tensor in device memory (buffer_amd has no CPU path)")
+    if not voxel_size > 0:
+        raise _lib.BufferHipError("voxel_down_sample: voxel_size <= 0.")
+    dt = torch.float64 if points.dtype == torch.float64 else torch.float32
+    points = points.to(dt).contiguous()
+    lens = np.ascontiguousarray(lengths, dtype=np.int32)
+    n, nb = int(points.shape[0]), int(lens.shape[0])
+    if int(lens.sum()) != n or nb == 0:
+        raise _lib.BufferHipError("voxel_down_sample_batch: lengths do not sum to the number of points")
+    if max_cells <= 0:
+        max_cells = max(1 << 16, 4 * n, 2 * nb)
+    nbytes = L.buf_voxel_downsample_batch_ws_bytes(n, nb, max_cells)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
+    out = torch.empty((max(n, 1), 3), dtype=torch.float64, device=points.device)
+    out_lens = np.zeros(nb, np.int32)
+    check(L.buf_voxel_downsample_batch(_ptr(points), 1 if dt == torch.float64 else 0, n, lens.ctypes.data_as(C.c_void_p), nb,
+                                       float(voxel_size), _ptr(out), out_lens.ctypes.data_as(C.c_void_p), max_cells, _ptr(ws), nbytes,
+                                       _stream()), "buf_voxel_downsample_batch")
+    return out[:int(out_lens.sum())], out_lens
+
+
 def estimate_normals(points, knn=30, camera=(0.0, 0.0, 0.0), orient=True, radius=None, ncand=40, grow=1.35, lengths=None):
     """open3d estimate_normals(KDTreeSearchParamKNN(knn)) [+ orient_normals_towards_camera_location(camera)]:
     points f32[n,3] (device) -> unit normals f32[n,3].  `lengths` (optional): the rows are several clouds stacked
@@ -111,11 +138,15 @@ def prepare_fragments(raws, downsample, voxel_size_0, max_num_pts=30000, seeds=N
     out, sds_all = [], []
     if not raws:
         return out
+    # both voxel levels for all fragments at once (second level on the first level's fp64 means: chained open3d calls)
+    fds_all, fds_lens = voxel_down_sample_batch(torch.cat(raws) if len(raws) > 1 else raws[0], [int(r.shape[0]) for r in raws], downsample)
+    sds_all64, sds_lens = voxel_down_sample_batch(fds_all, fds_lens, voxel_size_0)
+    fds32, sds32_all = fds_all.float(), sds_all64.float()
+    fo = np.concatenate([[0], np.cumsum(fds_lens)])
+    so = np.concatenate([[0], np.cumsum(sds_lens)])
     levels, keys = [], []
-    for raw, seed in zip(raws, seeds):
-        fds = voxel_down_sample(raw, downsample)
-        sds = voxel_down_sample(fds, voxel_size_0)                  # on the first level's fp64 means (chained open3d calls)
-        levels += [fds.float(), sds.float()]
+    for i, seed in enumerate(seeds):
+        levels += [fds32[fo[i]:fo[i + 1]], sds32_all[so[i]:so[i + 1]]]
         keys += [ops.perm_key(seed, 0), ops.perm_key(seed, 1)]
     # np.random.shuffle of both levels (dataset.py:95,112): a keyed pseudo-random permutation per cloud, ONE launch for all of
     # them (torch.randperm is a radix sort per call)

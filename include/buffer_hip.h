@@ -332,6 +332,12 @@ int     buf_recover_poses_batched(const float* ind, const float* ss_kpts, const 
 size_t  buf_voxel_downsample_ws_bytes(int n, int64_t max_cells);
 int     buf_voxel_downsample(const void* pts, const void* normals, int is_f64, int n, double voxel_size, double* out_pts,
                              double* out_normals, int* out_m_host, int64_t max_cells, void* ws, size_t ws_bytes, void* stream);
+/* The same for nb clouds stacked in pts (lengths_host int[nb]) in ONE set of launches and one host round trip: out_pts holds the
+ * voxel means of cloud 0, then cloud 1, ... (out_lengths_host int[nb]); every cloud has its own bounding box / voxel grid, so the
+ * rows equal those of nb separate calls. */
+size_t  buf_voxel_downsample_batch_ws_bytes(int n, int nb, int64_t max_cells);
+int     buf_voxel_downsample_batch(const void* pts, int is_f64, int n, const int* lengths_host, int nb, double voxel_size,
+                                   double* out_pts, int* out_lengths_host, int64_t max_cells, void* ws, size_t ws_bytes, void* stream);
 int     buf_knn_normals(const float* pts, int ns, const int* qidx, int nq, const int* cand, int ncand, int knn,
                         const double* camera_host, int orient, float* normals, unsigned char* deficient, void* stream);
 

@@ -209,3 +209,24 @@ def test_prepare_fragments_stacked_normals_equal_one_by_one(dev):
         assert torch.equal(g['fds_pts'], want['fds_pts']) and torch.equal(g['sds_pts'], want['sds_pts'])
     nrm = got[0]['sds_pts'][:, 3:]
     assert torch.allclose(nrm.norm(dim=1), torch.ones_like(nrm[:, 0]), atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_voxel_down_sample_batch_equals_cloud_by_cloud(dev):
+    """buf_voxel_downsample_batch: several stacked clouds (own bounding box each, one of them empty, fp32 and fp64 input) give,
+    cloud by cloud, exactly the rows of separate voxel_down_sample calls."""
+    import torch
+    from buffer_amd import preprocess
+    g = torch.Generator(device='cpu').manual_seed(4)
+    clouds = [torch.rand((n, 3), generator=g) * s + o for n, s, o in ((5000, 2.0, 0.0), (1, 1.0, 5.0), (0, 1.0, 0.0), (12345, 3.0, -7.0), (777, 0.5, 100.0))]
+    for dt in (torch.float32, torch.float64):
+        cl = [c.to(dt).to(dev) for c in clouds]
+        lens = [int(c.shape[0]) for c in cl]
+        out, out_lens = preprocess.voxel_down_sample_batch(torch.cat(cl), lens, 0.11)
+        lo = 0
+        for c, m in zip(cl, out_lens):
+            want = preprocess.voxel_down_sample(c, 0.11) if c.shape[0] else torch.zeros((0, 3), dtype=torch.float64, device=dev)
+            assert int(m) == want.shape[0]
+            assert torch.equal(out[lo:lo + int(m)], want)
+            lo += int(m)
+        assert lo == out.shape[0]

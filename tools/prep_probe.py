@@ -15,3 +15,5 @@ s32 = [s.float() for s in sds]
 t3, nr = T(lambda: [preprocess.estimate_normals(s) for s in s32])
 t4, _ = T(lambda: [stream.prepare(r, cfg, i) for i, r in enumerate(raws)])
 print(f'16 fragments: voxel L1 {t1:.1f} ms, voxel L2 {t2:.1f} ms, normals {t3:.1f} ms, prepare (all) {t4:.1f} ms; raw {clouds[0].shape[0]} fds {fds[0].shape[0]} sds {sds[0].shape[0]}')
+t5, _ = T(lambda: stream.prepare_batch(raws, cfg, list(range(len(raws)))))
+print(f'prepare_batch (8 pairs, stacked normals): {t5:.1f} ms = {t5 / 8:.2f} ms per pair')
