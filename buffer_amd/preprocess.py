@@ -12,6 +12,9 @@ from ._lib import check
 from .ops import _dev, _ptr, _stream
 
 
+_SHUFFLE_SALT = 0x5851F42D4C957F2D
+
+
 def voxel_down_sample(points, voxel_size, normals=None, max_cells=0):
     """open3d PointCloud.voxel_down_sample: points f32|f64[n,3] (device) -> f64[m,3] voxel means
     (, f64[m,3] mean normals), rows in ascending voxel-key order."""
@@ -147,7 +150,8 @@ def prepare_fragments(raws, downsample, voxel_size_0, max_num_pts=30000, seeds=N
     levels, keys = [], []
     for i, seed in enumerate(seeds):
         levels += [fds32[fo[i]:fo[i + 1]], sds32_all[so[i]:so[i + 1]]]
-        keys += [ops.perm_key(seed, 0), ops.perm_key(seed, 1)]
+        # salted: the pipeline permutes the support clouds of pair `seed` with perm_key(seed, 0 / 1) itself
+        keys += [ops.perm_key(seed, 0) ^ _SHUFFLE_SALT, ops.perm_key(seed, 1) ^ _SHUFFLE_SALT]
     # np.random.shuffle of both levels (dataset.py:95,112): a keyed pseudo-random permutation per cloud, ONE launch for all of
     # them (torch.randperm is a radix sort per call)
     stacked, lens = ops.permute_clouds(levels, keys)

@@ -114,6 +114,34 @@ def test_c_abi_error_codes(dev):
     rc = L.buf_permute_clouds(ptrs, lens, keys, 1, t.data_ptr(), s)
     assert rc == -1 and b"cloud 0" in L.buf_last_error()
     assert L.buf_permute_clouds(ptrs, lens, keys, 0, None, s) == 0          # nothing to do
+    # Winograd-form descriptor CNN: widths it does not support, missing weights; batched voxel down-sampling: lengths, voxel size
+    x = torch.zeros(2, 48, 140, device=dev)
+    y = torch.zeros(2, 32, 140, device=dev)
+    wts = [torch.zeros(16 * 128 * 128, device=dev) for _ in range(8)]
+    bs = [torch.zeros(128, device=dev) for _ in range(8)]
+    wp, bp = (C.c_void_p * 8)(*[w.data_ptr() for w in wts]), (C.c_void_p * 8)(*[b.data_ptr() for b in bs])
+    relu = (C.c_int * 8)(1, 1, 1, 1, 1, 1, 1, 0)
+    good_in, good_out = (48, 64, 64, 128, 128, 64, 64, 32), (64, 64, 128, 128, 64, 64, 32, 32)
+    assert L.buf_cylindrical_net_wg(x.data_ptr(), 0, wp, bp, (C.c_int * 8)(*good_in), (C.c_int * 8)(*good_out), relu, y.data_ptr(), s) == 0
+    assert L.buf_cylindrical_net_wg(x.data_ptr(), 2, wp, bp, (C.c_int * 8)(*good_in), (C.c_int * 8)(*good_out), relu, y.data_ptr(), s) == 0
+    bad_in = (C.c_int * 8)(40, 64, 64, 128, 128, 64, 64, 32)                    # 40 input channels: not a multiple of 16
+    rc = L.buf_cylindrical_net_wg(x.data_ptr(), 2, wp, bp, bad_in, (C.c_int * 8)(*good_out), relu, y.data_ptr(), s)
+    assert rc == -1 and b"unsupported widths" in L.buf_last_error()
+    bad_out = (C.c_int * 8)(64, 64, 128, 128, 64, 64, 32, 64)                   # the last layer must have 32 channels
+    rc = L.buf_cylindrical_net_wg(x.data_ptr(), 2, wp, bp, (C.c_int * 8)(*good_in), bad_out, relu, y.data_ptr(), s)
+    assert rc == -1
+    wp_null = (C.c_void_p * 8)(*([w.data_ptr() for w in wts[:7]] + [None]))
+    rc = L.buf_cylindrical_net_wg(x.data_ptr(), 2, wp_null, bp, (C.c_int * 8)(*good_in), (C.c_int * 8)(*good_out), relu, y.data_ptr(), s)
+    assert rc == -1 and b"null weights" in L.buf_last_error()
+    from buffer_amd import preprocess
+    with pytest.raises(_lib.BufferHipError):
+        preprocess.voxel_down_sample_batch(t, [60, 30], 0.1)                  # lengths do not sum to the number of points
+    with pytest.raises(_lib.BufferHipError):
+        preprocess.voxel_down_sample_batch(t, [100], 0.0)
+    out64 = torch.empty(100, 3, dtype=torch.float64, device=dev)
+    olen = (C.c_int * 1)(0)
+    rc = L.buf_voxel_downsample_batch(t.data_ptr(), 0, 100, lens, 1, 0.1, out64.data_ptr(), olen, 1 << 16, ws.data_ptr(), 1024, s)
+    assert rc == -3 and b"workspace" in L.buf_last_error()
     torch.cuda.synchronize()
 
 
