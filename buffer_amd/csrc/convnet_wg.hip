@@ -183,27 +183,41 @@ __device__ __forceinline__ void wg_ntile(unsigned (&RA)[3][4], const float* __re
 {
     const size_t pstride = (size_t)k4 * wstride;
     using std::integral_constant;
+    // The accumulators run on through the four passes (cleared once per N-tile): after pass I they hold the sum of the row
+    // components 0..I, F_I = its column transform, and with s_i = F_i - F_(i-1)
+    //     output row 0 = s_0 + s_1 + s_2 = F_2,      output row 1 = s_1 - s_2 - s_3 = -F_0 + 2 F_1 - F_3
+    // -- three accumulator clears and half of the output-transform adds less per N-tile (VALU work is what this kernel is short of).
+    // The bias enters component (1, 1)'s accumulator before pass 1: F_1, F_2, F_3 then carry it once in both columns.
+    wgf4 acc[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[t][j] = (wgf4){ 0.f, 0.f, 0.f, 0.f };
     auto run = [&](auto ic) __attribute__((always_inline)) {
         constexpr int I = decltype(ic)::value;
         // component 3 does nothing for a wavefront that only has M-tile 2: the pass before it hands over to component 0
         constexpr int INEXT = (I == 3 || (I == 2 && wg_te(3, T1) <= T0)) ? 0 : I + 1;
-        wgf4 acc[3][4];
+        if constexpr (I == 1) {
 #pragma unroll
-        for (int t = 0; t < 3; t++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[t][j] = (I == 1 && j == 1) ? bv : (wgf4){ 0.f, 0.f, 0.f, 0.f };
+            for (int t = T0; t < T1; t++) acc[t][1] += bv;
+        }
         wg_pass<I, INEXT, T0, T1>(RA, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, k4, wstride, Ba, Bb, D, acc);
 #pragma unroll
         for (int t = T0; t < T1; t++) {
             if (I == 3 && t == 2) continue;
-            const wgf4 s0 = acc[t][0] + acc[t][1] + acc[t][2];
-            const wgf4 s1 = acc[t][1] - acc[t][2] - acc[t][3];
-            // the bias rides in component (1, 1)'s accumulator: it is the one term both column sums of row component 1 contain once,
-            // and row component 1 enters both output rows once
-            if constexpr (I == 0) { Y[t][0][0] = s0; Y[t][0][1] = s1; }
-            else if constexpr (I == 1) { Y[t][0][0] += s0; Y[t][0][1] += s1; Y[t][1][0] = s0; Y[t][1][1] = s1; }
-            else if constexpr (I == 2) { Y[t][0][0] += s0; Y[t][0][1] += s1; Y[t][1][0] -= s0; Y[t][1][1] -= s1; }
-            else { Y[t][1][0] -= s0; Y[t][1][1] -= s1; }
+            if (I == 2 ? false : t == 2) continue;              // M-tile 2 (bottom tile row) only has output row 0 = F_2
+            const wgf4 f0 = acc[t][0] + acc[t][1] + acc[t][2];
+            const wgf4 f1 = acc[t][1] - acc[t][2] - acc[t][3];
+            if constexpr (I == 0) { Y[t][1][0] = f0; Y[t][1][1] = f1; }                       // F_0 (enters with a minus sign below)
+            else if constexpr (I == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    Y[t][1][0][r] = __builtin_fmaf(2.f, f0[r], -Y[t][1][0][r]);
+                    Y[t][1][1][r] = __builtin_fmaf(2.f, f1[r], -Y[t][1][1][r]);
+                }
+            }
+            else if constexpr (I == 2) { Y[t][0][0] = f0; Y[t][0][1] = f1; }
+            else { Y[t][1][0] -= f0; Y[t][1][1] -= f1; }
         }
     };
     run(integral_constant<int, 0>{});
