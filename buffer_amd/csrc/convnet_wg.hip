@@ -112,9 +112,9 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
     constexpr int A1 = wg_a1(I), A2 = wg_a2(I);
     constexpr int TE = wg_te(I, T1);
     constexpr int NT = TE > T0 ? TE - T0 : 1;
-    constexpr int NTN = wg_te(INEXT, T1) > T0 ? wg_te(INEXT, T1) - T0 : 1;
     if constexpr (TE <= T0) return;
     float V[2][4];
+    wg_first_steps<I, T0, T1>(RA, D);
     // row component (d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3), then the four column components
 #define WG_XFORM(BUF)                                                                                     \
     {                                                                                                     \
@@ -140,9 +140,8 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
 #pragma unroll
         for (int g = 0; g < 2; g++) {                           // the two steps past this iteration: the next one's or the next pass's
             const unsigned own0 = P[g % NT][0] + (4 + g / NT) * WG_KSTEP, own1 = P[g % NT][1] + (4 + g / NT) * WG_KSTEP;
-            const unsigned nx0 = RA[T0 + g % NTN][wg_a1(INEXT)] + (g / NTN) * WG_KSTEP, nx1 = RA[T0 + g % NTN][wg_a2(INEXT)] + (g / NTN) * WG_KSTEP;
-            E[g][0] = more ? own0 : nx0;
-            E[g][1] = more ? own1 : nx1;
+            E[g][0] = more ? own0 : P[g % NT][0];         // past the end: the iteration's own first steps again (unused)
+            E[g][1] = more ? own1 : P[g % NT][1];
         }
 #pragma unroll
         for (int s = 0; s < 4 * NT; s++) {
@@ -245,18 +244,26 @@ __device__ __forceinline__ void wg_store(const wgf4 (&Y)[3][2][2], int nt, int r
             if (t == 2 && u == 1) continue;                       // M-tile 2 is tile row 3: its second output row is row 7
             const bool ok = valid && (t != 1 || u == 0 || ty < 3);
             const int row = 2 * ty + u;
-            if (ok) {
+            if constexpr (GLB) {
+                if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float v0 = fmaxf(Y[t][u][0][r], lo), v1 = fmaxf(Y[t][u][1][r], lo);
+                        *reinterpret_cast<wgf2*>(out_glb + (size_t)(n0 + r) * 140 + row * 20 + 2 * tx) = (wgf2){ v0, v1 };
+                    }
+                }
+            } else {
+                // straight-line code (a branch per store costs more than the store): lanes with nothing to write, and the halo
+                // copies of the inner tiles, go to the two spare words behind the channel's zero area
+                const int pos = ok ? row * WG_ROW + 2 * tx + 1 : WG_ZERO + 4;
+                const int h0 = (ok && tx == 0) ? row * WG_ROW + 21 : WG_ZERO + 4;      // column 0 again behind column 19
+                const int h1 = (ok && tx == 9) ? row * WG_ROW : WG_ZERO + 5;           // column 19 again in front of column 0
+                float* p = act + n0 * WG_CS;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float v0 = fmaxf(Y[t][u][0][r], lo), v1 = fmaxf(Y[t][u][1][r], lo);
-                    if constexpr (GLB) {
-                        *reinterpret_cast<wgf2*>(out_glb + (size_t)(n0 + r) * 140 + row * 20 + 2 * tx) = (wgf2){ v0, v1 };
-                    } else {
-                        float* p = act + (n0 + r) * WG_CS + row * WG_ROW + 2 * tx;
-                        p[1] = v0; p[2] = v1;
-                        if (tx == 0) p[21] = v0;            // column 0 again behind column 19
-                        if (tx == 9) p[-18] = v1;           // column 19 again in front of column 0
-                    }
+                    p[r * WG_CS + pos] = v0; p[r * WG_CS + pos + 1] = v1;
+                    p[r * WG_CS + h0] = v0; p[r * WG_CS + h1] = v1;
                 }
             }
         }
@@ -321,7 +328,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
         for (int i = threadIdx.x; i < P.cin[0] * 140; i += WG_THREADS) {
             const int c = i / 140, pos = i - c * 140;
             const int row = pos / 20, col = pos - row * 20;
-            const float v = src[i];
+            const float v = __builtin_nontemporal_load(src + i);       // streamed once: leave the L2 to the filters
             float* p = act + c * WG_CS + row * WG_ROW + col;
             p[1] = v;
             if (col == 0) p[21] = v;
