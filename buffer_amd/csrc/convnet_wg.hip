@@ -15,8 +15,8 @@
 // every read of the elevation padding), rewritten in place after each layer -> two workgroups per CU (2 x 80 KB).
 // A wavefront owns one N-tile (16 output channels) at a time and walks the four row components i of the transform as four
 // passes over K: per k-step and M-tile it reads two window rows (four ds_read_b64), forms the four column components on the
-// VALU (packed fp32 adds) and issues four MFMAs; after a pass the column/row output transform is applied in registers (the
-// C/D layout keeps a tile in one lane), so only the 2 x 2 outputs are carried between passes.
+// VALU (eight plain adds) and issues four MFMAs; the accumulators run on through the four passes and after each pass the column
+// transform of the running sum is folded into the 2 x 2 outputs in registers (the C/D layout keeps a tile in one lane).
 // LDS banking (ds_read_b64: bank = word mod 64, lanes 0-31 and 32-63 served separately): the 40 tiles are dealt to the
 // three M-tiles such that the 16 lanes of a k-step channel cover 32 distinct banks, and the channel stride 160 = 32 mod 64
 // puts the second channel of the half-wave on the other 32:
@@ -104,15 +104,17 @@ __device__ __forceinline__ void wg_first_steps(unsigned (&RA)[3][4], wgf2 (&D)[2
 // pipe on this chip (tools/micro/mfma_coissue: every VALU per MFMA costs 2.5-6 cycles of it), so the loop carries nothing
 // but the eight adds of the transform: four k-steps per iteration, their LDS offsets ride in the instructions, the weights
 // (Ba: k-steps 0-1, Bb: 2-3; one 16-byte load per k-step) are reloaded in place half an iteration ahead, and the last
-// iteration fetches the weights and the first two steps of the pass that follows (INEXT, wp_next) instead of its own.
-template <int I, int INEXT, int T0, int T1>
+// iteration fetches the weights of the pass that follows (wp_next) instead of its own.  Every pass reads its own first two
+// steps (handing them over from the previous pass cost registers -- spills -- and bought no time).
+template <int I, int T0, int T1>
 __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_next, int k4, int wstride,
-                                        wgf4 (&Ba)[2], wgf4 (&Bb)[2], wgf2 (&D)[2][4], wgf4 (&acc)[3][4])
+                                        wgf4 (&Ba)[2], wgf4 (&Bb)[2], wgf4 (&acc)[3][4])
 {
     constexpr int A1 = wg_a1(I), A2 = wg_a2(I);
     constexpr int TE = wg_te(I, T1);
     constexpr int NT = TE > T0 ? TE - T0 : 1;
     if constexpr (TE <= T0) return;
+    wgf2 D[2][4];                                               // window rows A1 (columns 0-1, 2-3) and A2 of two steps in flight
     float V[2][4];
     wg_first_steps<I, T0, T1>(RA, D);
     // row component (d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3), then the four column components
@@ -174,11 +176,10 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
 }
 
 // All 16 components of one N-tile: Y[t][u][v] = 2 x 2 outputs of the tiles of M-tile t (C/D layout: tile = lane's column).
-// On entry Ba/Bb hold the weights of the first four k-steps and D the first two steps of component 0; on exit those of
-// the N-tile at wp_after (the wavefront's next one).
+// On entry Ba/Bb hold the weights of the first four k-steps; on exit those of the N-tile at wp_after (the wavefront's next one).
 template <int T0, int T1>
 __device__ __forceinline__ void wg_ntile(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_after, int k4, int wstride,
-                                         wgf4 bv, wgf4 (&Ba)[2], wgf4 (&Bb)[2], wgf2 (&D)[2][4], wgf4 (&Y)[3][2][2])
+                                         wgf4 bv, wgf4 (&Ba)[2], wgf4 (&Bb)[2], wgf4 (&Y)[3][2][2])
 {
     const size_t pstride = (size_t)k4 * wstride;
     using std::integral_constant;
@@ -200,7 +201,7 @@ __device__ __forceinline__ void wg_ntile(unsigned (&RA)[3][4], const float* __re
 #pragma unroll
             for (int t = T0; t < T1; t++) acc[t][1] += bv;
         }
-        wg_pass<I, INEXT, T0, T1>(RA, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, k4, wstride, Ba, Bb, D, acc);
+        wg_pass<I, T0, T1>(RA, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, k4, wstride, Ba, Bb, acc);
 #pragma unroll
         for (int t = T0; t < T1; t++) {
             if (I == 3 && t == 2) continue;
@@ -291,7 +292,6 @@ __device__ __forceinline__ void wg_layer(float* __restrict__ act, float* __restr
     }
     const int k4 = cin >> 2, wstride = (cout >> 4) * 256;
     wgf4 Ba[2], Bb[2];                               // weights of four k-steps: every pass hands the next one its first four
-    wgf2 D[2][4];                                    // window rows of two steps, handed over the same way
     const int nt_hi = NTW == 2 ? nt_first + 4 : nt_first, nt_lo = nt_first;
     const float* wp_hi = wt + ((size_t)nt_hi * 64 + lane) * 4;
     const float* wp_lo = wt + ((size_t)nt_lo * 64 + lane) * 4;
@@ -299,15 +299,14 @@ __device__ __forceinline__ void wg_layer(float* __restrict__ act, float* __restr
     Ba[1] = *reinterpret_cast<const wgf4*>(wp_hi + wstride);
     Bb[0] = *reinterpret_cast<const wgf4*>(wp_hi + 2 * wstride);
     Bb[1] = *reinterpret_cast<const wgf4*>(wp_hi + 3 * wstride);
-    wg_first_steps<0, T0, T1>(RA, D);
     wgf4 Y[NTW][3][2][2];
-    wg_ntile<T0, T1>(RA, wp_hi, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_hi * 16 + lk * 4), Ba, Bb, D, Y[0]);
+    wg_ntile<T0, T1>(RA, wp_hi, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_hi * 16 + lk * 4), Ba, Bb, Y[0]);
     // EARLY: known at compile time for the 64 -> 128 layer; the instantiation of the 128 -> 128 layer tests it at run time (always
     // false there) -- with the test compiled out the register allocator parks every partial result in scratch
     const bool early = NTW == 2 && !GLB && (EARLY || nt_hi * 16 >= cin);
     if constexpr (NTW == 2) {
         if (early) wg_store<T0, T1, false>(Y[0], nt_hi, relu, act, nullptr, li, lk);
-        wg_ntile<T0, T1>(RA, wp_lo, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_lo * 16 + lk * 4), Ba, Bb, D, Y[1]);
+        wg_ntile<T0, T1>(RA, wp_lo, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_lo * 16 + lk * 4), Ba, Bb, Y[1]);
     }
     __syncthreads();                                 // every wavefront has finished reading the layer's input
 #pragma unroll
