@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(WAVE) k_grid_query(const CellGrid* __restrict_
 #define QW_WAVES 4
 #define QG 16                       // lanes per query
 #define QPW (WAVE / QG)             // queries per wavefront
-#define QW_CAP 64
+#define QW_CAP 64                   // row capacity of the LDS slice: template parameter CAP = 64, or 128 for k_out > 32 (the 30-NN
+//                                     candidate search of the normals asks for 40 and meets 5 % of rows longer than 64)
 #define QW_QPB (QW_WAVES * QPW)     // queries per workgroup
 
 // exclusive prefix sum over each row of 16 lanes (DPP row shifts, zero fill)
@@ -236,6 +237,7 @@ __device__ __forceinline__ int row16_excl_scan(int v)
     return inc - v;
 }
 
+template <int CAP>
 __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellGrid* __restrict__ grids, const int* __restrict__ table,
                                                                   const float4* __restrict__ sorted, const float* __restrict__ queries,
                                                                   const int* __restrict__ q_off,
@@ -245,8 +247,8 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
                                                                   int* __restrict__ max_count_out, int* __restrict__ todo,
                                                                   int* __restrict__ todo_n)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long keys[QW_WAVES][QPW][QW_CAP];       // arrival order
-    __shared__ __attribute__((aligned(16))) unsigned long long bkeys[QW_WAVES][QPW][QW_CAP];      // bucket order
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[QW_WAVES][QPW][CAP];       // arrival order
+    __shared__ __attribute__((aligned(16))) unsigned long long bkeys[QW_WAVES][QPW][CAP];      // bucket order
     __shared__ __attribute__((aligned(16))) int runs[QW_WAVES][QPW][20];                           // 9 starts | 9 lengths
     __shared__ int hist[QW_WAVES][QPW][QG];                                                        // bucket counts
     __shared__ int pref[QW_WAVES][QPW][QG + 4];                                                    // exclusive prefix, [16] = total
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
             const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)__float_as_int(cand[u].w);
             const unsigned long long mask = (__ballot(hit) >> (grp * QG)) & 0xffffull;
             const int pos = m + __popcll(mask & gmask_lo);
-            if (hit && pos < QW_CAP) {
+            if (hit && pos < CAP) {
                 K[pos] = key;
                 atomicAdd(&hist[w][grp][min((int)(d2 * bin_scale), QG - 1)], 1);
             }
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
         if (max_count_out && m > 0) atomicMax(max_count_out, m);
     }
     if (k_out == 0) return;
-    if (m > QW_CAP) {                    // rare: row longer than the LDS slice -> lane-per-query fallback
+    if (m > CAP) {                    // rare: row longer than the LDS slice -> lane-per-query fallback
         if (active && l16 == 0) todo[atomicAdd(todo_n, 1)] = qi;
         m = 0;
     }
@@ -356,10 +358,10 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     unsigned long long* B = bkeys[w][grp];
     const int rounds = (mmax + QG - 1) / QG;
     // scatter into bucket order; every key remembers the extent of its bucket
-    unsigned long long mine[QW_CAP / QG];
-    int blo[QW_CAP / QG], bhi[QW_CAP / QG];
+    unsigned long long mine[CAP / QG];
+    int blo[CAP / QG], bhi[CAP / QG];
 #pragma unroll
-    for (int r = 0; r < QW_CAP / QG; r++) {
+    for (int r = 0; r < CAP / QG; r++) {
         mine[r] = 0ull; blo[r] = 0; bhi[r] = 0;
         if (r < rounds) {
             const int i = r * QG + l16;
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     __builtin_amdgcn_wave_barrier();
     // rank inside the bucket (the keys of lower buckets are all smaller), then write the row
 #pragma unroll
-    for (int r = 0; r < QW_CAP / QG; r++) {
+    for (int r = 0; r < CAP / QG; r++) {
         if (r < rounds) {
             int rank = blo[r];
             for (int tt = 0; __any(blo[r] + tt < bhi[r]); tt++) {
@@ -504,9 +506,14 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
         BUF_REQUIRE(g->nb <= 65535, BUF_EINVAL, "buf_grid_query: %d batch elements (at most 65535 per call)", g->nb);
         dim3 grid2(cdiv(qmax, QW_QPB), g->nb);
         const float bin_scale = r2 > 0.f ? (float)QG / r2 : 0.f;           // distance bucket = floor(d2 * 16 / r2), monotone in d2
-        k_grid_query_wave<<<grid2, QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries,
-                                                          ex.q_off, q_order, self_query, r2, bin_scale, k_out, g->ns, nbr_out,
-                                                          counts_out, max_count_out, todo, ex.todo_n);
+        if (k_out > 32)
+            k_grid_query_wave<2 * QW_CAP><<<grid2, QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
+                                                                             queries, ex.q_off, q_order, self_query, r2, bin_scale, k_out, g->ns,
+                                                                             nbr_out, counts_out, max_count_out, todo, ex.todo_n);
+        else
+            k_grid_query_wave<QW_CAP><<<grid2, QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries,
+                                                                         ex.q_off, q_order, self_query, r2, bin_scale, k_out, g->ns, nbr_out,
+                                                                         counts_out, max_count_out, todo, ex.todo_n);
     }
     if (timed) timing_end(s, &span);
     if (k_out > 0) {
