@@ -376,7 +376,7 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
     mine = [synth.make_raw_pair_device(20000 + i, overlaps[i % len(overlaps)], dev) for i in ids]
     first = stream.prepare(synth.make_raw_pair_device(20000, stream.OVERLAPS[0], dev), cfg, 0)     # same pair on every rank
     limits = pipe.calibrate([{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in first.items()}])
-    batch = a.pairs_per_step or 16
+    batch = a.pairs_per_step or 32
     stream.run(pipe, mine[:batch], batch)                                                           # warm-up
     torch.cuda.synchronize()
     if dist:

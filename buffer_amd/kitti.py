@@ -136,9 +136,12 @@ def register_pairs(pipe, dataset, indices, batch=4):
     dev = pipe.device
     poses = []
     idx = list(indices)
-    for lo in range(0, len(idx), batch):
-        chunk = idx[lo:lo + batch]
-        poses += pipe.register_batch([upload(s) for s in items_batched(dataset, chunk, dev)], seeds=chunk)
+    # batches software-pipelined over two HIP streams: reading and pre-processing the fragments of batch i+1 and its keypoint
+    # stage run beside the CNN kernels of batch i (BufferPipeline.register_batches; results equal batch-by-batch calls)
+    chunks = [idx[lo:lo + batch] for lo in range(0, len(idx), batch)]
+    makers = [(lambda ch=ch: [upload(s) for s in items_batched(dataset, ch, dev)]) for ch in chunks]
+    for ps in pipe.register_batches(makers, seeds=chunks):
+        poses += ps
     return torch.stack(poses) if poses else torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
 
 

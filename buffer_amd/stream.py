@@ -38,7 +38,7 @@ def prepare_batch(raws, cfg, indices):
              'tgt_fds_pts': frs[2 * k + 1]['fds_pts'], 'tgt_sds_pts': frs[2 * k + 1]['sds_pts']} for k, r in enumerate(raws)]
 
 
-def run(pipe, raws, batch=16, first_index=0):
+def run(pipe, raws, batch=32, first_index=0):
     """Timed part: pre-processing + registration of every pair, `batch` pairs per set of stacked launches, batches
     software-pipelined (BufferPipeline.register_batches: pre-processing and keypoint stage of batch i+1 on the side stream
     beside the CNN kernels of batch i).  -> (poses f32[n,4,4] device, seconds)."""

@@ -159,14 +159,17 @@ def upload(sample):
                 lengths=np.array([src.shape[0], tgt.shape[0]], np.int32), src_raw=sample['src_fds_pts'], tgt_raw=sample['tgt_fds_pts'])
 
 
-def register_pairs(pipe, dataset, indices, batch=8):
+def register_pairs(pipe, dataset, indices, batch=32):
     """This rank's share of the pairs through the device pipeline -> f32[k,4,4] (device), in the order of `indices`."""
     dev = pipe.device
     poses = []
     idx = list(indices)
-    for lo in range(0, len(idx), batch):
-        chunk = idx[lo:lo + batch]
-        poses += pipe.register_batch([upload(s) for s in items_batched(dataset, chunk, dev)], seeds=chunk)
+    # batches software-pipelined over two HIP streams: reading and pre-processing the fragments of batch i+1 and its keypoint
+    # stage run beside the CNN kernels of batch i (BufferPipeline.register_batches; results equal batch-by-batch calls)
+    chunks = [idx[lo:lo + batch] for lo in range(0, len(idx), batch)]
+    makers = [(lambda ch=ch: [upload(s) for s in items_batched(dataset, ch, dev)]) for ch in chunks]
+    for ps in pipe.register_batches(makers, seeds=chunks):
+        poses += ps
     return torch.stack(poses) if poses else torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
 
 
@@ -208,7 +211,7 @@ def main(argv=None):
     ap.add_argument('--dataset', default='3DMatch', choices=['3DMatch', '3DLoMatch'])
     ap.add_argument('--log-root', default=None)
     ap.add_argument('--log-name', default=time.strftime('%m%d%H%M') + '.log')
-    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--limits', default=None, help='frozen neighbourhood limits "a,b,c" (default: calibrate like dataloader.py:18-51)')
     a = ap.parse_args(argv)
     rank, world, dev, cdev = bdist.init(int(os.environ.get('LOCAL_RANK', 0)))
