@@ -13,7 +13,7 @@ void buf_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* buf_last_error(void) { return g_err; }
-extern "C" int buf_version(void) { return 100; }
+extern "C" int buf_version(void) { return 200; }   // 200: round 2 (batched entry points, Winograd descriptor CNN)
 
 // ------------------------------------------------------------------------------------------
 // Optional per-kernel timing for bench.py's roofline objects: HIP events recorded on the launch stream
