@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbuffer_hip.so")
+# BUF_LIB_PATH: development aid (tools/ab.sh times two builds of the library in one GPU session); the default is the in-tree build
+LIB_PATH = os.environ.get("BUF_LIB_PATH") or os.path.join(_HERE, "libbuffer_hip.so")
 
 BUF_OK = 0
 

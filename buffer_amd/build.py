@@ -20,18 +20,20 @@ def needs_build():
     return False
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None):
+    if out is None:
+        out = OUT
+    if out == OUT and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-           "-o", OUT, SRC] + os.environ.get("BUF_EXTRA_HIPCC_FLAGS", "").split()
+           "-o", out, SRC] + os.environ.get("BUF_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

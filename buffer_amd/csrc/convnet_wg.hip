@@ -11,12 +11,26 @@
 // the filter transform is done once on the host in fp64.
 //
 // One workgroup owns one patch for the whole stack.  Activations live in ONE LDS buffer [128][160] (rows of 22 = 20 azimuth
-// columns + the two circular halo columns, so a window row is one address + immediate offsets; 6 zeros per channel serve
+// columns + the two circular halo columns, so a window row is one address + immediate offsets; 4 zeros per channel serve
 // every read of the elevation padding), rewritten in place after each layer -> two workgroups per CU (2 x 80 KB).
-// A wavefront owns one N-tile (16 output channels) at a time and walks the four row components i of the transform as four
-// passes over K: per k-step and M-tile it reads two window rows (four ds_read_b64), forms the four column components on the
-// VALU (eight plain adds) and issues four MFMAs; the accumulators run on through the four passes and after each pass the column
-// transform of the running sum is folded into the 2 x 2 outputs in registers (the C/D layout keeps a tile in one lane).
+//
+// What bounds the kernel (round 3, tools/micro/mfma_group.hip): v_mfma_f32_16x16x4_f32 runs on the f32 vector lanes, so VALU
+// work does NOT hide behind it -- with two waves per SIMD a matrix slot costs 32.4 + 3.6 x (VALU instructions per MFMA) cycles,
+// however the two kinds are interleaved (alternating single instructions is worse still: 52+).  The input transform B^T d B
+// costs 8 adds per 4 component operands, i.e. 2.0 VALU per MFMA if every N-tile (16 output channels) transforms for itself.
+// Round 3 therefore lets ONE transform feed TWO N-tiles (8 MFMAs per 8 adds) wherever the layer allows it:
+//   * 128 output channels: a wavefront owns an N-tile pair; the accumulators of a pair over all three M-tiles would not fit
+//     beside the held outputs (the layer is in place: outputs wait in registers until every wavefront has read its input), so
+//     the M-tiles run in two rounds {0, 1} and {2}.
+//   * 64 output channels, Cin a multiple of 32: two wavefronts share an N-tile pair and split K; after the barrier that ends
+//     the reads each sends the partial sums of ONE N-tile to its partner through the (now dead) upper half of the buffer and
+//     finishes the other one.
+//   * anything else (layer 0: K = 12 steps does not halve into loop iterations of 4; 32 output channels): one N-tile per
+//     wavefront, M-tiles split over wavefront pairs for 32 channels, as in round 2.
+// A pass walks K for one row component i of the transform: per (k-step, M-tile) step it reads two window rows (four
+// ds_read_b64), forms the four column components (eight plain adds) and issues 4 MFMAs per N-tile; the accumulators run on
+// through the four passes and after each pass the column transform of the running sum is folded into the 2 x 2 outputs in
+// registers (the C/D layout keeps a tile in one lane).
 // LDS banking (ds_read_b64: bank = word mod 64, lanes 0-31 and 32-63 served separately): the 40 tiles are dealt to the
 // three M-tiles such that the 16 lanes of a k-step channel cover 32 distinct banks, and the channel stride 160 = 32 mod 64
 // puts the second channel of the half-wave on the other 32:
@@ -25,7 +39,7 @@
 #include "common.h"
 #include <type_traits>
 
-#define WG_CS 160             // channel stride in floats: 7 x 22 + 6 zeros
+#define WG_CS 160             // channel stride in floats: 7 x 22 + 4 zeros + 2 dump words
 #define WG_ROW 22             // [col 19][col 0 .. col 19][col 0]
 #define WG_ZERO 154           // zeros read by every window row outside 0 <= elevation < 7
 #define WG_MAXC 128
@@ -33,6 +47,12 @@
 #define WG_THREADS 256
 #define WG_BUF (WG_MAXC * WG_CS)
 #define WG_KSTEP (16 * WG_CS)  // bytes between k-steps (4 channels)
+#ifdef WG_EXP_NOBAR
+#define WG_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define WG_SYNC() __syncthreads()
+#endif
+#define WG_XCH_C 64            // K-split layers exchange partial sums through the rows of the channels >= 64
 
 typedef float wgf4 __attribute__((ext_vector_type(4)));
 typedef float wgf2 __attribute__((ext_vector_type(2)));
@@ -42,7 +62,15 @@ struct CylWgParams {
     const float* wt[WG_LAYERS];     // Winograd-domain weights, [i][k-step][N-tile][lane][j] (ops.winograd_tile_weights)
     const float* bias[WG_LAYERS];   // [Cout]
     int cin[WG_LAYERS], cout[WG_LAYERS], relu[WG_LAYERS];
+#ifdef WG_STAMP
+    long long* stamps;              // development build (-DWG_STAMP): [workgroup][wave][20] s_memtime at the layer boundaries
+#endif
 };
+#ifdef WG_STAMP
+#define WG_STAMP_AT(SLOT) if ((threadIdx.x & 63) == 0) P.stamps[((size_t)blockIdx.x * 4 + w) * 20 + (SLOT)] = __builtin_amdgcn_s_memtime();
+#else
+#define WG_STAMP_AT(SLOT)
+#endif
 
 // tile (ty, tx) held by row idx of M-tile t (branch-free)
 __device__ __forceinline__ bool wg_tile(int t, int idx, int& ty, int& tx)
@@ -72,8 +100,8 @@ __host__ __device__ constexpr int wg_a1(int I) { return I == 0 ? 0 : 1; }
 __host__ __device__ constexpr int wg_a2(int I) { return I == 3 ? 3 : 2; }
 __host__ __device__ constexpr int wg_te(int I, int T1) { return (I == 3 && T1 == 3) ? 2 : T1; }   // M-tile 2: bottom tile row only, component 3 unused
 
-// LDS reads of step G (M-tile G % NT of k-step G / NT) of a pass.  Two ds_read_b64 per row: the empty asm keeps the
-// compiler from fusing them into the half-rate ds_read2_b64.
+// LDS reads of one step.  Two ds_read_b64 per row: the empty asm keeps the compiler from fusing them into the half-rate
+// ds_read2_b64.
 #define WG_LOAD2(DST, A0, A1_, OFS)                                                                       \
     {                                                                                                     \
         DST[0] = *(wg_lds_f2)(size_t)((A0) + (OFS));                                                      \
@@ -86,29 +114,17 @@ __host__ __device__ constexpr int wg_te(int I, int T1) { return (I == 3 && T1 ==
         asm volatile("" : "+v"(A1_));                                                                     \
     }
 
-// The first two steps of pass I (fetched by whoever runs before the pass: the layer prologue or the previous pass)
-template <int I, int T0, int T1>
-__device__ __forceinline__ void wg_first_steps(unsigned (&RA)[3][4], wgf2 (&D)[2][4])
-{
-    constexpr int NT = wg_te(I, T1) - T0;
-    if constexpr (NT > 0) {
-#pragma unroll
-        for (int g = 0; g < 2; g++) WG_LOAD2(D[g], RA[T0 + g % NT][wg_a1(I)], RA[T0 + g % NT][wg_a2(I)], (g / NT) * WG_KSTEP)
-    }
-}
-
-// One row component I of the transform over the whole K range for the M-tiles [T0, T1): acc[t][j] += V_Ij(tile, c) * U_Ij(c, n).
-// The (k-step, M-tile) steps form a three-stage software pipeline pinned with sched_barriers (the compiler otherwise hoists the
-// loads to the top of the loop body and waits for them at once): step s issues the LDS reads of step s+2, forms the column
-// components of step s+1 on the VALU and runs the four MFMAs of step s.  VALU instructions do not hide behind the matrix
-// pipe on this chip (tools/micro/mfma_coissue: every VALU per MFMA costs 2.5-6 cycles of it), so the loop carries nothing
-// but the eight adds of the transform: four k-steps per iteration, their LDS offsets ride in the instructions, the weights
-// (Ba: k-steps 0-1, Bb: 2-3; one 16-byte load per k-step) are reloaded in place half an iteration ahead, and the last
-// iteration fetches the weights of the pass that follows (wp_next) instead of its own.  Every pass reads its own first two
-// steps (handing them over from the previous pass cost registers -- spills -- and bought no time).
-template <int I, int T0, int T1>
-__device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_next, int k4, int wstride,
-                                        wgf4 (&Ba)[2], wgf4 (&Bb)[2], wgf4 (&acc)[3][4])
+// One row component I of the transform over `niter` x 4 k-steps for the M-tiles [T0, T1) and NN N-tiles that share the
+// transformed operand: acc[n][t][j] += V_Ij(tile, c) * U_Ij(c, n).
+// The (k-step, M-tile) steps form a three-stage software pipeline held in place by sched_barriers (the compiler otherwise
+// hoists the loads to the top of the loop body and waits for them at once): step s issues the LDS reads of step s+2, runs
+// the 4 NN MFMAs of step s back to back, then forms the column components of step s+1.  Four k-steps per iteration: their LDS
+// offsets ride in the instructions, the weights (W[n][k-step]: one 16-byte load per lane) are reloaded in place half an
+// iteration ahead, and the last iteration fetches the weights of whatever runs next (wp_next) instead of its own.  Every
+// pass reads its own first two steps.  The N-tiles of a pair are neighbours in the weight tiling (256 floats apart).
+template <int I, int NN, int T0, int T1>
+__device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_next, int niter, int wstride,
+                                        wgf4 (&W)[NN][4], wgf4 (&acc)[NN][3][4])
 {
     constexpr int A1 = wg_a1(I), A2 = wg_a2(I);
     constexpr int TE = wg_te(I, T1);
@@ -116,7 +132,11 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
     if constexpr (TE <= T0) return;
     wgf2 D[2][4];                                               // window rows A1 (columns 0-1, 2-3) and A2 of two steps in flight
     float V[2][4];
-    wg_first_steps<I, T0, T1>(RA, D);
+    unsigned P[NT][2], Pn[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { P[t][0] = RA[T0 + t][A1]; P[t][1] = RA[T0 + t][A2]; }
+#pragma unroll
+    for (int g = 0; g < 2; g++) WG_LOAD2(D[g], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
     // row component (d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3), then the four column components
 #define WG_XFORM(BUF)                                                                                     \
     {                                                                                                     \
@@ -128,97 +148,100 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
         V[BUF][0] = wg_sub(r_[0], r_[2]); V[BUF][1] = wg_add(r_[1], r_[2]);                               \
         V[BUF][2] = wg_sub(r_[2], r_[1]); V[BUF][3] = wg_sub(r_[1], r_[3]);                               \
     }
-    const int niter = k4 >> 2;
-    unsigned P[NT][2], E[2][2];
     WG_XFORM(0)
 #pragma unroll 1
     for (int it = 0; it < niter; it++) {
         const bool more = it + 1 < niter;
         const float* wn = more ? wp + (size_t)(4 * it + 4) * wstride : wp_next;
-        const unsigned kb = (unsigned)it * (4 * WG_KSTEP);
+        const unsigned adv = more ? 4u * WG_KSTEP : 0u;         // past the end: the iteration's own first steps again (unused)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < NT; t++) { P[t][0] = RA[T0 + t][A1] + kb; P[t][1] = RA[T0 + t][A2] + kb; }
-#pragma unroll
-        for (int g = 0; g < 2; g++) {                           // the two steps past this iteration: the next one's or the next pass's
-            const unsigned own0 = P[g % NT][0] + (4 + g / NT) * WG_KSTEP, own1 = P[g % NT][1] + (4 + g / NT) * WG_KSTEP;
-            E[g][0] = more ? own0 : P[g % NT][0];         // past the end: the iteration's own first steps again (unused)
-            E[g][1] = more ? own1 : P[g % NT][1];
-        }
+        for (int t = 0; t < NT; t++) { Pn[t][0] = P[t][0] + adv; Pn[t][1] = P[t][1] + adv; }
 #pragma unroll
         for (int s = 0; s < 4 * NT; s++) {
             const int t = T0 + s % NT, kk = s / NT, g = s + 2;
             if (g < 4 * NT) WG_LOAD2(D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
-            else WG_LOAD2(D[s & 1], E[g >= 4 * NT ? g - 4 * NT : 0][0], E[g >= 4 * NT ? g - 4 * NT : 0][1], 0)
-            WG_XFORM((s + 1) & 1)
+            else WG_LOAD2(D[s & 1], Pn[(g - 4 * NT) % NT][0], Pn[(g - 4 * NT) % NT][1], ((g - 4 * NT) / NT) * WG_KSTEP)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kk < 2 ? Ba[kk][j] : Bb[kk - 2][j], V[s & 1][j], acc[t][j], 0, 0, 0);
+            for (int n = 0; n < NN; n++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][kk][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            WG_XFORM((s + 1) & 1)
             if (s == 2 * NT - 1) {                              // k-steps 0-1 are through: their registers take the next iteration's
-                Ba[0] = *reinterpret_cast<const wgf4*>(wn);
-                Ba[1] = *reinterpret_cast<const wgf4*>(wn + wstride);
+#pragma unroll
+                for (int n = 0; n < NN; n++) {
+                    W[n][0] = *reinterpret_cast<const wgf4*>(wn + n * 256);
+                    W[n][1] = *reinterpret_cast<const wgf4*>(wn + n * 256 + wstride);
+                }
             }
             if (s == 4 * NT - 1) {
-                Bb[0] = *reinterpret_cast<const wgf4*>(wn + 2 * wstride);
-                Bb[1] = *reinterpret_cast<const wgf4*>(wn + 3 * wstride);
-            }
-            // the step's LDS reads go first (they are consumed one step later), the VALU work is woven between the MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                for (int n = 0; n < NN; n++) {
+                    W[n][2] = *reinterpret_cast<const wgf4*>(wn + n * 256 + 2 * wstride);
+                    W[n][3] = *reinterpret_cast<const wgf4*>(wn + n * 256 + 3 * wstride);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int t = 0; t < NT; t++) { P[t][0] = Pn[t][0]; P[t][1] = Pn[t][1]; }
     }
 #undef WG_XFORM
 }
 
-// All 16 components of one N-tile: Y[t][u][v] = 2 x 2 outputs of the tiles of M-tile t (C/D layout: tile = lane's column).
-// On entry Ba/Bb hold the weights of the first four k-steps; on exit those of the N-tile at wp_after (the wavefront's next one).
-template <int T0, int T1>
-__device__ __forceinline__ void wg_ntile(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_after, int k4, int wstride,
-                                         wgf4 bv, wgf4 (&Ba)[2], wgf4 (&Bb)[2], wgf4 (&Y)[3][2][2])
+// All 16 components of NN N-tiles over the M-tiles [T0, T1): Y[n][t][u][v] = 2 x 2 outputs of the tiles of M-tile t (C/D
+// layout: tile = lane's column).  On entry W holds the weights of the first four k-steps; on exit those at wp_after.
+// The accumulators run on through the four passes (cleared once): after pass I they hold the sum of the row components
+// 0..I, F_I = its column transform, and with s_i = F_i - F_(i-1)
+//     output row 0 = s_0 + s_1 + s_2 = F_2,      output row 1 = s_1 - s_2 - s_3 = -F_0 + 2 F_1 - F_3
+// -- three accumulator clears and half of the output-transform adds less per N-tile.  The bias (when this wavefront carries
+// it: K-split layers add it once) enters component (1, 1)'s accumulator before pass 1: F_1, F_2, F_3 then carry it once in
+// both columns.
+template <int NN, int T0, int T1>
+__device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_after, int niter, int wstride,
+                                         size_t pstride, const wgf4 (&bv)[NN], wgf4 (&W)[NN][4], wgf4 (&Y)[NN][3][2][2])
 {
-    const size_t pstride = (size_t)k4 * wstride;
     using std::integral_constant;
-    // The accumulators run on through the four passes (cleared once per N-tile): after pass I they hold the sum of the row
-    // components 0..I, F_I = its column transform, and with s_i = F_i - F_(i-1)
-    //     output row 0 = s_0 + s_1 + s_2 = F_2,      output row 1 = s_1 - s_2 - s_3 = -F_0 + 2 F_1 - F_3
-    // -- three accumulator clears and half of the output-transform adds less per N-tile (VALU work is what this kernel is short of).
-    // The bias enters component (1, 1)'s accumulator before pass 1: F_1, F_2, F_3 then carry it once in both columns.
-    wgf4 acc[3][4];
+    wgf4 acc[NN][3][4];
 #pragma unroll
-    for (int t = 0; t < 3; t++)
+    for (int n = 0; n < NN; n++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[t][j] = (wgf4){ 0.f, 0.f, 0.f, 0.f };
+        for (int t = T0; t < T1; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[n][t][j] = (wgf4){ 0.f, 0.f, 0.f, 0.f };
     auto run = [&](auto ic) __attribute__((always_inline)) {
         constexpr int I = decltype(ic)::value;
-        // component 3 does nothing for a wavefront that only has M-tile 2: the pass before it hands over to component 0
+        // component 3 does nothing for a round that only has M-tile 2: the pass before it hands over to whatever runs next
         constexpr int INEXT = (I == 3 || (I == 2 && wg_te(3, T1) <= T0)) ? 0 : I + 1;
         if constexpr (I == 1) {
 #pragma unroll
-            for (int t = T0; t < T1; t++) acc[t][1] += bv;
+            for (int n = 0; n < NN; n++)
+#pragma unroll
+                for (int t = T0; t < T1; t++) acc[n][t][1] += bv[n];
         }
-        wg_pass<I, T0, T1>(RA, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, k4, wstride, Ba, Bb, acc);
+        wg_pass<I, NN, T0, T1>(RA, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, niter, wstride, W, acc);
 #pragma unroll
-        for (int t = T0; t < T1; t++) {
-            if (I == 3 && t == 2) continue;
-            if (I == 2 ? false : t == 2) continue;              // M-tile 2 (bottom tile row) only has output row 0 = F_2
-            const wgf4 f0 = acc[t][0] + acc[t][1] + acc[t][2];
-            const wgf4 f1 = acc[t][1] - acc[t][2] - acc[t][3];
-            if constexpr (I == 0) { Y[t][1][0] = f0; Y[t][1][1] = f1; }                       // F_0 (enters with a minus sign below)
-            else if constexpr (I == 1) {
+        for (int n = 0; n < NN; n++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    Y[t][1][0][r] = __builtin_fmaf(2.f, f0[r], -Y[t][1][0][r]);
-                    Y[t][1][1][r] = __builtin_fmaf(2.f, f1[r], -Y[t][1][1][r]);
+            for (int t = T0; t < T1; t++) {
+                if (I == 3 && t == 2) continue;
+                if (I == 2 ? false : t == 2) continue;          // M-tile 2 (bottom tile row) only has output row 0 = F_2
+                const wgf4 f0 = acc[n][t][0] + acc[n][t][1] + acc[n][t][2];
+                const wgf4 f1 = acc[n][t][1] - acc[n][t][2] - acc[n][t][3];
+                if constexpr (I == 0) { Y[n][t][1][0] = f0; Y[n][t][1][1] = f1; }                 // F_0 (enters with a minus sign below)
+                else if constexpr (I == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        Y[n][t][1][0][r] = __builtin_fmaf(2.f, f0[r], -Y[n][t][1][0][r]);
+                        Y[n][t][1][1][r] = __builtin_fmaf(2.f, f1[r], -Y[n][t][1][1][r]);
+                    }
                 }
+                else if constexpr (I == 2) { Y[n][t][0][0] = f0; Y[n][t][0][1] = f1; }
+                else { Y[n][t][1][0] -= f0; Y[n][t][1][1] -= f1; }
             }
-            else if constexpr (I == 2) { Y[t][0][0] = f0; Y[t][0][1] = f1; }
-            else { Y[t][1][0] -= f0; Y[t][1][1] -= f1; }
-        }
     };
     run(integral_constant<int, 0>{});
     run(integral_constant<int, 1>{});
@@ -255,7 +278,7 @@ __device__ __forceinline__ void wg_store(const wgf4 (&Y)[3][2][2], int nt, int r
                 }
             } else {
                 // straight-line code (a branch per store costs more than the store): lanes with nothing to write, and the halo
-                // copies of the inner tiles, go to the two spare words behind the channel's zero area
+                // copies of the inner tiles, go to the two dump words behind the channel's zero area
                 const int pos = ok ? row * WG_ROW + 2 * tx + 1 : WG_ZERO + 4;
                 const int h0 = (ok && tx == 0) ? row * WG_ROW + 21 : WG_ZERO + 4;      // column 0 again behind column 19
                 const int h1 = (ok && tx == 9) ? row * WG_ROW : WG_ZERO + 5;           // column 19 again in front of column 0
@@ -271,48 +294,110 @@ __device__ __forceinline__ void wg_store(const wgf4 (&Y)[3][2][2], int nt, int r
     }
 }
 
-// One layer for the calling wavefront.  NTW N-tiles per wavefront (2 for 128 output channels), M-tiles [T0, T1).
-// The layer is written in place, so a wavefront keeps its outputs in registers until every wavefront has finished reading
-// the input.  With 128 output channels it owns two N-tiles: the upper one (channels >= 64) first -- when the layer has 64
-// input channels its rows are free and it is stored at once (EARLY), otherwise it is held while the lower one is computed.
-template <int NTW, int T0, int T1, bool GLB, bool EARLY>
-__device__ __forceinline__ void wg_layer(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
-                                         const float* __restrict__ bias, int cin, int cout, int relu, int nt_first)
+// Window-row addresses of the lane: 3 M-tiles x 4 rows, channel lk of k-step k0
+__device__ __forceinline__ void wg_addresses(const float* act, int k0, int li, int lk, unsigned (&RA)[3][4])
+{
+    const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)act + (unsigned)k0 * WG_KSTEP;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) RA[t][a] = wg_row_addr(act_addr, t, a, li, lk);
+}
+
+template <int NN>
+__device__ __forceinline__ void wg_first_weights(const float* __restrict__ wp, int wstride, wgf4 (&W)[NN][4])
+{
+#pragma unroll
+    for (int n = 0; n < NN; n++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) W[n][k] = *reinterpret_cast<const wgf4*>(wp + n * 256 + k * wstride);
+}
+
+// One layer, one N-tile per wavefront (nt), M-tiles [T0, T1): the round-2 form, kept for the layers the paired forms do not
+// take.  The layer is written in place, so the outputs wait in registers until every wavefront has finished reading.
+template <int T0, int T1, bool GLB>
+__device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
+                                                const float* __restrict__ bias, int cin, int cout, int relu, int nt)
 {
     int lane = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane));                   // lane-derived values are formed per layer: kept across the layers they are spilled
     const int li = lane & 15, lk = lane >> 4;
-    unsigned RA[3][4];                               // window-row addresses of the lane: 3 M-tiles x 4 rows, channel lk of k-step 0
-    {
-        const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)act;
-#pragma unroll
-        for (int t = 0; t < 3; t++)
-#pragma unroll
-            for (int a = 0; a < 4; a++) RA[t][a] = wg_row_addr(act_addr, t, a, li, lk);
-    }
+    unsigned RA[3][4];
+    wg_addresses(act, 0, li, lk, RA);
+#ifdef WG_EXP_SAMEW
+    const int k4 = cin >> 2, wstride = 0;
+#else
     const int k4 = cin >> 2, wstride = (cout >> 4) * 256;
-    wgf4 Ba[2], Bb[2];                               // weights of four k-steps: every pass hands the next one its first four
-    const int nt_hi = NTW == 2 ? nt_first + 4 : nt_first, nt_lo = nt_first;
-    const float* wp_hi = wt + ((size_t)nt_hi * 64 + lane) * 4;
-    const float* wp_lo = wt + ((size_t)nt_lo * 64 + lane) * 4;
-    Ba[0] = *reinterpret_cast<const wgf4*>(wp_hi);
-    Ba[1] = *reinterpret_cast<const wgf4*>(wp_hi + wstride);
-    Bb[0] = *reinterpret_cast<const wgf4*>(wp_hi + 2 * wstride);
-    Bb[1] = *reinterpret_cast<const wgf4*>(wp_hi + 3 * wstride);
-    wgf4 Y[NTW][3][2][2];
-    wg_ntile<T0, T1>(RA, wp_hi, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_hi * 16 + lk * 4), Ba, Bb, Y[0]);
-    // EARLY: known at compile time for the 64 -> 128 layer; the instantiation of the 128 -> 128 layer tests it at run time (always
-    // false there) -- with the test compiled out the register allocator parks every partial result in scratch
-    const bool early = NTW == 2 && !GLB && (EARLY || nt_hi * 16 >= cin);
-    if constexpr (NTW == 2) {
-        if (early) wg_store<T0, T1, false>(Y[0], nt_hi, relu, act, nullptr, li, lk);
-        wg_ntile<T0, T1>(RA, wp_lo, wp_lo, k4, wstride, *reinterpret_cast<const wgf4*>(bias + nt_lo * 16 + lk * 4), Ba, Bb, Y[1]);
-    }
-    __syncthreads();                                 // every wavefront has finished reading the layer's input
+#endif
+    const float* wp = wt + ((size_t)nt * 64 + lane) * 4;
+    wgf4 W[1][4];
+    wg_first_weights<1>(wp, wstride, W);
+    wgf4 Y[1][3][2][2];
+    const wgf4 bv[1] = { *reinterpret_cast<const wgf4*>(bias + nt * 16 + lk * 4) };
+#ifdef WG_EXP_P0
+    wg_round<1, T0, T1>(RA, wp, wp, k4 >> 2, wstride, 0, bv, W, Y);
+#else
+    wg_round<1, T0, T1>(RA, wp, wp, k4 >> 2, wstride, (size_t)k4 * wstride, bv, W, Y);
+#endif
+    WG_SYNC();                                 // every wavefront has finished reading the layer's input
+    wg_store<T0, T1, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
+}
+
+// One layer with an N-tile pair per wavefront (the transform of a step feeds 8 MFMAs).
+//   KSPLIT = 1 (128 output channels): wavefront w owns the N-tiles 2w, 2w+1 over the whole K.
+//   KSPLIT = 2 (64 output channels):  wavefronts w and w^2 own the pair 2(w&1), 2(w&1)+1 and half of K each (w>>1); after
+//     the reads each hands the partial sums of one N-tile (40 registers: 16 + 16 + 8) to the other through the rows of the
+//     channels >= 64 and finishes the N-tile 2(w&1) + (w>>1).  The bias rides in the lower half's accumulators.
+// The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs: two rounds, M-tiles {0, 1} and {2}.
+template <int KSPLIT>
+__device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
+                                              int cin, int cout, int relu, int w)
+{
+    int lane = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    const int pair = KSPLIT == 1 ? w : (w & 1), half = KSPLIT == 1 ? 0 : (w >> 1);
+#ifdef WG_EXP_SAMEW
+    const int k4 = cin >> 2, kn = k4 / KSPLIT, k0 = half * kn, wstride = 0;
+#else
+    const int k4 = cin >> 2, kn = k4 / KSPLIT, k0 = half * kn, wstride = (cout >> 4) * 256;
+#endif
+    unsigned RA[3][4];
+    wg_addresses(act, k0, li, lk, RA);
+    const float* wp = wt + (size_t)k0 * wstride + ((size_t)(2 * pair) * 64 + lane) * 4;
+#ifdef WG_EXP_P0
+    const size_t pstride = 0;
+#else
+    const size_t pstride = (size_t)k4 * wstride;
+#endif
+    wgf4 W[2][4];
+    wg_first_weights<2>(wp, wstride, W);
+    wgf4 Y[2][3][2][2];
+    wgf4 bv[2];
 #pragma unroll
-    for (int q = 0; q < NTW; q++) {
-        if (NTW == 2 && q == 0 && early) continue;
-        wg_store<T0, T1, GLB>(Y[q], q == 0 ? nt_hi : nt_lo, relu, act, out_glb, li, lk);
+    for (int n = 0; n < 2; n++) {
+        bv[n] = *reinterpret_cast<const wgf4*>(bias + (2 * pair + n) * 16 + lk * 4);
+        if (KSPLIT == 2 && half) bv[n] = (wgf4){ 0.f, 0.f, 0.f, 0.f };
+    }
+    wg_round<2, 0, 2>(RA, wp, wp, kn >> 2, wstride, pstride, bv, W, Y);
+    wg_round<2, 2, 3>(RA, wp, wp, kn >> 2, wstride, pstride, bv, W, Y);
+    WG_SYNC();                                 // every wavefront has finished reading the layer's input
+    if constexpr (KSPLIT == 1) {
+        wg_store<0, 3, false>(Y[0], 2 * pair, relu, act, nullptr, li, lk);
+        wg_store<0, 3, false>(Y[1], 2 * pair + 1, relu, act, nullptr, li, lk);
+    } else {
+        wgf4* slot_out = reinterpret_cast<wgf4*>(act + WG_XCH_C * WG_CS) + w * 640 + lane;           // 10 x 64 float4 per wavefront
+        const wgf4* slot_in = reinterpret_cast<const wgf4*>(act + WG_XCH_C * WG_CS) + (w ^ 2) * 640 + lane;
+        auto xch = [&](auto keep) __attribute__((always_inline)) {
+            constexpr int KEEP = decltype(keep)::value, SEND = 1 - KEEP;
+#pragma unroll
+            for (int q = 0; q < 10; q++) slot_out[q * 64] = Y[SEND][q >> 2][(q >> 1) & 1][q & 1];   // t = q / 4, u, column pair; t = 2 has u = 0 only
+            WG_SYNC();
+#pragma unroll
+            for (int q = 0; q < 10; q++) Y[KEEP][q >> 2][(q >> 1) & 1][q & 1] += slot_in[q * 64];
+            wg_store<0, 3, false>(Y[KEEP], 2 * pair + KEEP, relu, act, nullptr, li, lk);
+        };
+        if (half) xch(std::integral_constant<int, 1>{}); else xch(std::integral_constant<int, 0>{});
     }
 }
 
@@ -322,36 +407,59 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
     float* act = lds;
     const int patch = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-    {   // input [48][140] -> rows of 22 with the halo columns
-        const float* src = x + (size_t)patch * P.cin[0] * 140;
-        for (int i = threadIdx.x; i < P.cin[0] * 140; i += WG_THREADS) {
-            const int c = i / 140, pos = i - c * 140;
-            const int row = pos / 20, col = pos - row * 20;
-            const float v = __builtin_nontemporal_load(src + i);       // streamed once: leave the L2 to the filters
-            float* p = act + c * WG_CS + row * WG_ROW + col;
-            p[1] = v;
-            if (col == 0) p[21] = v;
-            if (col == 19) p[-19] = v;
+    WG_STAMP_AT(17)
+    {   // input [48][140] -> rows of 22 with the halo columns.  A row is five float4: every load of the patch is issued before the
+        // first LDS store (one load at a time, each behind the previous one's stores, took 40 k cycles per patch: 5 % of the kernel)
+        const wgf4* src = reinterpret_cast<const wgf4*>(x + (size_t)patch * P.cin[0] * 140);
+        const int nq = P.cin[0] * 35;                               // float4 per patch (7 per thread for the 48 channels of this network)
+        wgf4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = threadIdx.x + k * WG_THREADS;
+            if (i < nq) v[k] = __builtin_nontemporal_load(src + i);    // streamed once: leave the L2 to the filters
         }
+        auto put = [&](int i, wgf4 u) __attribute__((always_inline)) {
+            const int c = i / 35, q = i - c * 35;
+            const int row = q / 5, col = (q - row * 5) * 4;
+            float* p = act + c * WG_CS + row * WG_ROW + col + 1;
+            p[0] = u[0]; p[1] = u[1]; p[2] = u[2]; p[3] = u[3];
+            if (col == 0) p[20] = u[0];
+            if (col == 16) p[-17] = u[3];
+        };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = threadIdx.x + k * WG_THREADS;
+            if (i < nq) put(i, v[k]);
+        }
+        for (int i = threadIdx.x + 8 * WG_THREADS; i < nq; i += WG_THREADS) put(i, __builtin_nontemporal_load(src + i));   // wider first layers
     }
-    for (int i = threadIdx.x; i < WG_MAXC * 6; i += WG_THREADS) act[(i / 6) * WG_CS + WG_ZERO + i % 6] = 0.f;
+    for (int i = threadIdx.x; i < WG_MAXC * 4; i += WG_THREADS) act[(i >> 2) * WG_CS + WG_ZERO + (i & 3)] = 0.f;
     __syncthreads();
+    WG_STAMP_AT(0)
 #pragma unroll 1
     for (int l = 0; l < WG_LAYERS; l++) {
         const int cin = P.cin[l], cout = P.cout[l];
-        if (cout == 128) {
-            if (cin <= 64)   wg_layer<2, 0, 3, false, true>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-            else             wg_layer<2, 0, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-        } else if (cout == 64) wg_layer<1, 0, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-        else if (l < WG_LAYERS - 1) {
-            if (w & 1)       wg_layer<1, 1, 3, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer<1, 0, 1, false, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+        if (cout == 128) wg_layer_pair<1>(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        else if (cout == 64) {
+            if ((cin & 31) == 0) {
+                wg_layer_pair<2>(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+                // the exchange ran over the zero words of the channels >= 64: restore them once every wavefront has read its slot
+                // (the next layer has 64 input channels; those rows are rewritten, and barriers passed, before anyone reads them)
+                WG_SYNC();
+                act[(WG_XCH_C + (threadIdx.x >> 2)) * WG_CS + WG_ZERO + (threadIdx.x & 3)] = 0.f;
+            }
+            else wg_layer_single<0, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        } else if (l < WG_LAYERS - 1) {
+            if (w & 1)       wg_layer_single<1, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         } else {
             float* glb = y + (size_t)patch * cout * 140;
-            if (w & 1)       wg_layer<1, 1, 3, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer<1, 0, 1, true, false>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer_single<1, 3, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         }
-        __syncthreads();
+        WG_STAMP_AT(2 * l + 1)
+        WG_SYNC();
+        WG_STAMP_AT(2 * l + 2)
     }
 }
 
@@ -403,8 +511,35 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
     for (int l = 0; l < WG_LAYERS; l++) macs += 9.0 * P.cin[l] * P.cout[l];
     TimedSpan span;
     bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * 140 * macs * npatch, BUF_TIMED_CYL_NET);
+#ifdef WG_STAMP
+    BUF_CHECK_HIP(hipMalloc(&P.stamps, (size_t)npatch * 4 * 20 * sizeof(long long)));
+#endif
     k_cyl_net_wg<<<npatch, WG_THREADS, lds, (hipStream_t)stream>>>(x, P, y);
     if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
+#ifdef WG_STAMP
+    {   // per-layer wave cycles (to the wave's arrival at the closing barrier | wait there), second half of the workgroups
+        BUF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        long long* h = (long long*)malloc((size_t)npatch * 4 * 20 * sizeof(long long));
+        BUF_CHECK_HIP(hipMemcpy(h, P.stamps, (size_t)npatch * 4 * 20 * sizeof(long long), hipMemcpyDeviceToHost));
+        double comp[WG_LAYERS][4] = {}, wait[WG_LAYERS][4] = {}, tot = 0, pre = 0; long n = 0;
+        for (int b = npatch / 2; b < npatch; b++, n++)
+            for (int w = 0; w < 4; w++) {
+                const long long* q = h + ((size_t)b * 4 + w) * 20;
+                for (int l = 0; l < WG_LAYERS; l++) { comp[l][w] += (double)(q[2 * l + 1] - q[2 * l]); wait[l][w] += (double)(q[2 * l + 2] - q[2 * l + 1]); }
+                if (w == 0) { tot += (double)(q[2 * WG_LAYERS] - q[0]); pre += (double)(q[0] - q[17]); }
+            }
+        if (n && npatch >= 1024) {
+            fprintf(stderr, "WG_STAMP: %ld workgroups, layers total %.0f cycles per patch, input phase %.0f\n", n, tot / n, pre / n);
+            for (int l = 0; l < WG_LAYERS; l++) {
+                const double mf = 44.0 * (P.cin[l] / 4) * (P.cout[l] / 16) / 4;     // MFMAs per wave
+                fprintf(stderr, "  layer %d %3d->%3d: MFMAs/wave %5.0f | to barrier %7.0f %7.0f %7.0f %7.0f | wait %6.0f %6.0f %6.0f %6.0f | cycles per MFMA slot %.1f\n",
+                        l, P.cin[l], P.cout[l], mf, comp[l][0] / n, comp[l][1] / n, comp[l][2] / n, comp[l][3] / n, wait[l][0] / n, wait[l][1] / n,
+                        wait[l][2] / n, wait[l][3] / n, (comp[l][0] + wait[l][0]) / n / (2 * mf));
+            }
+        }
+        free(h); (void)hipFree(P.stamps);
+    }
+#endif
     return BUF_OK;
 }
