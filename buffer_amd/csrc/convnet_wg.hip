@@ -52,7 +52,6 @@
 #else
 #define WG_SYNC() __syncthreads()
 #endif
-#define WG_XCH_C 64            // K-split layers exchange partial sums through the rows of the channels >= 64
 
 typedef float wgf4 __attribute__((ext_vector_type(4)));
 typedef float wgf2 __attribute__((ext_vector_type(2)));
@@ -114,6 +113,19 @@ __host__ __device__ constexpr int wg_te(int I, int T1) { return (I == 3 && T1 ==
         asm volatile("" : "+v"(A1_));                                                                     \
     }
 
+// A lane's 16 bytes of a weight block through a buffer resource: wavefront-uniform byte offset (SGPR) + the lane's 32-bit offset.
+// The form matters: global_load_dwordx4 with a 64-bit VGPR address costs ~50 cycles of the SIMD's issue beside MFMAs, an
+// SGPR-based address ~10 (tools/micro/mfma_vmem.hip) -- with per-lane pointers the filter stream took 8 % of the kernel.
+typedef unsigned wgu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_weights(const float* wt)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, 0x7fffffff, 0x00027000);
+}
+__device__ __forceinline__ wgf4 wg_ldw(__amdgpu_buffer_rsrc_t rs, unsigned uniform_float_ofs, unsigned lane_byte_ofs)
+{
+    return __builtin_bit_cast(wgf4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_byte_ofs, uniform_float_ofs * 4, 0));
+}
+
 // One row component I of the transform over `niter` x 4 k-steps for the M-tiles [T0, T1) and NN N-tiles that share the
 // transformed operand: acc[n][t][j] += V_Ij(tile, c) * U_Ij(c, n).
 // The (k-step, M-tile) steps form a three-stage software pipeline held in place by sched_barriers (the compiler otherwise
@@ -122,9 +134,9 @@ __host__ __device__ constexpr int wg_te(int I, int T1) { return (I == 3 && T1 ==
 // offsets ride in the instructions, the weights (W[n][k-step]: one 16-byte load per lane) are reloaded in place half an
 // iteration ahead, and the last iteration fetches the weights of whatever runs next (wp_next) instead of its own.  Every
 // pass reads its own first two steps.  The N-tiles of a pair are neighbours in the weight tiling (256 floats apart).
-template <int I, int NN, int T0, int T1>
-__device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_next, int niter, int wstride,
-                                        wgf4 (&W)[NN][4], wgf4 (&acc)[NN][3][4])
+template <int I, int NN, int T0, int T1, int WD>
+__device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_next, unsigned lofs, int niter,
+                                        int wstride, wgf4 (&W)[NN][4 * WD], wgf4 (&acc)[NN][3][4])
 {
     constexpr int A1 = wg_a1(I), A2 = wg_a2(I);
     constexpr int TE = wg_te(I, T1);
@@ -132,7 +144,7 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
     if constexpr (TE <= T0) return;
     wgf2 D[2][4];                                               // window rows A1 (columns 0-1, 2-3) and A2 of two steps in flight
     float V[2][4];
-    unsigned P[NT][2], Pn[NT][2];
+    unsigned P[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; t++) { P[t][0] = RA[T0 + t][A1]; P[t][1] = RA[T0 + t][A2]; }
 #pragma unroll
@@ -150,44 +162,51 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
     }
     WG_XFORM(0)
 #pragma unroll 1
-    for (int it = 0; it < niter; it++) {
-        const bool more = it + 1 < niter;
-        const float* wn = more ? wp + (size_t)(4 * it + 4) * wstride : wp_next;
-        const unsigned adv = more ? 4u * WG_KSTEP : 0u;         // past the end: the iteration's own first steps again (unused)
-        __builtin_amdgcn_sched_barrier(0);
+    for (int it0 = 0; it0 < niter; it0 += WD) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) { Pn[t][0] = P[t][0] + adv; Pn[t][1] = P[t][1] + adv; }
-#pragma unroll
-        for (int s = 0; s < 4 * NT; s++) {
-            const int t = T0 + s % NT, kk = s / NT, g = s + 2;
-            if (g < 4 * NT) WG_LOAD2(D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
-            else WG_LOAD2(D[s & 1], Pn[(g - 4 * NT) % NT][0], Pn[(g - 4 * NT) % NT][1], ((g - 4 * NT) / NT) * WG_KSTEP)
+        for (int h = 0; h < WD; h++) {
+            const int it = it0 + h;
+            const bool more = it + 1 < niter;
+            // the registers of this iteration's k-steps take the k-steps WD iterations on: of this pass, or of whatever runs next
+            const unsigned wn = it + WD < niter ? wp + 4 * (it + WD) * wstride : wp_next + 4 * (it + WD - niter) * wstride;
+            const unsigned adv = more ? 4u * WG_KSTEP : 0u;     // past the end: the iteration's own first steps again (unused)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < NN; n++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][kk][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            WG_XFORM((s + 1) & 1)
-            if (s == 2 * NT - 1) {                              // k-steps 0-1 are through: their registers take the next iteration's
-#pragma unroll
-                for (int n = 0; n < NN; n++) {
-                    W[n][0] = *reinterpret_cast<const wgf4*>(wn + n * 256);
-                    W[n][1] = *reinterpret_cast<const wgf4*>(wn + n * 256 + wstride);
+            for (int s = 0; s < 4 * NT; s++) {
+                const int t = T0 + s % NT, kk = s / NT, g = s + 2;
+                if (g < 4 * NT) WG_LOAD2(D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+                else {
+                    const int t2 = (g - 4 * NT) % NT;            // the next iteration's base from here on (this one no longer reads through it)
+                    if ((g - 4 * NT) / NT == 0) { P[t2][0] += adv; P[t2][1] += adv; }
+                    WG_LOAD2(D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * WG_KSTEP)
                 }
-            }
-            if (s == 4 * NT - 1) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < NN; n++) {
-                    W[n][2] = *reinterpret_cast<const wgf4*>(wn + n * 256 + 2 * wstride);
-                    W[n][3] = *reinterpret_cast<const wgf4*>(wn + n * 256 + 3 * wstride);
+                for (int n = 0; n < NN; n++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][4 * h + kk][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                WG_XFORM((s + 1) & 1)
+                if (s == 2 * NT - 1) {                          // k-steps 0-1 are through
+#pragma unroll
+                    for (int n = 0; n < NN; n++) {
+                        W[n][4 * h + 0] = wg_ldw(rs, wn + n * 256, lofs);
+                        W[n][4 * h + 1] = wg_ldw(rs, wn + n * 256 + wstride, lofs);
+                    }
                 }
+                if (s == 4 * NT - 1) {
+#pragma unroll
+                    for (int n = 0; n < NN; n++) {
+                        W[n][4 * h + 2] = wg_ldw(rs, wn + n * 256 + 2 * wstride, lofs);
+                        W[n][4 * h + 3] = wg_ldw(rs, wn + n * 256 + 3 * wstride, lofs);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 2; t < NT; t++) { P[t][0] += adv; P[t][1] += adv; }     // the first two M-tiles were advanced by the look-ahead steps
         }
-#pragma unroll
-        for (int t = 0; t < NT; t++) { P[t][0] = Pn[t][0]; P[t][1] = Pn[t][1]; }
     }
 #undef WG_XFORM
 }
@@ -200,9 +219,9 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], const float* __res
 // -- three accumulator clears and half of the output-transform adds less per N-tile.  The bias (when this wavefront carries
 // it: K-split layers add it once) enters component (1, 1)'s accumulator before pass 1: F_1, F_2, F_3 then carry it once in
 // both columns.
-template <int NN, int T0, int T1>
-__device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], const float* __restrict__ wp, const float* __restrict__ wp_after, int niter, int wstride,
-                                         size_t pstride, const wgf4 (&bv)[NN], wgf4 (&W)[NN][4], wgf4 (&Y)[NN][3][2][2])
+template <int NN, int T0, int T1, int WD>
+__device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_after, unsigned lofs, int niter,
+                                         int wstride, unsigned pstride, const wgf4 (&bv)[NN], wgf4 (&W)[NN][4 * WD], wgf4 (&Y)[NN][3][2][2])
 {
     using std::integral_constant;
     wgf4 acc[NN][3][4];
@@ -222,7 +241,7 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], const float* __re
 #pragma unroll
                 for (int t = T0; t < T1; t++) acc[n][t][1] += bv[n];
         }
-        wg_pass<I, NN, T0, T1>(RA, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, niter, wstride, W, acc);
+        wg_pass<I, NN, T0, T1, WD>(RA, rs, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, lofs, niter, wstride, W, acc);
 #pragma unroll
         for (int n = 0; n < NN; n++)
 #pragma unroll
@@ -304,18 +323,18 @@ __device__ __forceinline__ void wg_addresses(const float* act, int k0, int li, i
         for (int a = 0; a < 4; a++) RA[t][a] = wg_row_addr(act_addr, t, a, li, lk);
 }
 
-template <int NN>
-__device__ __forceinline__ void wg_first_weights(const float* __restrict__ wp, int wstride, wgf4 (&W)[NN][4])
+template <int NN, int K0, int K1, int KN>
+__device__ __forceinline__ void wg_first_weights(__amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned lofs, int wstride, wgf4 (&W)[NN][KN])
 {
 #pragma unroll
     for (int n = 0; n < NN; n++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) W[n][k] = *reinterpret_cast<const wgf4*>(wp + n * 256 + k * wstride);
+        for (int k = K0; k < K1; k++) W[n][k] = wg_ldw(rs, wp + n * 256 + k * wstride, lofs);
 }
 
 // One layer, one N-tile per wavefront (nt), M-tiles [T0, T1): the round-2 form, kept for the layers the paired forms do not
 // take.  The layer is written in place, so the outputs wait in registers until every wavefront has finished reading.
-template <int T0, int T1, bool GLB>
+template <int T0, int T1, bool GLB, int WD>
 __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
                                                 const float* __restrict__ bias, int cin, int cout, int relu, int nt)
 {
@@ -324,81 +343,62 @@ __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* 
     const int li = lane & 15, lk = lane >> 4;
     unsigned RA[3][4];
     wg_addresses(act, 0, li, lk, RA);
-#ifdef WG_EXP_SAMEW
-    const int k4 = cin >> 2, wstride = 0;
+#ifdef WG_EXP_SAMEW_SINGLE
+    const int k4 = cin >> 2, wstride = relu >> 4;              // timing experiment: a run-time zero (every k-step fetches the same KB: L1 hits)
 #else
-    const int k4 = cin >> 2, wstride = (cout >> 4) * 256;
+    const int k4 = cin >> 2, wstride = 256;
 #endif
-    const float* wp = wt + ((size_t)nt * 64 + lane) * 4;
-    wgf4 W[1][4];
-    wg_first_weights<1>(wp, wstride, W);
+    const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
+    const unsigned wp = (unsigned)nt * (16 * cin * 16);                   // [N-tile][i][k-step][lane][j]: a wavefront streams its own block
+    const unsigned lofs = lane * 16;
+    wgf4 W[1][4 * WD];                                // WD iterations of weights in registers: every load is issued 4 WD - 2 k-steps ahead
+    wg_first_weights<1, 0, 4 * WD>(rs, wp, lofs, wstride, W);
     wgf4 Y[1][3][2][2];
     const wgf4 bv[1] = { *reinterpret_cast<const wgf4*>(bias + nt * 16 + lk * 4) };
-#ifdef WG_EXP_P0
-    wg_round<1, T0, T1>(RA, wp, wp, k4 >> 2, wstride, 0, bv, W, Y);
-#else
-    wg_round<1, T0, T1>(RA, wp, wp, k4 >> 2, wstride, (size_t)k4 * wstride, bv, W, Y);
-#endif
+    wg_round<1, T0, T1, WD>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bv, W, Y);
     WG_SYNC();                                 // every wavefront has finished reading the layer's input
     wg_store<T0, T1, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
 }
 
-// One layer with an N-tile pair per wavefront (the transform of a step feeds 8 MFMAs).
-//   KSPLIT = 1 (128 output channels): wavefront w owns the N-tiles 2w, 2w+1 over the whole K.
-//   KSPLIT = 2 (64 output channels):  wavefronts w and w^2 own the pair 2(w&1), 2(w&1)+1 and half of K each (w>>1); after
-//     the reads each hands the partial sums of one N-tile (40 registers: 16 + 16 + 8) to the other through the rows of the
-//     channels >= 64 and finishes the N-tile 2(w&1) + (w>>1).  The bias rides in the lower half's accumulators.
-// The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs: two rounds, M-tiles {0, 1} and {2}.
-template <int KSPLIT>
+// One layer with 128 output channels: wavefront w owns the N-tile pair 2w, 2w+1 over the whole K, and the transform of a step
+// feeds 8 MFMAs.  The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs: two rounds, M-tiles
+// {0, 1} and {2}.  The second round has few MFMAs per weight fetch and registers to spare: it keeps two iterations of weights.
 __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
-                                              int cin, int cout, int relu, int w)
+                                              int cin, int cout, int relu, int pair)
 {
     int lane = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane));
     const int li = lane & 15, lk = lane >> 4;
-    const int pair = KSPLIT == 1 ? w : (w & 1), half = KSPLIT == 1 ? 0 : (w >> 1);
-#ifdef WG_EXP_SAMEW
-    const int k4 = cin >> 2, kn = k4 / KSPLIT, k0 = half * kn, wstride = 0;
+#ifdef WG_EXP_SAMEW_PAIR
+    const int k4 = cin >> 2, wstride = relu >> 4;
 #else
-    const int k4 = cin >> 2, kn = k4 / KSPLIT, k0 = half * kn, wstride = (cout >> 4) * 256;
+    const int k4 = cin >> 2, wstride = 512;
 #endif
     unsigned RA[3][4];
-    wg_addresses(act, k0, li, lk, RA);
-    const float* wp = wt + (size_t)k0 * wstride + ((size_t)(2 * pair) * 64 + lane) * 4;
-#ifdef WG_EXP_P0
-    const size_t pstride = 0;
-#else
-    const size_t pstride = (size_t)k4 * wstride;
-#endif
-    wgf4 W[2][4];
-    wg_first_weights<2>(wp, wstride, W);
+    wg_addresses(act, 0, li, lk, RA);
+    const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
+    const unsigned wp = (unsigned)pair * (16 * cin * 32);                  // [pair][i][k-step][n2][lane][j]
+    const unsigned lofs = lane * 16;
+    const unsigned pstride = (unsigned)(k4 * wstride);
     wgf4 Y[2][3][2][2];
     wgf4 bv[2];
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        bv[n] = *reinterpret_cast<const wgf4*>(bias + (2 * pair + n) * 16 + lk * 4);
-        if (KSPLIT == 2 && half) bv[n] = (wgf4){ 0.f, 0.f, 0.f, 0.f };
-    }
-    wg_round<2, 0, 2>(RA, wp, wp, kn >> 2, wstride, pstride, bv, W, Y);
-    wg_round<2, 2, 3>(RA, wp, wp, kn >> 2, wstride, pstride, bv, W, Y);
-    WG_SYNC();                                 // every wavefront has finished reading the layer's input
-    if constexpr (KSPLIT == 1) {
-        wg_store<0, 3, false>(Y[0], 2 * pair, relu, act, nullptr, li, lk);
-        wg_store<0, 3, false>(Y[1], 2 * pair + 1, relu, act, nullptr, li, lk);
-    } else {
-        wgf4* slot_out = reinterpret_cast<wgf4*>(act + WG_XCH_C * WG_CS) + w * 640 + lane;           // 10 x 64 float4 per wavefront
-        const wgf4* slot_in = reinterpret_cast<const wgf4*>(act + WG_XCH_C * WG_CS) + (w ^ 2) * 640 + lane;
-        auto xch = [&](auto keep) __attribute__((always_inline)) {
-            constexpr int KEEP = decltype(keep)::value, SEND = 1 - KEEP;
+    for (int n = 0; n < 2; n++) bv[n] = *reinterpret_cast<const wgf4*>(bias + (2 * pair + n) * 16 + lk * 4);
+    wgf4 W2[2][8];
+    {
+        wgf4 W1[2][4];
+        wg_first_weights<2, 0, 4>(rs, wp, lofs, wstride, W1);
+        wg_round<2, 0, 2, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
 #pragma unroll
-            for (int q = 0; q < 10; q++) slot_out[q * 64] = Y[SEND][q >> 2][(q >> 1) & 1][q & 1];   // t = q / 4, u, column pair; t = 2 has u = 0 only
-            WG_SYNC();
+        for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int q = 0; q < 10; q++) Y[KEEP][q >> 2][(q >> 1) & 1][q & 1] += slot_in[q * 64];
-            wg_store<0, 3, false>(Y[KEEP], 2 * pair + KEEP, relu, act, nullptr, li, lk);
-        };
-        if (half) xch(std::integral_constant<int, 1>{}); else xch(std::integral_constant<int, 0>{});
+            for (int k = 0; k < 4; k++) W2[n][k] = W1[n][k];     // the first round left the first four k-steps of the second
     }
+    wg_first_weights<2, 4, 8>(rs, wp, lofs, wstride, W2);
+    wg_round<2, 2, 3, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W2, Y);
+    WG_SYNC();                                       // every wavefront has finished reading the layer's input
+    wg_store<0, 3, false>(Y[0], 2 * pair, relu, act, nullptr, li, lk);
+    wg_store<0, 3, false>(Y[1], 2 * pair + 1, relu, act, nullptr, li, lk);
 }
 
 __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __restrict__ x, CylWgParams P, float* __restrict__ y)
@@ -439,23 +439,18 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
 #pragma unroll 1
     for (int l = 0; l < WG_LAYERS; l++) {
         const int cin = P.cin[l], cout = P.cout[l];
-        if (cout == 128) wg_layer_pair<1>(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        const int odd = (cin >> 4) & 1;                          // K in an odd number of loop iterations: one iteration of weights in registers
+        if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (cout == 64) {
-            if ((cin & 31) == 0) {
-                wg_layer_pair<2>(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-                // the exchange ran over the zero words of the channels >= 64: restore them once every wavefront has read its slot
-                // (the next layer has 64 input channels; those rows are rewritten, and barriers passed, before anyone reads them)
-                WG_SYNC();
-                act[(WG_XCH_C + (threadIdx.x >> 2)) * WG_CS + WG_ZERO + (threadIdx.x & 3)] = 0.f;
-            }
-            else wg_layer_single<0, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+            if (odd) wg_layer_single<0, 3, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+            else     wg_layer_single<0, 3, false, 2>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         } else if (l < WG_LAYERS - 1) {
-            if (w & 1)       wg_layer_single<1, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer_single<1, 3, false, 2>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, false, 2>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         } else {
             float* glb = y + (size_t)patch * cout * 140;
-            if (w & 1)       wg_layer_single<1, 3, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer_single<1, 3, true, 2>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, true, 2>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         }
         WG_STAMP_AT(2 * l + 1)
         WG_SYNC();
@@ -464,23 +459,27 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
 }
 
 
-// Host helper: filters w [Cout][Cin][3][3] (BN folded) -> U = G g G^T in fp64, rounded once, in the kernel's B-operand tiling
-// out[16 * Cout * Cin] = [i][k-step][N-tile][lk][li][j] = U[i][j][16 n + li][4 ks + lk].  No device work.
+// Host helper: filters w [Cout][Cin][3][3] (BN folded) -> U = G g G^T in fp64, rounded once, in the kernel's A-operand tiling
+//     out[16 * Cout * Cin] = [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk]
+// with N-groups of NG = 2 N-tiles for 128 output channels (a wavefront owns a pair there) and NG = 1 otherwise: the
+// k-steps of a wavefront follow each other in memory (round 2 had the N-tile inside the k-step: every 1 KB fetch of a
+// wavefront then sat on another 4-8 KB page, and the filter stream cost 8 % of the kernel in translation misses).  No device work.
 extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host)
 {
     BUF_REQUIRE(w_host && out_host, BUF_EINVAL, "buf_winograd_tile_weights: null argument");
     BUF_REQUIRE(cout > 0 && cin > 0 && cout % 16 == 0 && cin % 4 == 0, BUF_EINVAL, "buf_winograd_tile_weights: widths %d -> %d", cin, cout);
     static const double G[4][3] = { { 1, 0, 0 }, { .5, .5, .5 }, { .5, -.5, .5 }, { 0, 0, 1 } };
-    const int k4 = cin / 4, nt = cout / 16;
+    const int k4 = cin / 4, ng = cout == 128 ? 2 : 1;
     for (int o = 0; o < cout; o++)
         for (int c = 0; c < cin; c++) {
             const float* g = w_host + ((size_t)o * cin + c) * 9;
+            const int n = o / 16;
             for (int i = 0; i < 4; i++)
                 for (int j = 0; j < 4; j++) {
                     double u = 0;
                     for (int a = 0; a < 3; a++)
                         for (int b = 0; b < 3; b++) u += G[i][a] * (double)g[3 * a + b] * G[j][b];
-                    const size_t idx = ((((size_t)i * k4 + c / 4) * nt + o / 16) * 4 + c % 4) * 16 + o % 16;
+                    const size_t idx = ((((((size_t)(n / ng) * 4 + i) * k4 + c / 4) * ng + n % ng) * 4 + c % 4) * 16 + o % 16);
                     out_host[idx * 4 + j] = (float)u;
                 }
         }
@@ -501,6 +500,8 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
         BUF_REQUIRE(P.wt[l] && P.bias[l], BUF_EINVAL, "buf_cylindrical_net_wg: null weights for layer %d", l);
         BUF_REQUIRE(P.cin[l] % 16 == 0 && P.cin[l] <= WG_MAXC && (P.cout[l] == 32 || P.cout[l] == 64 || P.cout[l] == 128),
                     BUF_EINVAL, "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d", l, P.cin[l], P.cout[l]);
+        BUF_REQUIRE(P.cout[l] == 64 || P.cin[l] % 32 == 0, BUF_EINVAL,
+                    "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (32 and 128 output channels need Cin %% 32 == 0)", l, P.cin[l], P.cout[l]);
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net_wg: layer %d width mismatch", l);
     }
     BUF_REQUIRE(P.cout[WG_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_wg: the last layer must have 32 channels");

@@ -509,14 +509,16 @@ def mfma_tile_weights(wt, lk_major=False):
 
 
 def winograd_tile_weights(w):
-    """[Cout, Cin, 3, 3] -> the F(2x2, 3x3) filter transform U = G g G^T (fp64, rounded once to fp32) in the B-operand tiling
-    of csrc/convnet_wg.hip: [i][k-step][N-tile][lk][li][j] = U[i][j][16 n + li][4 ks + lk]."""
+    """[Cout, Cin, 3, 3] -> the F(2x2, 3x3) filter transform U = G g G^T (fp64, rounded once to fp32) in the A-operand tiling
+    of csrc/convnet_wg.hip: [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk], N-groups of NG = 2
+    N-tiles for 128 output channels and 1 otherwise (buf_winograd_tile_weights is the same function on the C side)."""
     cout, cin = w.shape[0], w.shape[1]
     assert cin % 4 == 0 and cout % 16 == 0
+    ng = 2 if cout == 128 else 1
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     U = np.einsum('ia,ocab,jb->ijoc', G, np.asarray(w, np.float64), G)                 # [i, j, Cout, Cin]
-    U = U.reshape(4, 4, cout // 16, 16, cin // 4, 4)                                   # [i, j, n, li, ks, lk]
-    return np.ascontiguousarray(np.transpose(U, (0, 4, 2, 5, 3, 1)), dtype=np.float32).reshape(-1)
+    U = U.reshape(4, 4, cout // (16 * ng), ng, 16, cin // 4, 4)                        # [i, j, g, n2, li, ks, lk]
+    return np.ascontiguousarray(np.transpose(U, (2, 0, 5, 3, 6, 4, 1)), dtype=np.float32).reshape(-1)
 
 
 class CylindricalNet:

@@ -175,8 +175,8 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
     cin, cout = 8, 16
     w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
     x = rng.standard_normal((cin, 7, 20))
-    U = ops.winograd_tile_weights(w).reshape(4, cin // 4, cout // 16, 4, 16, 4)          # [i, ks, n, lk, li, j]
-    U = np.transpose(U, (0, 5, 2, 4, 1, 3)).reshape(4, 4, cout, cin).astype(np.float64)   # [i, j, Cout, Cin]
+    U = ops.winograd_tile_weights(w).reshape(cout // 16, 4, cin // 4, 4, 16, 4)          # [n, i, ks, lk, li, j]
+    U = np.transpose(U, (1, 5, 0, 4, 2, 3)).reshape(4, 4, cout, cin).astype(np.float64)   # [i, j, Cout, Cin]
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
     assert np.abs(U - np.einsum('ia,ocab,jb->ijoc', G, w.astype(np.float64), G)).max() < 1e-6
     BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
@@ -201,3 +201,11 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
     rc = _lib.lib().buf_winograd_tile_weights(w2.ctypes.data_as(C.c_void_p), 32, 16, got.ctypes.data_as(C.c_void_p))
     assert rc == 0 and np.array_equal(got, ops.winograd_tile_weights(w2))
     assert _lib.lib().buf_winograd_tile_weights(w2.ctypes.data_as(C.c_void_p), 30, 16, got.ctypes.data_as(C.c_void_p)) == -1
+    # 128 output channels: N-tile pairs [pair][i][ks][n2][lk][li][j]
+    w3 = np.ascontiguousarray(rng.standard_normal((128, 32, 3, 3)).astype(np.float32))
+    t3 = ops.winograd_tile_weights(w3)
+    U3 = np.transpose(t3.reshape(4, 4, 8, 2, 4, 16, 4), (1, 6, 0, 3, 5, 2, 4)).reshape(4, 4, 128, 32)
+    assert np.abs(U3 - np.einsum('ia,ocab,jb->ijoc', G, w3.astype(np.float64), G)).max() < 1e-6
+    got3 = np.empty(16 * 128 * 32, np.float32)
+    assert _lib.lib().buf_winograd_tile_weights(w3.ctypes.data_as(C.c_void_p), 128, 32, got3.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(got3, t3)
