@@ -351,7 +351,7 @@ __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* 
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
     const unsigned wp = (unsigned)nt * (16 * cin * 16);                   // [N-tile][i][k-step][lane][j]: a wavefront streams its own block
     const unsigned lofs = lane * 16;
-    wgf4 W[1][4 * WD];                                // WD iterations of weights in registers: every load is issued 4 WD - 2 k-steps ahead
+    wgf4 W[1][4 * WD];                                // WD iterations of weights in registers (two bought nothing here: measured)
     wg_first_weights<1, 0, 4 * WD>(rs, wp, lofs, wstride, W);
     wgf4 Y[1][3][2][2];
     const wgf4 bv[1] = { *reinterpret_cast<const wgf4*>(bias + nt * 16 + lk * 4) };
@@ -359,6 +359,11 @@ __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* 
     WG_SYNC();                                 // every wavefront has finished reading the layer's input
     wg_store<T0, T1, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
 }
+
+// N-tiles per wavefront of a layer: 2 (the paired form below) or 1.  The filter tiling follows it (buf_winograd_tile_weights).
+// Pairs for the 64-channel layers too (two wavefronts per pair, K split between them, partial sums exchanged through the dead
+// half of the buffer) measured 1 % slower, before and after the filter stream became cheap: short K loops, a third barrier.
+__host__ __device__ constexpr int wg_group(int cin, int cout) { return cout == 128 ? 2 : 1; }
 
 // One layer with 128 output channels: wavefront w owns the N-tile pair 2w, 2w+1 over the whole K, and the transform of a step
 // feeds 8 MFMAs.  The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs: two rounds, M-tiles
@@ -439,18 +444,16 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
 #pragma unroll 1
     for (int l = 0; l < WG_LAYERS; l++) {
         const int cin = P.cin[l], cout = P.cout[l];
-        const int odd = (cin >> 4) & 1;                          // K in an odd number of loop iterations: one iteration of weights in registers
         if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (cout == 64) {
-            if (odd) wg_layer_single<0, 3, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-            else     wg_layer_single<0, 3, false, 2>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+            wg_layer_single<0, 3, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         } else if (l < WG_LAYERS - 1) {
-            if (w & 1)       wg_layer_single<1, 3, false, 2>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, false, 2>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer_single<1, 3, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         } else {
             float* glb = y + (size_t)patch * cout * 140;
-            if (w & 1)       wg_layer_single<1, 3, true, 2>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, true, 2>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer_single<1, 3, true, 1>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, true, 1>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         }
         WG_STAMP_AT(2 * l + 1)
         WG_SYNC();
@@ -469,7 +472,7 @@ extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin,
     BUF_REQUIRE(w_host && out_host, BUF_EINVAL, "buf_winograd_tile_weights: null argument");
     BUF_REQUIRE(cout > 0 && cin > 0 && cout % 16 == 0 && cin % 4 == 0, BUF_EINVAL, "buf_winograd_tile_weights: widths %d -> %d", cin, cout);
     static const double G[4][3] = { { 1, 0, 0 }, { .5, .5, .5 }, { .5, -.5, .5 }, { 0, 0, 1 } };
-    const int k4 = cin / 4, ng = cout == 128 ? 2 : 1;
+    const int k4 = cin / 4, ng = wg_group(cin, cout);
     for (int o = 0; o < cout; o++)
         for (int c = 0; c < cin; c++) {
             const float* g = w_host + ((size_t)o * cin + c) * 9;
@@ -486,6 +489,9 @@ extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin,
     return BUF_OK;
 }
 
+// N-tiles per group in the filter tiling of a layer with these widths (the Python side asks instead of restating the rule)
+extern "C" int buf_winograd_group(int cin, int cout) { return wg_group(cin, cout); }
+
 // x f32[np,48,140] -> y f32[np,32,140]; weights in the Winograd-domain tiling (see CylWgParams).
 extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                       const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream)
@@ -500,8 +506,8 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
         BUF_REQUIRE(P.wt[l] && P.bias[l], BUF_EINVAL, "buf_cylindrical_net_wg: null weights for layer %d", l);
         BUF_REQUIRE(P.cin[l] % 16 == 0 && P.cin[l] <= WG_MAXC && (P.cout[l] == 32 || P.cout[l] == 64 || P.cout[l] == 128),
                     BUF_EINVAL, "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d", l, P.cin[l], P.cout[l]);
-        BUF_REQUIRE(P.cout[l] == 64 || P.cin[l] % 32 == 0, BUF_EINVAL,
-                    "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (32 and 128 output channels need Cin %% 32 == 0)", l, P.cin[l], P.cout[l]);
+        BUF_REQUIRE(P.cout[l] != 128 || P.cin[l] % 32 == 0, BUF_EINVAL,
+                    "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (128 output channels need Cin %% 32 == 0)", l, P.cin[l], P.cout[l]);
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net_wg: layer %d width mismatch", l);
     }
     BUF_REQUIRE(P.cout[WG_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_wg: the last layer must have 32 channels");

@@ -514,7 +514,7 @@ def winograd_tile_weights(w):
     N-tiles for 128 output channels and 1 otherwise (buf_winograd_tile_weights is the same function on the C side)."""
     cout, cin = w.shape[0], w.shape[1]
     assert cin % 4 == 0 and cout % 16 == 0
-    ng = 2 if cout == 128 else 1
+    ng = _lib.lib().buf_winograd_group(cin, cout)                  # N-tiles per wavefront for these widths: the kernel's rule
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     U = np.einsum('ia,ocab,jb->ijoc', G, np.asarray(w, np.float64), G)                 # [i, j, Cout, Cin]
     U = U.reshape(4, 4, cout // (16 * ng), ng, 16, cin // 4, 4)                        # [i, j, g, n2, li, ks, lk]

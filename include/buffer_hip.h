@@ -249,8 +249,10 @@ int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_h
  * (csrc/convnet_wg.hip: 44 instead of 75 matrix instructions per 4 input x 16 output channels; a different fp32 summation
  * order, within 1e-6 of the output scale of the direct form).  Same x / y as buf_cylindrical_net.
  * wt_host[l]: DEVICE pointers to U = G g G^T of the BN-folded filters ([Cout,Cin,3,3]; layer 0: Cin = c16*3 + depth) in the
- * tiling [i][k-step][N-tile][lk][li][j] = U[i][j][16 n + li][4 ks + lk] (buf_winograd_tile_weights, fp64 on the host); Cin a multiple of 16,
- * Cout in {32, 64, 128}, last layer 32. */
+ * tiling [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk] with NG = buf_winograd_group(Cin, Cout)
+ * N-tiles per group (the N-tiles one wavefront owns: its k-steps are contiguous in memory), as buf_winograd_tile_weights lays
+ * them out (fp64 on the host).  Cin a multiple of 16 (of 32 for Cout 128), Cout in {32, 64, 128}, last layer 32. */
+int     buf_winograd_group(int cin, int cout);                                                   /* host only: NG of a layer */
 int     buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host);   /* host only: [Cout,Cin,3,3] -> 16*Cout*Cin floats */
 int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
