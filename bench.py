@@ -59,7 +59,8 @@ def parse():
                     help='the pairs of a step are split into this many stacked batches, one host thread + HIP stream each')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='do not overlap the keypoint stage of step i+1 with the descriptor stage of step i (two HIP streams)')
-    ap.add_argument('--distinct-pairs', type=int, default=4, help='synthetic pairs generated per rank (cycled)')
+    ap.add_argument('--distinct-pairs', type=int, default=None,
+                    help='synthetic pairs generated per rank, distinct seeds (default: pairs-per-step, so a step never repeats a pair)')
     ap.add_argument('--stream-pairs', type=int, default=1623, help='1623 = 3DMatch test set, 1781 = 3DLoMatch')
     ap.add_argument('--stream-overlaps', default=None,
                     help='overlap classes of the synthetic stream, equal shares (default 0.75,0.6,0.45,0.3; a 3DLoMatch-like set: 0.3,0.25,0.2,0.15)')
@@ -143,13 +144,21 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
     """`roofline` (dominant kernel) + `roofline_other` (every other kernel with a roofline class in SURVEY 8d)."""
     main = roof_entry(timed, 'cyl_net', 'k_cyl_net_wg (A11 Cylindrical_Net, fused fp32 MFMA, Winograd F(2x2,3x3))', 'mfma', MFMA_F32_PEAK_TFLOPS,
                       'TFLOP/s', 1e12, traffic_of(pmc, 'k_cyl_net_wg', units.get('patches')),
-                      flops='achieved = dense algorithmic count of the reference convolutions (SURVEY 8d: 0.1187 GFLOP/patch) / time; the '
-                            'kernel evaluates them in the Winograd F(2x2,3x3) domain in fp32 and executes 0.559 of that count on the '
-                            'matrix pipe, so frac can exceed 1: executed_frac is the matrix-pipe utilisation',
                       executed_fraction_of_dense=CYL_NET_EXECUTED_FRACTION)
     if main:
-        main['executed_tflops'] = main['achieved'] * CYL_NET_EXECUTED_FRACTION
-        main['executed_frac'] = main['frac'] * CYL_NET_EXECUTED_FRACTION
+        # What the hardware did: the kernel evaluates the reference's convolutions in the Winograd F(2x2,3x3) domain in fp32 and
+        # EXECUTES 0.559 of their dense count on the matrix pipe.  achieved / frac = executed flops (matrix-pipe utilisation);
+        # the dense algorithmic count of SURVEY 8d (0.1187 GFLOP/patch) over the same time is reported beside it.
+        dense = main['achieved']
+        main['dense_equivalent_tflops'] = dense
+        main['achieved'] = dense * CYL_NET_EXECUTED_FRACTION
+        main['frac'] = main['achieved'] / MFMA_F32_PEAK_TFLOPS
+        main['avg_executed_flops'] = main['avg_algorithmic_flops'] * CYL_NET_EXECUTED_FRACTION
+        main['flops'] = ('achieved = flops EXECUTED on the matrix pipe (44 v_mfma_f32_16x16x4_f32 per 4 input x 16 output channels = 0.559 '
+                         'of the dense count) / HIP-event time on the launch stream; dense_equivalent_* = the algorithmic count of the '
+                         'reference convolutions (SURVEY 8d: 0.1187 GFLOP/patch) over the same time')
+        main['traffic_source'] = ('replayed: HBM bytes per patch of profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                                  'passes of this build, gfx950 corrections) x the patches of one launch of this run') if main['traffic'] else None
     matches = timed['cost_net'][2] / max(timed['cost_net'][0], 1) / COST_NET_FLOPS_PER_MATCH
     other = [
         roof_entry(timed, 'cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
@@ -240,7 +249,7 @@ def main():
     pipe = BufferPipeline(cfg, dev)
     calib = make(1000)                                # same calibration pair on every rank -> identical limits
     limits = pipe.calibrate([calib])
-    samples = [make(2000 + rank * 97 + i) for i in range(a.distinct_pairs)]
+    samples = [make(2000 + rank * 1000 + i) for i in range(a.distinct_pairs or pps)]
     inputs = [pipe.upload(s) for s in samples]
     torch.cuda.synchronize()
 
@@ -344,6 +353,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': label, 'pairs_per_step_per_gpu': pps, 'streams': nconc,
                        'steps_pipelined': bool(pool is None and not a.no_pipeline), 'keypoints_per_fragment': keypts,
+                       'distinct_pairs_per_gpu': len(samples),
                        'fds_points': [int(samples[0]['src_fds_pts'].shape[0]), int(samples[0]['tgt_fds_pts'].shape[0])],
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,
                        'weights': ('KITTI 06050001' if kitti else '3DMatch 06132318') + ' (released)', 'parallelism': f'pair-sharded x{world}',
@@ -387,8 +397,7 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
     makers = [(lambda ch=ch: [upload(x) for x in stream.prepare_batch([mine[j] for j in ch], cfg, [ids[j] for j in ch])]) for ch in chunks]
     poses = [p for ps in pipe.register_batches(makers, seeds=[[ids[j] for j in ch] for ch in chunks]) for p in ps]
     local_poses = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
-    if world > 1:
-        bdist.gather_poses(ids, local_poses, n, device=cdev)
+    all_poses = bdist.gather_poses(ids, local_poses, n, device=cdev) if world > 1 else local_poses      # the path's one exchange
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -400,8 +409,15 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        quality = stream.evaluate_stream(mine, local_poses.cpu().numpy())          # (N > 1: rank 0 scores its own shard)
-        quality['scored'] = f'{len(ids)} pairs' + (' (rank 0 shard)' if world > 1 else '')
+        # every pair of the job is scored on rank 0 from the gathered poses; the ground truth of the other ranks' pairs is
+        # regenerated here (untimed: same seeds), keeping only what the evaluator reads
+        meta = {i: m for i, m in zip(ids, mine)}
+        for i in range(n):
+            if i not in meta:
+                r = synth.make_raw_pair_device(20000 + i, overlaps[i % len(overlaps)], dev)
+                meta[i] = {'relt_pose': r['relt_pose'], 'overlap_pts': r['overlap_pts']}
+        quality = stream.evaluate_stream([meta[i] for i in range(n)], all_poses.cpu().numpy())
+        quality['scored'] = f'{n} pairs (all ranks, gathered poses)'
         main_roof, other = rooflines(timed, load_traffic(), None, {})
         print(json.dumps({
             'metric': 'registration pairs/sec', 'value': n / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': 1, 'warmup': 0,

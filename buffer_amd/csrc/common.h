@@ -61,6 +61,15 @@ size_t scan_tmp_ints();
 int exclusive_scan_i32(int* data, long long n, int* tmp, int* total_out, hipStream_t stream);
 
 // ---- device helpers ---------------------------------------------------------------------
+// Hand-over of LDS data between the lanes of ONE wavefront: the scheduling barrier alone is no memory fence for the compiler
+// (IntrNoMem), so it is paired with wavefront-scope release / acquire fences (no instructions on a single wave).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Reference distance: result = 0; result += dx*dx; += dy*dy; += dz*dz  (nanoflann.hpp:433-441).
 // __fmul_rn/__fadd_rn are never contracted into FMA.
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz)

@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(SPB_WAVES * WAVE) k_select_patches_grid(const 
         unsigned long long* M = spb_mask + (size_t)w * mask_words;
         const int nw = (n + 63) >> 6;
         for (int i = lane; i < nw; i += WAVE) M[i] = 0ull;
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
         for (int c0 = 0; c0 < total; c0 += WAVE) {
             const int cc = c0 + lane;
             int off = st[0];
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(SPB_WAVES * WAVE) k_select_patches_grid(const 
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
         // ordered emission: lane l owns the words [l*wpl, (l+1)*wpl); slot of its first hit = hits in the lanes below
         const int wpl = (nw + WAVE - 1) / WAVE;
         int mine = 0;

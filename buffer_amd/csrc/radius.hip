@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     const int e_lo = q_off[b], e_n = q_off[b + 1] - e_lo;                 // scalar loads
     if ((int)blockIdx.x * QW_QPB >= e_n) return;                          // chunk past this element's queries
     const int tl = (blockIdx.x * QW_WAVES + w) * QPW + grp;               // query number inside the element
-    const bool active = tl < e_n;
+    bool active = tl < e_n;
     const int t = e_lo + tl;
     int qi = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -269,7 +269,15 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
             qi = __float_as_int(s.w); qx = s.x; qy = s.y; qz = s.z;
         } else {
             qi = q_order ? q_order[t] : t;
-            qx = queries[3 * (size_t)qi]; qy = queries[3 * (size_t)qi + 1]; qz = queries[3 * (size_t)qi + 2];
+            // The block takes its batch element from blockIdx.y, i.e. from the SLOT t.  A caller's q_order may put a query of
+            // another element into this slot (any permutation of 0..nq-1 is allowed): that query goes to the todo list -- the
+            // lane-per-query pass behind this kernel finds the element of every query it handles from the query's index.
+            if (qi < e_lo || qi >= e_lo + e_n) {
+                if (l16 == 0) todo[atomicAdd(todo_n, 1)] = qi;
+                active = false;
+            } else {
+                qx = queries[3 * (size_t)qi]; qy = queries[3 * (size_t)qi + 1]; qz = queries[3 * (size_t)qi + 2];
+            }
         }
     }
     const CellGrid g = grids[b];                                          // uniform address: scalar loads
@@ -294,7 +302,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
         }
         if (l16 < 10) { runs[w][grp][l16] = rs; runs[w][grp][10 + l16] = len; }          // slots 9 / 19: zero padding
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     int st[9], pre[9], total = 0;
     {
         const int4* R4 = reinterpret_cast<const int4*>(runs[w][grp]);
@@ -346,7 +354,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     for (int dd = QG; dd < WAVE; dd <<= 1) mmax = max(mmax, __shfl_xor(mmax, dd, WAVE));      // max over the 4 groups
     mmax = __builtin_amdgcn_readfirstlane(mmax);
     // bucket offsets: exclusive scan of the 16 counts over the group's lanes
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     {
         const int cnt = hist[w][grp][l16];
         const int ex = row16_excl_scan(cnt);
@@ -354,7 +362,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
         cur[w][grp][l16] = ex;
         if (l16 == QG - 1) pref[w][grp][QG] = ex + cnt;
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     unsigned long long* B = bkeys[w][grp];
     const int rounds = (mmax + QG - 1) / QG;
     // scatter into bucket order; every key remembers the extent of its bucket
@@ -373,7 +381,7 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     // rank inside the bucket (the keys of lower buckets are all smaller), then write the row
 #pragma unroll
     for (int r = 0; r < CAP / QG; r++) {
@@ -492,6 +500,9 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
     float r2 = radius * radius;     // neighbors.cpp:228
     int blocks = cdiv(nq, WAVE);
     BUF_REQUIRE(todo_ws || k_out == 0, BUF_EINVAL, "buf_grid_query: todo workspace missing");
+    // a caller-supplied order other than the grid's own may cross batch elements: those queries need the todo list
+    const bool foreign_order = q_order && !self_query;
+    BUF_REQUIRE(todo_ws || !foreign_order, BUF_EINVAL, "buf_grid_query: a q_order other than the grid's own needs the todo workspace");
     int* todo = (int*)todo_ws;
     BUF_CHECK_HIP(hipMemsetAsync(ex.todo_n, 0, sizeof(int), s));
     // algorithmic bytes of this launch: queries + supports + the index table
@@ -516,14 +527,15 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
                                                                          counts_out, max_count_out, todo, ex.todo_n);
     }
     if (timed) timing_end(s, &span);
-    if (k_out > 0) {
-        // fallback pass over the (normally empty) todo list; exits at once when the device-side count is 0
+    if (k_out > 0 || foreign_order) {
+        // fallback pass over the (normally empty) todo list; exits at once when the device-side count is 0.  It rewrites whole
+        // rows and counts (the same values where the wave kernel already counted a long row)
         if (k_out <= 32)
             k_grid_query<32><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
-                                                    ex.q_off, g->nb, todo, r2, k_out, g->ns, nbr_out, nullptr, nullptr, ex.todo_n);
+                                                    ex.q_off, g->nb, todo, r2, k_out, g->ns, nbr_out, counts_out, max_count_out, ex.todo_n);
         else
             k_grid_query<64><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
-                                                    ex.q_off, g->nb, todo, r2, k_out, g->ns, nbr_out, nullptr, nullptr, ex.todo_n);
+                                                    ex.q_off, g->nb, todo, r2, k_out, g->ns, nbr_out, counts_out, max_count_out, ex.todo_n);
     }
     BUF_LAUNCH_CHECK();
     return BUF_OK;

@@ -15,6 +15,7 @@
 
 #define VOX_THREADS 448     // 7 wavefronts >= 420 centres
 #define VOX_MAXPTS 1024
+static_assert(VOX_MAXPTS <= 32 * 32, "the non-empty-word summary of a hit mask is one 32-bit register (voxelize phase 2+3)");
 #define VOX_CH 16
 #define VOX_MAXS 16           // max samples per voxel kept in the hit list
 #define VOX_GRID 16           // lookup grid cells per axis

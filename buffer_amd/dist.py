@@ -36,12 +36,15 @@ def gather_poses(local_ids, local_poses, n_pairs, device=None):
     world = dist.get_world_size() if dist.is_initialized() else 1
     device = device or (local_poses.device if isinstance(local_poses, torch.Tensor) else 'cpu')
     cap = (n_pairs + world - 1) // world
+    # one [cap, 17] block per rank: column 0 carries the pair id as the BITS of an int32 (exact for any id; a float would stop
+    # at 2^24), columns 1..16 the pose; -1 marks an unused row
     buf = torch.zeros((cap, 17), dtype=torch.float32, device=device)
-    buf[:, 0] = -1
+    idcol = torch.full((cap,), -1, dtype=torch.int32, device=device)
     k = len(local_ids)
     if k:
-        buf[:k, 0] = torch.as_tensor(local_ids, dtype=torch.float32, device=device)
+        idcol[:k] = torch.as_tensor(local_ids, dtype=torch.int32, device=device)
         buf[:k, 1:] = torch.as_tensor(local_poses, dtype=torch.float32, device=device).reshape(k, 16)
+    buf[:, 0] = idcol.view(torch.float32)
     if world > 1:
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf)
@@ -49,9 +52,9 @@ def gather_poses(local_ids, local_poses, n_pairs, device=None):
     else:
         allbuf = buf
     out = torch.eye(4, dtype=torch.float32, device=device).repeat(n_pairs, 1, 1)
-    valid = allbuf[:, 0] >= 0
-    ids = allbuf[valid, 0].long()
-    out[ids] = allbuf[valid, 1:].reshape(-1, 4, 4)
+    ids = allbuf[:, 0].contiguous().view(torch.int32)
+    valid = ids >= 0
+    out[ids[valid].long()] = allbuf[valid, 1:].reshape(-1, 4, 4)
     return out
 
 

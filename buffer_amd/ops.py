@@ -80,7 +80,7 @@ class CellGrid:
         if q_order is not None:
             q_order = _dev(q_order, torch.int32, "q_order")
         r = self.radius if radius is None else float(radius)
-        todo = torch.empty((max(nq, 1),), dtype=torch.int32, device=queries.device) if k > 0 else None
+        todo = torch.empty((max(nq, 1),), dtype=torch.int32, device=queries.device) if (k > 0 or q_order is not None) else None
         check(L.buf_grid_query(C.byref(self.g), _ptr(queries), nq, _hptr(q_lengths), _ptr(q_order), r, int(k),
                                _ptr(out), _ptr(cnt), _ptr(max_count), _ptr(todo), _stream()), "buf_grid_query")
         return (out, cnt) if counts else out

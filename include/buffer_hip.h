@@ -94,10 +94,13 @@ int64_t buf_grid_default_cells(int ns, int nb);
 size_t  buf_grid_ws_bytes(int ns, int nb, int64_t cells_per_elem);
 int     buf_grid_build(buf_grid_t* g, const float* supports, int ns, const int* s_batches_host, int nb,
                        float radius, int64_t cells_per_elem, void* ws, size_t ws_bytes, void* stream);
-/* queries f32[nq,3]; q_order (nullable) int32[nq]: processing order (thread t handles query
- * q_order[t]) -- a spatially coherent order keeps a wavefront inside few cells; the result
- * does not depend on it.  Passing the grid's own supports with q_order == g->order (a self query in
- * cell order) lets the kernel take index and coordinates from the cell-ordered array in one load.  nbr_out int32[nq,k_out] (k_out may be 0: count only);
+/* queries f32[nq,3]; q_order (nullable) int32[nq]: processing order, any permutation of 0..nq-1 (slot t handles query
+ * q_order[t]) -- a spatially coherent order keeps a wavefront inside few cells; the result does not depend on it.  The fast
+ * kernel takes a slot's batch element from the slot, so an order that keeps every element's queries inside that element's
+ * range [q_off[b], q_off[b+1]) runs entirely on it (the grid's own order, or the order of another grid over the same
+ * clouds, do); a query placed in another element's range is handed to the slower lane-per-query pass (same result).
+ * Passing the grid's own supports with q_order == g->order (a self query in cell order) lets the kernel take index and
+ * coordinates from the cell-ordered array in one load.  nbr_out int32[nq,k_out] (k_out may be 0: count only);
  * counts_out (nullable) int32[nq] = untruncated neighbour counts; max_count_out (nullable)
  * int32[1], atomically max-ed (caller zeroes it).  radius may differ from the build radius
  * as long as it is <= the grid's cell edge. */
@@ -105,7 +108,7 @@ int     buf_grid_query(const buf_grid_t* g, const float* queries, int nq, const 
                        const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
                        int* max_count_out, void* todo_ws, void* stream);
 /* todo_ws: int32[nq] scratch (rows longer than 64 neighbours are redone by a second, unbounded pass);
- * may be null when k_out == 0.
+ * may be null when k_out == 0 and q_order is null or the grid's own order.
  * Build + query in one call (what batch_query does); ws >= buf_grid_ws_bytes(ns,nb,0) + 4*nq bytes. */
 int     buf_radius_neighbors(const float* queries, int nq, const float* supports, int ns,
                              const int* q_batches_host, const int* s_batches_host, int nb, float radius,

@@ -72,6 +72,19 @@ def test_truncated_table_is_prefix_of_full(big, dev):
         assert torch.equal(grid.query(P, lens, k), full[:, :k])
     # the result does not depend on the processing order
     assert torch.equal(grid.query(P, lens, 17, q_order=grid.order), full[:, :17])
+    # ... including an order that moves queries into another batch element's range of slots (any permutation is allowed:
+    # those queries take the lane-per-query pass), with and without rows, and on a query cloud other than the supports
+    g = torch.Generator(device='cpu').manual_seed(7)
+    perm = torch.randperm(P.shape[0], generator=g).int().to(dev)
+    _, cnt_ref = grid.query(P, lens, 17, counts=True)
+    tab, cnt = grid.query(P, lens, 17, q_order=perm, counts=True)
+    assert torch.equal(tab, full[:, :17]) and torch.equal(cnt, cnt_ref)
+    mc = torch.zeros(1, dtype=torch.int32, device=dev)
+    _, cnt0 = grid.query(P, lens, 0, q_order=perm, counts=True, max_count=mc)
+    assert torch.equal(cnt0, cnt_ref) and int(mc.item()) == int(cnt_ref.max().item())
+    Q = P + 0.01
+    swap = torch.arange(Q.shape[0], dtype=torch.int32, device=dev).flip(0)          # every slot holds the other element's query
+    assert torch.equal(grid.query(Q, lens, 20, q_order=swap), grid.query(Q, lens, 20))
 
 
 def test_subsample_mass_and_voxel_membership(big, dev):

@@ -2,7 +2,7 @@
 # The measurement set of a round, on the GPU box: bench lines (headline, stream, kitti), rocprofv3 kernel stats of the
 # headline command, the two HBM-traffic PMC passes, SQ counters.  Everything lands in gpurun_out/<tag>/; copy what is to be
 # judged into profiles/.
-set -x
+set -ex
 tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$tag
