@@ -11,8 +11,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_ORACLE_SO = os.path.join(_HERE, "liboracle.so")
-_REF_SO = os.path.join(_HERE, "_ref", "libbuffer_ref.so")
+# BUF_ORACLE_SO / BUF_ORACLE_REF_SO: the sanitizer builds (make -C oracle asan) under tests/test_sanitizers_cpu.py
+_ORACLE_SO = os.environ.get("BUF_ORACLE_SO") or os.path.join(_HERE, "liboracle.so")
+_REF_SO = os.environ.get("BUF_ORACLE_REF_SO") or os.path.join(_HERE, "_ref", "libbuffer_ref.so")
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
