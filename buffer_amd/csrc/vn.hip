@@ -64,19 +64,25 @@ __global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_p
     float bsc = has_bn ? P.bn_scale[o] : 0.f, bsh = has_bn ? P.bn_shift[o] : 0.f;
     float qx = q_pts[3 * (size_t)i], qy = q_pts[3 * (size_t)i + 1], qz = q_pts[3 * (size_t)i + 2];
     const int* row = idx + (size_t)i * K;
+    // Dot products over the input channels and the sums over the K slots run in fp64 and are rounded once (round 3): an fp32
+    // sum is one summation order among many, and on the KITTI branch (80 m coordinates, features near zero behind VN-BN) this
+    // kernel's order put the HIP path at twice the reference's own distance from the float64 network (eps 9.0e-4 vs 4.3e-4 of
+    // scale); with fp64 sums it sits at the reference's level (6e-4: what is left is the fp32 rounding of the stored
+    // features, which every fp32 run has).
     float mx = 0.f, my = 0.f, mz = 0.f;
     if (mode6) {                                            // mean over K of delta (point_learner.py:392)
+        double sx = 0.0, sy = 0.0, sz = 0.0;
         for (int k = 0; k < K; k++) {
             int j = row[k];
             if (j < ns) {
-                mx += (s_pts[3 * (size_t)j] - qx) / scale;
-                my += (s_pts[3 * (size_t)j + 1] - qy) / scale;
-                mz += (s_pts[3 * (size_t)j + 2] - qz) / scale;
+                sx += (double)((s_pts[3 * (size_t)j] - qx) / scale);
+                sy += (double)((s_pts[3 * (size_t)j + 1] - qy) / scale);
+                sz += (double)((s_pts[3 * (size_t)j + 2] - qz) / scale);
             }
         }
-        mx /= (float)K; my /= (float)K; mz /= (float)K;
+        mx = (float)(sx / (double)K); my = (float)(sy / (double)K); mz = (float)(sz / (double)K);
     }
-    float ax = 0.f, ay = 0.f, az = 0.f;
+    double ax = 0.0, ay = 0.0, az = 0.0;
     for (int k = 0; k < K; k++) {
         int j = row[k];
         bool real = j < ns;                                  // shadow: delta = 0, features = 0 (:329-349)
@@ -87,6 +93,7 @@ __global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_p
             ez = (s_pts[3 * (size_t)j + 2] - qz) / scale;
         }
         float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+        double Px = 0, Py = 0, Pz = 0, Dx = 0, Dy = 0, Dz = 0;
         if (mode6) {
             float fx = 0.f, fy = 0.f, fz = 0.f;
             if (real) { fx = feats[3 * (size_t)j]; fy = feats[3 * (size_t)j + 1]; fz = feats[3 * (size_t)j + 2]; }
@@ -101,21 +108,20 @@ __global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_p
             if (real) {
                 const float* f = feats + (size_t)j * 3 * cin;
                 for (int c = 0; c < cin; c++) {
-                    float a = wfo[c], b = wdo[c];
-                    float fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
-                    px = fmaf(a, fx, px); py = fmaf(a, fy, py); pz = fmaf(a, fz, pz);
-                    dx = fmaf(b, fx, dx); dy = fmaf(b, fy, dy); dz = fmaf(b, fz, dz);
+                    double a = wfo[c], b = wdo[c];
+                    double fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
+                    Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
                 }
-                float a = wfo[cin], b = wdo[cin];
-                px = fmaf(a, ex, px); py = fmaf(a, ey, py); pz = fmaf(a, ez, pz);
-                dx = fmaf(b, ex, dx); dy = fmaf(b, ey, dy); dz = fmaf(b, ez, dz);
+                { double a = wfo[cin], b = wdo[cin];
+                  Px += a * ex; Py += a * ey; Pz += a * ez; Dx += b * ex; Dy += b * ey; Dz += b * ez; }
+                px = (float)Px; py = (float)Py; pz = (float)Pz; dx = (float)Dx; dy = (float)Dy; dz = (float)Dz;
             }
         }
         vn_epilogue(px, py, pz, dx, dy, dz, has_bn, bsc, bsh, P.slope);
-        ax += px; ay += py; az += pz;
+        ax += (double)px; ay += (double)py; az += (double)pz;
     }
     float* dst = out + (size_t)i * 3 * cout + 3 * o;
-    dst[0] = ax / (float)K; dst[1] = ay / (float)K; dst[2] = az / (float)K;      // mean_pool, vn_layers.py:165-166
+    dst[0] = (float)(ax / (double)K); dst[1] = (float)(ay / (double)K); dst[2] = (float)(az / (double)K);      // mean_pool, vn_layers.py:165-166
 }
 
 // Point-wise VN layer (VNLinearLeakyReLU with dim=4; VNBlock, unary, shortcut, fc_layer, VNStdFeature):
@@ -139,26 +145,25 @@ __global__ void __launch_bounds__(256) k_vn_pointwise(const float* __restrict__ 
     int i = (int)(t / cout), o = (int)(t % cout);
     const float* wfo = wf + o * cin;
     const float* wdo = wd + o * cin;
-    float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    double Px = 0, Py = 0, Pz = 0, Dx = 0, Dy = 0, Dz = 0;
     int ia = ind_a ? ind_a[(size_t)i * ind_stride] : i;
     if (ca > 0 && ia < na) {
         const float* f = A + (size_t)ia * 3 * ca;
         for (int c = 0; c < ca; c++) {
-            float a = wfo[c], b = has_dir ? wdo[c] : 0.f;
-            float fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
-            px = fmaf(a, fx, px); py = fmaf(a, fy, py); pz = fmaf(a, fz, pz);
-            dx = fmaf(b, fx, dx); dy = fmaf(b, fy, dy); dz = fmaf(b, fz, dz);
+            double a = wfo[c], b = has_dir ? wdo[c] : 0.f;
+            double fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
+            Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
         }
     }
     if (cb > 0) {
         const float* f = B + (size_t)i * 3 * cb;
         for (int c = 0; c < cb; c++) {
-            float a = wfo[ca + c], b = has_dir ? wdo[ca + c] : 0.f;
-            float fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
-            px = fmaf(a, fx, px); py = fmaf(a, fy, py); pz = fmaf(a, fz, pz);
-            dx = fmaf(b, fx, dx); dy = fmaf(b, fy, dy); dz = fmaf(b, fz, dz);
+            double a = wfo[ca + c], b = has_dir ? wdo[ca + c] : 0.f;
+            double fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
+            Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
         }
     }
+    float px = (float)Px, py = (float)Py, pz = (float)Pz, dx = (float)Dx, dy = (float)Dy, dz = (float)Dz;
     if (has_dir) {
         bool has_bn = P.bn_scale != nullptr;
         vn_epilogue(px, py, pz, dx, dy, dz, has_bn, has_bn ? P.bn_scale[o] : 0.f, has_bn ? P.bn_shift[o] : 0.f, P.slope);
@@ -279,38 +284,38 @@ extern "C" int buf_vn_std(const float* x, const float* z, int n, int c, float* o
 // partial[seg][split][ch] = sum over the chunk's rows of (x - mean)^(SQ ? 2 : 1); blockDim = c * rows_per_iter
 template <bool SQ>
 __global__ void __launch_bounds__(256) k_seg_partial(const float* __restrict__ x, const int* __restrict__ seg_off, int c,
-                                                   const float* __restrict__ mean, float* __restrict__ partial)
+                                                   const float* __restrict__ mean, double* __restrict__ partial)
 {
-    __shared__ float sh[256];
+    __shared__ double sh[256];
     const int seg = blockIdx.x, split = blockIdx.y;
     const int lo = seg_off[seg], hi = seg_off[seg + 1];
     const int chunk = (hi - lo + SEG_SPLITS - 1) / SEG_SPLITS;
     const int r0 = lo + split * chunk, r1 = min(r0 + chunk, hi);
     const int rpi = blockDim.x / c, ch = threadIdx.x % c, rr = threadIdx.x / c;
     const float mu = SQ ? mean[seg * c + ch] : 0.f;
-    float acc = 0.f;
+    double acc = 0.0;                                        // fp64 sums (tens of thousands of rows per segment), rounded once in k_seg_final
     for (int r = r0 + rr; r < r1; r += rpi) {
         float v = x[(size_t)r * c + ch] - mu;
-        acc += SQ ? v * v : v;
+        acc += SQ ? (double)v * (double)v : (double)v;
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < c) {
-        float t = 0.f;
+        double t = 0.0;
         for (int k = 0; k < rpi; k++) t += sh[k * c + threadIdx.x];
         partial[((size_t)seg * SEG_SPLITS + split) * c + threadIdx.x] = t;
     }
 }
 
-__global__ void k_seg_final(const float* __restrict__ partial, const int* __restrict__ seg_off, int nseg, int c, float* __restrict__ out)
+__global__ void k_seg_final(const double* __restrict__ partial, const int* __restrict__ seg_off, int nseg, int c, float* __restrict__ out)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nseg * c) return;
     int seg = t / c, ch = t % c;
-    float s = 0.f;
+    double s = 0.0;
     for (int k = 0; k < SEG_SPLITS; k++) s += partial[((size_t)seg * SEG_SPLITS + k) * c + ch];
     int cnt = seg_off[seg + 1] - seg_off[seg];
-    out[t] = cnt > 0 ? s / (float)cnt : 0.f;
+    out[t] = cnt > 0 ? (float)(s / (double)cnt) : 0.f;
 }
 
 __global__ void __launch_bounds__(256) k_seg_apply(const float* __restrict__ x, const int* __restrict__ seg_off, int nseg, int c, long long total,
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(256) k_seg_apply(const float* __restrict__ x, 
 extern "C" size_t buf_segment_instance_norm_ws_bytes(int nseg, int c)
 {
     if (nseg <= 0 || c <= 0) return 256;
-    return 256 + sizeof(int) * ((size_t)nseg + 1) + sizeof(float) * (size_t)nseg * c * (SEG_SPLITS + 2) + 256;
+    return 512 + sizeof(int) * ((size_t)nseg + 1) + sizeof(double) * (size_t)nseg * c * SEG_SPLITS + sizeof(float) * (size_t)nseg * c * 2 + 256;
 }
 
 // x f32[n,c] (rows of segment s contiguous, lens_host[s] rows each) -> out f32[n,c] = (x - mean_s) / sqrt(var_s + eps)
@@ -339,7 +344,7 @@ extern "C" int buf_segment_instance_norm(const float* x, int n, int c, const int
     hipStream_t s = (hipStream_t)stream;
     WsCarver w(ws, ws_bytes);
     int* off = w.take<int>((size_t)nseg + 1);
-    float* partial = w.take<float>((size_t)nseg * c * SEG_SPLITS);
+    double* partial = w.take<double>((size_t)nseg * c * SEG_SPLITS);
     float* mean = w.take<float>((size_t)nseg * c);
     float* var = w.take<float>((size_t)nseg * c);
     BUF_REQUIRE(w.ok, BUF_EWORKSPACE, "buf_segment_instance_norm: workspace %zu < %zu", ws_bytes, w.used());

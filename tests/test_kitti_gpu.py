@@ -75,8 +75,10 @@ def test_kitti_branch_vs_reference_fixture(dev):
     axis, eps, bottle, skips, _ = pl.efcnn(pyr, t(f['features']))
     score = pl.detnet(pyr, bottle, skips)
     a, b = axis.cpu().numpy(), f['axis']
-    # 80 m coordinates in fp32: neighbour offsets carry ~1e-5 relative round-off that summation order amplifies;
-    # the oracle (CPU torch) sits at 3e-4 of the axis length from the same fixture, the HIP path at 7e-4
+    # 80 m coordinates in fp32, features near zero behind VN-BN: the REFERENCE'S OWN run is 1.8e-4 (axis) / 4.3e-4 (eps) /
+    # 3.3e-4 (score) of scale away from the float64 network (test_point_learner_error_is_the_fp32_conditioning_of_the_network),
+    # the HIP path 2.0e-4 / 6.3e-4 / 3.4e-4 with its fp64 sums; element-wise against the fixture that is 1.4e-3 (eps) and
+    # 3.8e-3 (score) relative at the worst element (round 3), so the bounds below are 1.3-3x what is measured
     assert np.all(np.linalg.norm(a - b, axis=1) < 1e-3 * np.linalg.norm(b, axis=1) + 1e-5)
     assert np.min((a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))) > 1 - 1e-5
     np.testing.assert_allclose(eps.cpu().numpy(), f['eps'], rtol=5e-3, atol=1e-4)             # sigmoid / softplus after two

@@ -103,7 +103,9 @@ def test_matching_and_pose_vs_reference(W, dev):
                                                   t(f['tgt_R'])[t_mids].contiguous())
     np.testing.assert_allclose(R.cpu().numpy(), f['R_hyp'], rtol=0, atol=1e-5)
     np.testing.assert_allclose(tr.cpu().numpy(), f['t_hyp'], rtol=0, atol=1e-5)
-    assert np.abs(num.cpu().numpy() - f['inlier_num']).max() <= 1      # borderline residuals may flip
+    dnum = np.abs(num.cpu().numpy() - f['inlier_num'])
+    print('INLIER_NUM max |diff|', int(dnum.max()), 'hypotheses differing', int((dnum > 0).sum()), 'of', dnum.size)
+    assert dnum.max() <= 1 and (dnum > 0).sum() <= max(1, dnum.size // 100)      # a residual at the threshold to fp32 round-off may flip
     assert int(best.item()) == int(f['best'])
     assert np.array_equal(np.nonzero(mask.cpu().numpy())[0], f['inlier_ind'])
     T, info = ops.post_refine(t(f['init_pose']), ss, tt, 0.10, 20)
@@ -239,8 +241,8 @@ def test_point_learner_error_is_the_fp32_conditioning_of_the_network(which, dev)
     """Why the element-wise tolerances of the point-learner tests sit above 1e-4: the REFERENCE'S OWN fp32 outputs (fixtures
     F3 / F7) differ from the exact (float64) network by up to 5e-4 element-wise (values near zero after InstanceNorm), i.e.
     the fixture is one fp32 summation order among many.  The bound that holds: measured against the float64 network and
-    normalised by the tensor's scale, the HIP path is as accurate as the reference's run (within 3x) and below 1e-4
-    (below three times the reference's own error where that already exceeds 3e-5: the KITTI branch at 80 m coordinates)."""
+    normalised by the tensor's scale, the HIP path is as accurate as the reference's run (within 1.6x) and below 1e-4
+    (below 1.6 times the reference's own error where that already exceeds 3e-5: the KITTI branch at 80 m coordinates)."""
     from buffer_amd.config import KITTI, THREEDMATCH
     from buffer_amd.point_learner import PointLearner
     from buffer_amd.weights import load_weights
@@ -260,7 +262,8 @@ def test_point_learner_error_is_the_fp32_conditioning_of_the_network(which, dev)
         print(f'{which} {k}: reference fp32 vs fp64 {e_ref:.2e}, HIP vs fp64 {e_hip:.2e}, HIP vs reference '
               f'{np.abs(got[k] - f[k]).max() / scale:.2e} (of the tensor scale {scale:.3g})')
         # (KITTI: 80 m coordinates put the reference's own run at ~2e-4 of the exact axis; 1e-4 is not available to anyone there)
-        assert e_hip <= max(3 * e_ref, 2e-5) and e_hip < max(1e-4, 3 * e_ref), (k, e_ref, e_hip)
+        # measured (round 3, fp64 sums in the VN kernels): 3DMatch HIP 0.4-0.5x the reference's error; KITTI 1.0-1.5x
+        assert e_hip <= max(1.6 * e_ref, 2e-5) and e_hip < max(1e-4, 1.6 * e_ref), (k, e_ref, e_hip)
         assert np.abs(got[k] - f[k]).max() <= max(1e-4, 3 * e_ref) * scale
 
 
