@@ -81,6 +81,15 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return r;
 }
 
+// XCD-aware block order (speed only; MI355X_MICROARCH "Workgroup dispatch": blocks b and b + 8 share an XCD and its L2).
+// Logical block of physical block `bid`: the blocks of one XCD take a CONTIGUOUS range of logical blocks, so neighbouring
+// work items -- which gather from the same rows -- meet in one L2 instead of being dealt over all eight.  A bijection on [0, nb).
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nb)
+{
+    const int x = bid & 7, idx = bid >> 3, q = nb >> 3, r = nb & 7;
+    return x * q + min(x, r) + idx;
+}
+
 // element b such that off[b] <= i < off[b+1]
 __device__ __forceinline__ int find_elem(const int* __restrict__ off, int nb, int i)
 {

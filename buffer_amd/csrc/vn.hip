@@ -55,7 +55,8 @@ __global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_p
     float* wd = lds + cout * cinp;
     for (int t = threadIdx.x; t < cout * cinp; t += 256) { wf[t] = P.wf[t]; wd[t] = P.wd[t]; }
     __syncthreads();
-    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    // blocks of one XCD take neighbouring points: the rows they gather (shared between neighbouring queries) then live in ONE L2
+    long long t = (long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= (long long)nq * cout) return;
     int i = (int)(t / cout), o = (int)(t % cout);
     const float* wfo = wf + o * cinp;
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(256) k_vn_pointwise(const float* __restrict__ 
 __global__ void __launch_bounds__(256) k_gather_max(const float* __restrict__ feats, const int* __restrict__ idx, int nq, int ns,
                                                   int K, int width, float* __restrict__ out)
 {
-    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long t = (long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= (long long)nq * width) return;
     int i = (int)(t / width), f = (int)(t % width);
     const int* row = idx + (size_t)i * K;
