@@ -23,6 +23,7 @@
 // (row stride = 4 mod 32 banks) keeps eight neighbouring positions on distinct bank quads.  With one wavefront per SIMD
 // the number of memory instructions per MFMA, not their bytes, sets the MFMA duty: 1 LDS + 1-2 global loads per group.
 #include "common.h"
+#include <type_traits>
 
 #define CV_THREADS 256
 #define CV_BUF 19200              // floats per ping-pong buffer (largest map: 144 positions x (128 + 4) channels = 19008)
@@ -168,8 +169,10 @@ __device__ __forceinline__ void form_rows(float* __restrict__ R, const float* __
 // weight offset is an immediate on one per-tile base register, so a group of 4 k-steps issues only its loads
 // (one ds_read_b128 per M-tile, one global_load_dwordx4 per N-tile) and its MFMAs.
 // Operands of group g+1 (possibly the first group of the next tap) are loaded while group g multiplies.
-template <int MT, int NT, int CIN, int COUT, int WIN, int KW>
-__device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ wt,
+// INPLACE: `out` is the buffer `in` lives in (all four wavefronts take part): the accumulators ARE the outputs, so they simply
+// wait for the barrier that ends everybody's reads -- one 75 KB buffer instead of two, i.e. two workgroups per CU (round 3).
+template <int MT, int NT, int CIN, int COUT, int WIN, int KW, bool INPLACE>
+__device__ __forceinline__ void cv_conv_layer(const float* in, float* out, const float* __restrict__ wt,
                                               const float* __restrict__ bias, int nt0, bool relu)
 {
     constexpr int WOUT = WIN - KW + 1, P = WOUT * WOUT, GPT = CIN / 16, TAPS = KW * KW, NTOT = COUT / 16;
@@ -237,6 +240,7 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
         wcur = wnxt;
     }
 #undef CVC_LOAD
+    if constexpr (INPLACE) __syncthreads();          // every wavefront has finished reading the map this one overwrites
     // epilogue: ReLU + store; C/D layout: a lane holds channel n at the four positions m = 16t + 4lk + r
 #pragma unroll
     for (int u = 0; u < NT; u++) {
@@ -253,12 +257,12 @@ __device__ __forceinline__ void cv_conv_layer(const float* __restrict__ in, floa
     }
 }
 
-__global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict__ s_eq, const float* __restrict__ t_eq, CostNetParams P,
+__global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restrict__ s_eq, const float* __restrict__ t_eq, CostNetParams P,
                                                         float* __restrict__ ind_out)
 {
-    extern __shared__ float lds[];
-    float* bufA = lds;                       // layer-1 output first, then ping-pong
-    float* bufB = lds + CV_BUF;              // phase A: the maps of the separated layer 0 and the row chunks live here
+    extern __shared__ float lds[];           // ONE buffer of CV_BUF floats (75 KB): two workgroups per CU
+    float* bufA = lds;                       // every map from layer 1 on (layers 2..6 rewrite it in place)
+    float* bufB = lds;                       // phase A: the maps of the separated layer 0 and the row chunks live here first
     float* SP = bufB + CVA_SP;
     float* TP = bufB + CVA_TP;
     float* SM = bufB + CVA_SM;
@@ -318,6 +322,9 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         const float b1v = P.bias[1][w * 16 + li];
         const float* w1 = P.wt[1] + ((size_t)w * 64 + lane) * 4;          // N-tile w of 4; a dn slab = 18 groups
         cvx4 acc5[5];
+        // the 16 output rows of this wavefront's N-tile wait in registers (64) until the last chunk has been read: the layer-1
+        // map then takes the place of the chunks
+        cvx4 done[16];
 #pragma unroll
         for (int i = 0; i < 5; i++) acc5[i] = (cvx4){ 0.f, 0.f, 0.f, 0.f };
         form_rows(bufB + CVA_R0, SM, TB, 0);
@@ -332,47 +339,57 @@ __global__ void __launch_bounds__(CV_THREADS) k_cost_net(const float* __restrict
         cv_gemm_static<MT_, 1, 4, 18>(a_, L, w1 + (size_t)(DN) * 18 * 4 * 256, 4);                       \
         _Pragma("unroll") for (int t = 0; t < MT_; t++) acc5[(T0) + t - (DN) + 2] = a_[t][0];            \
     }
-#pragma unroll 1
-        for (int j = 0; j < 6; j++) {
+        auto chunk = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
             const float* Rc = bufB + ((j & 1) ? CVA_R1 : CVA_R0);
             if (j < 5) form_rows(bufB + ((j & 1) ? CVA_R0 : CVA_R1), SM, TB, 3 * j + 3);     // next chunk, other buffer
-            if (j == 0)      { CV_SLAB(0, 0, 3) CV_SLAB(1, 1, 3) CV_SLAB(2, 2, 3) }
-            else if (j == 5) { CV_SLAB(0, 0, 1) CV_SLAB(1, 0, 2) CV_SLAB(2, 0, 3) }
-            else             { CV_SLAB(0, 0, 3) CV_SLAB(1, 0, 3) CV_SLAB(2, 0, 3) }
+            if constexpr (j == 0)      { CV_SLAB(0, 0, 3) CV_SLAB(1, 1, 3) CV_SLAB(2, 2, 3) }
+            else if constexpr (j == 5) { CV_SLAB(0, 0, 1) CV_SLAB(1, 0, 2) CV_SLAB(2, 0, 3) }
+            else                       { CV_SLAB(0, 0, 3) CV_SLAB(1, 0, 3) CV_SLAB(2, 0, 3) }
 #pragma unroll
             for (int i = 0; i < 3; i++) {                    // completed output rows 3j-2, 3j-1, 3j
-                const int n2 = 3 * j - 2 + i;
-                if (n2 >= 0 && n2 < 16) {
+                constexpr int nb = 3 * j - 2;
+                if (nb + i >= 0 && nb + i < 16) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) bufA[(n2 * 16 + lk * 4 + r) * CV_C64 + w * 16 + li] = fmaxf(acc5[i][r] + b1v, 0.f);
+                    for (int r = 0; r < 4; r++) done[(nb + i) & 15][r] = fmaxf(acc5[i][r] + b1v, 0.f);
                 }
             }
             acc5[0] = acc5[3]; acc5[1] = acc5[4];
             acc5[2] = acc5[3] = acc5[4] = (cvx4){ 0.f, 0.f, 0.f, 0.f };
             __syncthreads();                 // the chunk just read may be overwritten; the next one is complete
-        }
+        };
+        chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{}); chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) bufA[(n2 * 16 + lk * 4 + r) * CV_C64 + w * 16 + li] = done[n2][r];
+        __syncthreads();
 #undef CV_SLAB
     }
 
-    // ---- phase B: layers 2..9, ping-pong bufA <-> bufB ---------------------------------------------------
-    cv_conv_layer<13, 1, 64, 64, 16, 3>(bufA, bufB, P.wt[2], P.bias[2], w, true);            // 16x16 -> 14x14
+    // ---- phase B: layers 2..6 rewrite the buffer in place; the three tiny last layers hop through its free parts -----------
+    cv_conv_layer<13, 1, 64, 64, 16, 3, true>(bufA, bufA, P.wt[2], P.bias[2], w, true);          // 16x16 -> 14x14
     __syncthreads();
-    cv_conv_layer<9, 2, 64, 128, 14, 3>(bufB, bufA, P.wt[3], P.bias[3], 2 * w, true);        // -> 12x12
+    cv_conv_layer<9, 2, 64, 128, 14, 3, true>(bufA, bufA, P.wt[3], P.bias[3], 2 * w, true);      // -> 12x12
     __syncthreads();
-    cv_conv_layer<7, 2, 128, 128, 12, 3>(bufA, bufB, P.wt[4], P.bias[4], 2 * w, true);       // -> 10x10
+    cv_conv_layer<7, 2, 128, 128, 12, 3, true>(bufA, bufA, P.wt[4], P.bias[4], 2 * w, true);     // -> 10x10
     __syncthreads();
-    cv_conv_layer<4, 1, 128, 64, 10, 3>(bufB, bufA, P.wt[5], P.bias[5], w, true);            // -> 8x8
+    cv_conv_layer<4, 1, 128, 64, 10, 3, true>(bufA, bufA, P.wt[5], P.bias[5], w, true);          // -> 8x8
     __syncthreads();
-    cv_conv_layer<3, 1, 64, 64, 8, 3>(bufA, bufB, P.wt[6], P.bias[6], w, true);              // -> 6x6
+    cv_conv_layer<3, 1, 64, 64, 8, 3, true>(bufA, bufA, P.wt[6], P.bias[6], w, true);            // -> 6x6 (36 x 68 floats)
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 64, 32, 6, 3>(bufB, bufA, P.wt[7], P.bias[7], w, true);   // -> 4x4
+    float* hop1 = lds + 4096;
+    float* hop2 = lds + 8192;
+    float* hop3 = lds + 12288;
+    if (w < 2) cv_conv_layer<1, 1, 64, 32, 6, 3, false>(bufA, hop1, P.wt[7], P.bias[7], w, true);    // -> 4x4
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 32, 32, 4, 3>(bufA, bufB, P.wt[8], P.bias[8], w, true);   // -> 2x2
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 4, 3, false>(hop1, hop2, P.wt[8], P.bias[8], w, true);    // -> 2x2
     __syncthreads();
-    if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2>(bufB, bufA, P.wt[9], P.bias[9], w, false);  // -> 1x1, 20 (+12 zero) logits
+    if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2, false>(hop2, hop3, P.wt[9], P.bias[9], w, false);   // -> 1x1, 20 (+12 zero) logits
     __syncthreads();
     if (w == 0) {                            // softmax over the 20 logits, expected index (BUFFER.py:63-65)
-        float v = lane < 20 ? bufA[lane] : -3.4e38f;               // the 1x1 map: position 0, channels 0..19
+        float v = lane < 20 ? hop3[lane] : -3.4e38f;               // the 1x1 map: position 0, channels 0..19
         float mx = v;
         for (int d = WAVE / 2; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, WAVE));
         float e = lane < 20 ? expf(v - mx) : 0.f;
@@ -394,7 +411,7 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
     P.chan_floats = s_rows ? ele_n * 20 : 100;
     P.row_floats = 32 * P.chan_floats;
     P.skip_floats = s_rows ? 20 : 0;                         // elevation row 0 of every channel is not part of the cost volume
-    size_t lds = sizeof(float) * 2 * CV_BUF;
+    size_t lds = sizeof(float) * CV_BUF;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
     // EXECUTED flops per match: layer 0 in its separated form (S-term 60 x 480 x 32, T-term 54 x 288 x 32 MAC instead of the
