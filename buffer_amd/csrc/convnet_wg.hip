@@ -367,7 +367,7 @@ __host__ __device__ constexpr int wg_group(int cin, int cout) { return cout == 1
 
 // One layer with 128 output channels: wavefront w owns the N-tile pair 2w, 2w+1 over the whole K, and the transform of a step
 // feeds 8 MFMAs.  The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs: two rounds, M-tiles
-// {0, 1} and {2}.  The second round has few MFMAs per weight fetch and registers to spare: it keeps two iterations of weights.
+// {0, 1} and {2}.
 __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
                                               int cin, int cout, int relu, int pair)
 {
@@ -389,18 +389,12 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
     wgf4 bv[2];
 #pragma unroll
     for (int n = 0; n < 2; n++) bv[n] = *reinterpret_cast<const wgf4*>(bias + (2 * pair + n) * 16 + lk * 4);
-    wgf4 W2[2][8];
-    {
-        wgf4 W1[2][4];
-        wg_first_weights<2, 0, 4>(rs, wp, lofs, wstride, W1);
-        wg_round<2, 0, 2, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) W2[n][k] = W1[n][k];     // the first round left the first four k-steps of the second
-    }
-    wg_first_weights<2, 4, 8>(rs, wp, lofs, wstride, W2);
-    wg_round<2, 2, 3, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W2, Y);
+    // (both rounds keep one iteration of weights in registers: a second iteration in the short second round -- 64 registers --
+    // measured 0.5 % slower: it spills)
+    wgf4 W1[2][4];
+    wg_first_weights<2, 0, 4>(rs, wp, lofs, wstride, W1);
+    wg_round<2, 0, 2, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    wg_round<2, 2, 3, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
     WG_SYNC();                                       // every wavefront has finished reading the layer's input
     wg_store<0, 3, false>(Y[0], 2 * pair, relu, act, nullptr, li, lk);
     wg_store<0, 3, false>(Y[1], 2 * pair + 1, relu, act, nullptr, li, lk);
