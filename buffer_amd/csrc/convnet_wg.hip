@@ -15,18 +15,17 @@
 // every read of the elevation padding), rewritten in place after each layer -> two workgroups per CU (2 x 80 KB).
 //
 // What bounds the kernel (round 3, tools/micro/mfma_group.hip): v_mfma_f32_16x16x4_f32 runs on the f32 vector lanes, so VALU
-// work does NOT hide behind it -- with two waves per SIMD a matrix slot costs 32.4 + 3.6 x (VALU instructions per MFMA) cycles,
-// however the two kinds are interleaved (alternating single instructions is worse still: 52+).  The input transform B^T d B
-// costs 8 adds per 4 component operands, i.e. 2.0 VALU per MFMA if every N-tile (16 output channels) transforms for itself.
-// Round 3 therefore lets ONE transform feed TWO N-tiles (8 MFMAs per 8 adds) wherever the layer allows it:
-//   * 128 output channels: a wavefront owns an N-tile pair; the accumulators of a pair over all three M-tiles would not fit
-//     beside the held outputs (the layer is in place: outputs wait in registers until every wavefront has read its input), so
-//     the M-tiles run in two rounds {0, 1} and {2}.
-//   * 64 output channels, Cin a multiple of 32: two wavefronts share an N-tile pair and split K; after the barrier that ends
-//     the reads each sends the partial sums of ONE N-tile to its partner through the (now dead) upper half of the buffer and
-//     finishes the other one.
-//   * anything else (layer 0: K = 12 steps does not halve into loop iterations of 4; 32 output channels): one N-tile per
-//     wavefront, M-tiles split over wavefront pairs for 32 channels, as in round 2.
+// work does NOT hide behind it -- with two waves per SIMD a matrix slot costs 32.4 + 3.6 x (VALU instructions per MFMA) cycles
+// (alternating single MFMAs and VALU instructions is worse still: 52+; groups of >= 4 MFMAs are enough).  The input transform
+// B^T d B costs 8 adds per 4 component operands, i.e. 2.0 VALU per MFMA if every N-tile (16 output channels) transforms for itself.
+//   * 128 output channels (52 % of the MFMAs): a wavefront owns an N-tile PAIR and one transform feeds the 8 MFMAs of both
+//     (1.06 VALU per MFMA in the loop).  The layer is in place -- the outputs of a pair (80 registers) wait until every
+//     wavefront has read its input -- so the M-tiles run in three rounds of one tile (32 accumulator registers).
+//   * 64 / 32 output channels: one N-tile per wavefront (M-tiles split over wavefront pairs for 32 channels).  Pairs there
+//     too (two wavefronts per pair, K split, partial sums exchanged through the dead half of the buffer) measured 1 % slower.
+// The filter stream: weights come through a buffer resource with wavefront-uniform offsets (a global_load_dwordx4 with a
+// 64-bit VGPR address costs ~50 cycles of SIMD issue beside MFMAs, an SGPR-based one ~10: tools/micro/mfma_vmem.hip), tiled
+// so that a wavefront's k-steps are contiguous, two k-steps of weights in registers per N-tile.
 // A pass walks K for one row component i of the transform: per (k-step, M-tile) step it reads two window rows (four
 // ds_read_b64), forms the four column components (eight plain adds) and issues 4 MFMAs per N-tile; the accumulators run on
 // through the four passes and after each pass the column transform of the running sum is folded into the 2 x 2 outputs in
@@ -99,6 +98,15 @@ __host__ __device__ constexpr int wg_a1(int I) { return I == 0 ? 0 : 1; }
 __host__ __device__ constexpr int wg_a2(int I) { return I == 3 ? 3 : 2; }
 __host__ __device__ constexpr int wg_te(int I, int T1) { return (I == 3 && T1 == 3) ? 2 : T1; }   // M-tile 2: bottom tile row only, component 3 unused
 
+// Does the pass of row component I (M-tiles [T0, T1)) hand its successor I + 1 the first two LDS steps?  Only where steps 0
+// and 1 have the same (k-step, M-tile) shape in both passes.
+__host__ __device__ constexpr bool wg_chains(int I, int T0, int T1)
+{
+    if (I < 0 || I >= 3) return false;
+    const int nt = wg_te(I, T1) - T0, ntn = wg_te(I + 1, T1) - T0;
+    return nt >= 1 && ntn >= 1 && (1 / nt) == (1 / ntn) && (1 % nt) == (1 % ntn);
+}
+
 // LDS reads of one step.  Two ds_read_b64 per row: the empty asm keeps the compiler from fusing them into the half-rate
 // ds_read2_b64.
 #define WG_LOAD2(DST, A0, A1_, OFS)                                                                       \
@@ -134,21 +142,30 @@ __device__ __forceinline__ wgf4 wg_ldw(__amdgpu_buffer_rsrc_t rs, unsigned unifo
 // offsets ride in the instructions, the weights (W[n][k-step]: one 16-byte load per lane) are reloaded in place half an
 // iteration ahead, and the last iteration fetches the weights of whatever runs next (wp_next) instead of its own.  Every
 // pass reads its own first two steps.  The N-tiles of a pair are neighbours in the weight tiling (256 floats apart).
-template <int I, int NN, int T0, int T1, int WD>
+// PRIMED: the previous pass already fetched this pass's first two steps into D; INEXT >= 0: this pass fetches those of the row
+// component INEXT in its last iteration (the LDS latency of a pass start is then covered by the previous pass's MFMAs).
+// Weights: W[n][k-step & 1], a ring of TWO k-steps per N-tile -- the registers of a k-step are reloaded with the k-step two
+// further on (of this pass, or of whatever runs next: wp_next) as soon as its MFMAs are through, so every load is issued two
+// k-steps before its use with half the registers of a whole-iteration buffer (the paired layers were spilling their outputs).
+template <int I, int NN, int T0, int T1, bool PRIMED, int INEXT>
 __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_next, unsigned lofs, int niter,
-                                        int wstride, wgf4 (&W)[NN][4 * WD], wgf4 (&acc)[NN][3][4])
+                                        int wstride, wgf4 (&W)[NN][2], wgf4 (&acc)[NN][3][4], wgf2 (&D)[2][4])
 {
     constexpr int A1 = wg_a1(I), A2 = wg_a2(I);
     constexpr int TE = wg_te(I, T1);
     constexpr int NT = TE > T0 ? TE - T0 : 1;
     if constexpr (TE <= T0) return;
-    wgf2 D[2][4];                                               // window rows A1 (columns 0-1, 2-3) and A2 of two steps in flight
+    constexpr int A1N = wg_a1(INEXT < 0 ? 0 : INEXT), A2N = wg_a2(INEXT < 0 ? 0 : INEXT);
+    constexpr int NTN = INEXT < 0 ? NT : (wg_te(INEXT, T1) - T0);
+    static_assert(INEXT < 0 || (NTN >= 1 && (1 / NT) == (1 / NTN) && (1 % NT) == (1 % NTN)), "steps 0 and 1 of the chained pass have this pass's shape");
     float V[2][4];
     unsigned P[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; t++) { P[t][0] = RA[T0 + t][A1]; P[t][1] = RA[T0 + t][A2]; }
+    if constexpr (!PRIMED) {
 #pragma unroll
-    for (int g = 0; g < 2; g++) WG_LOAD2(D[g], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+        for (int g = 0; g < 2; g++) WG_LOAD2(D[g], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+    }
     // row component (d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3), then the four column components
 #define WG_XFORM(BUF)                                                                                     \
     {                                                                                                     \
@@ -162,51 +179,42 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
     }
     WG_XFORM(0)
 #pragma unroll 1
-    for (int it0 = 0; it0 < niter; it0 += WD) {
+    for (int it = 0; it < niter; it++) {
+        const bool more = it + 1 < niter;
+        const unsigned wcur = wp + 4 * it * wstride;            // this iteration's k-steps 2, 3 ...
+        const unsigned wn = more ? wcur + 4 * wstride : wp_next;   // ... and the k-steps 0, 1 of the next one (or of the next pass)
+        const unsigned adv = more ? 4u * WG_KSTEP : 0u;         // past the end: the iteration's own first steps again (unused)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int h = 0; h < WD; h++) {
-            const int it = it0 + h;
-            const bool more = it + 1 < niter;
-            // the registers of this iteration's k-steps take the k-steps WD iterations on: of this pass, or of whatever runs next
-            const unsigned wn = it + WD < niter ? wp + 4 * (it + WD) * wstride : wp_next + 4 * (it + WD - niter) * wstride;
-            const unsigned adv = more ? 4u * WG_KSTEP : 0u;     // past the end: the iteration's own first steps again (unused)
+        for (int s = 0; s < 4 * NT; s++) {
+            const int t = T0 + s % NT, kk = s / NT, g = s + 2;
+            if (g < 4 * NT) WG_LOAD2(D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+            else {
+                const int t2 = (g - 4 * NT) % NT;                // the next iteration's base from here on (this one no longer reads through it)
+                if ((g - 4 * NT) / NT == 0) { P[t2][0] += adv; P[t2][1] += adv; }
+                if constexpr (INEXT >= 0) {                      // last iteration: the next pass's first steps instead
+                    unsigned q0 = more ? P[t2][0] : RA[T0 + t2][A1N], q1 = more ? P[t2][1] : RA[T0 + t2][A2N];
+                    WG_LOAD2(D[s & 1], q0, q1, ((g - 4 * NT) / NT) * WG_KSTEP)
+                } else
+                    WG_LOAD2(D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * WG_KSTEP)
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4 * NT; s++) {
-                const int t = T0 + s % NT, kk = s / NT, g = s + 2;
-                if (g < 4 * NT) WG_LOAD2(D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
-                else {
-                    const int t2 = (g - 4 * NT) % NT;            // the next iteration's base from here on (this one no longer reads through it)
-                    if ((g - 4 * NT) / NT == 0) { P[t2][0] += adv; P[t2][1] += adv; }
-                    WG_LOAD2(D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * WG_KSTEP)
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int n = 0; n < NN; n++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][kk & 1][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            WG_XFORM((s + 1) & 1)
+            if (s % NT == NT - 1) {                              // k-step kk is through: its registers take the k-step two further on
 #pragma unroll
                 for (int n = 0; n < NN; n++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][4 * h + kk][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                WG_XFORM((s + 1) & 1)
-                if (s == 2 * NT - 1) {                          // k-steps 0-1 are through
-#pragma unroll
-                    for (int n = 0; n < NN; n++) {
-                        W[n][4 * h + 0] = wg_ldw(rs, wn + n * 256, lofs);
-                        W[n][4 * h + 1] = wg_ldw(rs, wn + n * 256 + wstride, lofs);
-                    }
-                }
-                if (s == 4 * NT - 1) {
-#pragma unroll
-                    for (int n = 0; n < NN; n++) {
-                        W[n][4 * h + 2] = wg_ldw(rs, wn + n * 256 + 2 * wstride, lofs);
-                        W[n][4 * h + 3] = wg_ldw(rs, wn + n * 256 + 3 * wstride, lofs);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    W[n][kk & 1] = kk < 2 ? wg_ldw(rs, wcur + n * 256 + (kk + 2) * wstride, lofs) : wg_ldw(rs, wn + n * 256 + (kk - 2) * wstride, lofs);
             }
-#pragma unroll
-            for (int t = 2; t < NT; t++) { P[t][0] += adv; P[t][1] += adv; }     // the first two M-tiles were advanced by the look-ahead steps
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int t = 2; t < NT; t++) { P[t][0] += adv; P[t][1] += adv; }     // the first two M-tiles were advanced by the look-ahead steps
     }
 #undef WG_XFORM
 }
@@ -219,11 +227,16 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
 // -- three accumulator clears and half of the output-transform adds less per N-tile.  The bias (when this wavefront carries
 // it: K-split layers add it once) enters component (1, 1)'s accumulator before pass 1: F_1, F_2, F_3 then carry it once in
 // both columns.
-template <int NN, int T0, int T1, int WD>
+template <int NN, int T0, int T1>
 __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_after, unsigned lofs, int niter,
-                                         int wstride, unsigned pstride, const wgf4 (&bv)[NN], wgf4 (&W)[NN][4 * WD], wgf4 (&Y)[NN][3][2][2])
+                                         int wstride, unsigned pstride, const float* __restrict__ bias_lane, wgf4 (&W)[NN][2], wgf4 (&Y)[NN][3][2][2])
 {
     using std::integral_constant;
+    wgf2 D[2][4];                                               // window rows A1 (columns 0-1, 2-3) and A2 of two steps in flight
+    // the lane's four biases per N-tile: fetched per round and only alive through pass 0, when no partial output exists yet
+    wgf4 bv[NN];
+#pragma unroll
+    for (int n = 0; n < NN; n++) bv[n] = *reinterpret_cast<const wgf4*>(bias_lane + n * 16);
     wgf4 acc[NN][3][4];
 #pragma unroll
     for (int n = 0; n < NN; n++)
@@ -241,7 +254,8 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
 #pragma unroll
                 for (int t = T0; t < T1; t++) acc[n][t][1] += bv[n];
         }
-        wg_pass<I, NN, T0, T1, WD>(RA, rs, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, lofs, niter, wstride, W, acc);
+        constexpr int ICHAIN = (INEXT != 0 && wg_chains(I, T0, T1)) ? INEXT : -1;      // the next row component of this round, if any
+        wg_pass<I, NN, T0, T1, wg_chains(I - 1, T0, T1), ICHAIN>(RA, rs, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, lofs, niter, wstride, W, acc, D);
 #pragma unroll
         for (int n = 0; n < NN; n++)
 #pragma unroll
@@ -334,7 +348,7 @@ __device__ __forceinline__ void wg_first_weights(__amdgpu_buffer_rsrc_t rs, unsi
 
 // One layer, one N-tile per wavefront (nt), M-tiles [T0, T1): the round-2 form, kept for the layers the paired forms do not
 // take.  The layer is written in place, so the outputs wait in registers until every wavefront has finished reading.
-template <int T0, int T1, bool GLB, int WD>
+template <int T0, int T1, bool GLB>
 __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
                                                 const float* __restrict__ bias, int cin, int cout, int relu, int nt)
 {
@@ -351,11 +365,10 @@ __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* 
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
     const unsigned wp = (unsigned)nt * (16 * cin * 16);                   // [N-tile][i][k-step][lane][j]: a wavefront streams its own block
     const unsigned lofs = lane * 16;
-    wgf4 W[1][4 * WD];                                // WD iterations of weights in registers (two bought nothing here: measured)
-    wg_first_weights<1, 0, 4 * WD>(rs, wp, lofs, wstride, W);
+    wgf4 W[1][2];
+    wg_first_weights<1, 0, 2>(rs, wp, lofs, wstride, W);
     wgf4 Y[1][3][2][2];
-    const wgf4 bv[1] = { *reinterpret_cast<const wgf4*>(bias + nt * 16 + lk * 4) };
-    wg_round<1, T0, T1, WD>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bv, W, Y);
+    wg_round<1, T0, T1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bias + nt * 16 + lk * 4, W, Y);
     WG_SYNC();                                 // every wavefront has finished reading the layer's input
     wg_store<T0, T1, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
 }
@@ -366,8 +379,8 @@ __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* 
 __host__ __device__ constexpr int wg_group(int cin, int cout) { return cout == 128 ? 2 : 1; }
 
 // One layer with 128 output channels: wavefront w owns the N-tile pair 2w, 2w+1 over the whole K, and the transform of a step
-// feeds 8 MFMAs.  The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs: two rounds, M-tiles
-// {0, 1} and {2}.
+// feeds 8 MFMAs.  The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs (80): three rounds of
+// one M-tile each (the weights of the pair are fetched once per round: 3 x 1 KB per k-step and wavefront from L2).
 __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
                                               int cin, int cout, int relu, int pair)
 {
@@ -386,18 +399,17 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
     const unsigned lofs = lane * 16;
     const unsigned pstride = (unsigned)(k4 * wstride);
     wgf4 Y[2][3][2][2];
-    wgf4 bv[2];
-#pragma unroll
-    for (int n = 0; n < 2; n++) bv[n] = *reinterpret_cast<const wgf4*>(bias + (2 * pair + n) * 16 + lk * 4);
-    // (both rounds keep one iteration of weights in registers: a second iteration in the short second round -- 64 registers --
-    // measured 0.5 % slower: it spills)
-    wgf4 W1[2][4];
-    wg_first_weights<2, 0, 4>(rs, wp, lofs, wstride, W1);
-    wg_round<2, 0, 2, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
-    wg_round<2, 2, 3, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    const float* bv = bias + (2 * pair) * 16 + lk * 4;
+    wgf4 W1[2][2];
+    wg_first_weights<2, 0, 2>(rs, wp, lofs, wstride, W1);
+    wg_round<2, 0, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    wg_round<2, 1, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    wg_round<2, 2, 3>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
     WG_SYNC();                                       // every wavefront has finished reading the layer's input
-    wg_store<0, 3, false>(Y[0], 2 * pair, relu, act, nullptr, li, lk);
-    wg_store<0, 3, false>(Y[1], 2 * pair + 1, relu, act, nullptr, li, lk);
+    int lane_s = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane_s));                 // the store offsets are formed here, not kept (spilled) from the layer's start
+    wg_store<0, 3, false>(Y[0], 2 * pair, relu, act, nullptr, lane_s & 15, lane_s >> 4);
+    wg_store<0, 3, false>(Y[1], 2 * pair + 1, relu, act, nullptr, lane_s & 15, lane_s >> 4);
 }
 
 __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __restrict__ x, CylWgParams P, float* __restrict__ y)
@@ -440,14 +452,14 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
         const int cin = P.cin[l], cout = P.cout[l];
         if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (cout == 64) {
-            wg_layer_single<0, 3, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+            wg_layer_single<0, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         } else if (l < WG_LAYERS - 1) {
-            if (w & 1)       wg_layer_single<1, 3, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, false, 1>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer_single<1, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         } else {
             float* glb = y + (size_t)patch * cout * 140;
-            if (w & 1)       wg_layer_single<1, 3, true, 1>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, true, 1>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            if (w & 1)       wg_layer_single<1, 3, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
+            else             wg_layer_single<0, 1, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
         }
         WG_STAMP_AT(2 * l + 1)
         WG_SYNC();
