@@ -70,7 +70,6 @@ _SIGNATURES = {
     "buf_patch_voxelize_ws_bytes": (_sz, [_i]),
     "buf_patch_voxelize": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _sz, _vp]),
-    "buf_cylindrical_net": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_cylindrical_net_wg": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_winograd_tile_weights": (_i, [_vp, _i, _i, _vp]),
     "buf_winograd_group": (_i, [_i, _i]),

@@ -522,17 +522,15 @@ def winograd_tile_weights(w):
 
 
 class CylindricalNet:
-    """Device weights of Cylindrical_Net re-laid for csrc/convnet.hip: per layer Wt[(ky*3+kx)*Cin + c][Cout], MFMA-tiled
-    (winograd=True: the Winograd-domain tiling of csrc/convnet_wg.hip)."""
+    """Device weights of Cylindrical_Net for csrc/convnet_wg.hip: per layer U = G g G^T in the kernel's tiling, biases."""
 
-    def __init__(self, layers, device, winograd=False):
+    def __init__(self, layers, device):
         """layers: list of 8 (w [Cout,Cin,3,3] np.float32 with BN folded, b [Cout], relu)"""
         self.wt, self.bias, self.cin, self.cout, self.relu = [], [], [], [], []
-        self.entry = "buf_cylindrical_net_wg" if winograd else "buf_cylindrical_net"
+        self.entry = "buf_cylindrical_net_wg"
         for w, b, relu in layers:
             cout, cin = w.shape[0], w.shape[1]
-            wt = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)).reshape(9 * cin, cout), dtype=np.float32)
-            self.wt.append(torch.from_numpy(winograd_tile_weights(w) if winograd else mfma_tile_weights(wt)).to(device))
+            self.wt.append(torch.from_numpy(winograd_tile_weights(w)).to(device))
             self.bias.append(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(device))
             self.cin.append(cin); self.cout.append(cout); self.relu.append(1 if relu else 0)
         n = len(layers)
@@ -548,7 +546,7 @@ class CylindricalNet:
         x = x.contiguous()
         P = x.shape[0]
         y = torch.empty((P, self.cout[-1], 7, 20), dtype=torch.float32, device=x.device)
-        check(getattr(L, self.entry)(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(y), _stream()), self.entry)
+        check(L.buf_cylindrical_net_wg(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(y), _stream()), self.entry)
         return y
 
 

@@ -58,7 +58,7 @@ class PatchEmbedder:
             layers.append((w, b, True))
         layers.append((np.asarray(W[f'{p}.21.weight'], np.float32), np.asarray(W[f'{p}.21.bias'], np.float32), False))
         self.layers = layers
-        self.fused = ops.CylindricalNet(layers, device, winograd=True)
+        self.fused = ops.CylindricalNet(layers, device)
         q = 'Desc.pool_layer'
         w0, b0 = _fold_bn(W[f'{q}.0.weight'], W[f'{q}.0.bias'], W[f'{q}.1.running_mean'], W[f'{q}.1.running_var'],
                           W[f'{q}.1.weight'], W[f'{q}.1.bias'])

@@ -237,20 +237,11 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
                            const float* bn_shift_host, float* out_x, float* out_R, float* out_rand, float* out_patches,
                            void* ws, size_t ws_bytes, void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * A11 (dense)  Cylindrical_Net (models/patchnet.py:15-85) fused: Conv3d(16->64,3^3) + 7 x Conv2d 3x3 with the
- * reference's circular-azimuth / zero-elevation padding, BN folded, ReLU, on fp32 MFMA; activations stay in LDS.
- * x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140] (= [np,32,7,20]).
- * wt_host[l] / bias_host[l]: HOST arrays of 8 DEVICE pointers: weights W[9*Cin][Cout] with
- * k = (ky*3+kx)*Cin + c (layer 0: c = c16*3 + depth) in the MFMA B-operand tiling (blocks [K/16][Cout/16] of 256
- * floats, block (g, n) = [lk][li][p] = W[16g + 4p + lk][16n + li]; ops.mfma_tile_weights), biases [Cout]; widths in
- * cin_host/cout_host. */
-int     buf_cylindrical_net(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
-                            const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
-
-/* A11 (dense), the form the pipeline runs: the same stack evaluated in the Winograd F(2x2,3x3) domain, all fp32
+/* A11 (dense)  Cylindrical_Net (models/patchnet.py:15-85): Conv3d(16->64, 3x3x3) + 7 x Conv2d 3x3, BatchNorms folded, circular
+ * azimuth / zero elevation padding (utils/common.py:265-310), as ONE kernel in the Winograd F(2x2,3x3) domain, all fp32
  * (csrc/convnet_wg.hip: 44 instead of 75 matrix instructions per 4 input x 16 output channels; a different fp32 summation
- * order, within 1e-6 of the output scale of the direct form).  Same x / y as buf_cylindrical_net.
+ * order, within 1e-6 of the output scale of a direct-form evaluation: tests/native/convnet_direct.hip is that cross-check).
+ * x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140] (= [np,32,7,20]); bias_host[l]: DEVICE pointers to [Cout].
  * wt_host[l]: DEVICE pointers to U = G g G^T of the BN-folded filters ([Cout,Cin,3,3]; layer 0: Cin = c16*3 + depth) in the
  * tiling [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk] with NG = buf_winograd_group(Cin, Cout)
  * N-tiles per group (the N-tiles one wavefront owns: its k-steps are contiguous in memory), as buf_winograd_tile_weights lays

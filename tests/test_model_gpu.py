@@ -137,7 +137,7 @@ def test_ransac_recovers_planted_pose(dev):
 
 
 def test_fused_cylindrical_net_vs_library_convs(W, dev):
-    """csrc/convnet.hip (fp32 MFMA, padding folded into addressing) == torch convolutions with explicit padding."""
+    """csrc/convnet_wg.hip (fp32 MFMA in the Winograd domain, padding in the LDS layout) == torch convolutions with explicit padding."""
     from buffer_amd.config import THREEDMATCH
     from buffer_amd.patch_embedder import PatchEmbedder
     pe = PatchEmbedder(W, dev, THREEDMATCH)
@@ -150,7 +150,7 @@ def test_fused_cylindrical_net_vs_library_convs(W, dev):
 
 
 def test_winograd_and_direct_forms_against_float64(W, dev):
-    """csrc/convnet_wg.hip (Winograd F(2x2,3x3), the product's form) and csrc/convnet.hip (direct form) against the stack in
+    """csrc/convnet_wg.hip (Winograd F(2x2,3x3), the product's kernel) and tests/native/convnet_direct.hip (direct form) against the stack in
     float64: both stay within 1e-5 of the output scale on the released weights, on non-negative (post-ReLU-like) and on signed
     inputs, and agree with each other; a patch's result does not depend on its position in the batch."""
     from buffer_amd import ops
@@ -158,7 +158,8 @@ def test_winograd_and_direct_forms_against_float64(W, dev):
     from buffer_amd.patch_embedder import PatchEmbedder
     pe = PatchEmbedder(W, dev, THREEDMATCH)
     assert pe.fused.entry == "buf_cylindrical_net_wg"
-    direct = ops.CylindricalNet(pe.layers, dev)
+    from util import DirectCylindricalNet
+    direct = DirectCylindricalNet(pe.layers, dev)                       # tests/native: the round-1/2 kernel, test infrastructure now
     g = torch.Generator(device='cpu').manual_seed(5)
     for signed in (False, True):
         x = torch.rand((70, 16, 420), generator=g)

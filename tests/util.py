@@ -35,3 +35,39 @@ def assert_neighbors_equal_mod_ties(ours, ref, q, s):
             real = ours[r][ours[r] < len(s)]
             assert len(np.unique(real)) == len(real)
     return int(diff.any(1).sum())
+
+
+class DirectCylindricalNet:
+    """TEST INFRASTRUCTURE: the direct-form Cylindrical_Net kernel (tests/native/convnet_direct.hip, its own library) as the
+    k-ordered fp32 cross-check of the product's Winograd-domain kernel.  layers: as ops.CylindricalNet."""
+
+    def __init__(self, layers, device):
+        import ctypes as C
+        import torch
+        from buffer_amd import ops
+        from tests.native import build as native_build
+        self._C, self._torch = C, torch
+        self.lib = C.CDLL(native_build.build())
+        self.lib.buf_last_error.restype = C.c_char_p
+        self.wt, self.bias, cin, cout, relu = [], [], [], [], []
+        for w, b, r in layers:
+            co, ci = w.shape[0], w.shape[1]
+            wt = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)).reshape(9 * ci, co), dtype=np.float32)   # [(ky*3+kx)*Cin + c][Cout]
+            self.wt.append(torch.from_numpy(ops.mfma_tile_weights(wt)).to(device))
+            self.bias.append(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(device))
+            cin.append(ci); cout.append(co); relu.append(1 if r else 0)
+        n = len(layers)
+        self._wp = (C.c_void_p * n)(*[t.data_ptr() for t in self.wt])
+        self._bp = (C.c_void_p * n)(*[t.data_ptr() for t in self.bias])
+        self._ci, self._co, self._re = (C.c_int * n)(*cin), (C.c_int * n)(*cout), (C.c_int * n)(*relu)
+        self.cout = cout
+
+    def __call__(self, x):
+        C, torch = self._C, self._torch
+        x = x.contiguous()
+        P = x.shape[0]
+        y = torch.empty((P, self.cout[-1], 7, 20), dtype=torch.float32, device=x.device)
+        rc = self.lib.buf_test_cylindrical_net_direct(C.c_void_p(x.data_ptr()), P, self._wp, self._bp, self._ci, self._co, self._re,
+                                                      C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, self.lib.buf_last_error()
+        return y

@@ -1,5 +1,5 @@
 """Development probe: the Winograd-form Cylindrical_Net kernel (csrc/convnet_wg.hip) against the direct-form one
-(csrc/convnet.hip): accuracy vs the stack in float64, speed.   python tools/wg_probe.py [patches]"""
+(tests/native/convnet_direct.hip, test infrastructure): accuracy vs the stack in float64, speed.   python tools/wg_probe.py [patches]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +12,11 @@ dev = torch.device('cuda:0')
 W = load_weights('3dmatch')
 pe = PatchEmbedder(W, dev, THREEDMATCH)
 layers = pe.layers
-direct = ops.CylindricalNet(layers, dev)
-wino = ops.CylindricalNet(layers, dev, winograd=True)
+wino = ops.CylindricalNet(layers, dev)
+if not os.environ.get('WG_ONLY'):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    from util import DirectCylindricalNet
+    direct = DirectCylindricalNet(layers, dev)
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 names = [('winograd', wino)] if os.environ.get('WG_ONLY') else [('direct', direct), ('winograd', wino)]
 g = torch.Generator(device='cpu').manual_seed(0)
