@@ -477,9 +477,12 @@ __global__ void __launch_bounds__(SPB_WAVES * WAVE) k_select_patches_grid(const 
                                                                       float r2, int nsample, int mask_words, float* __restrict__ patches)
 {
     extern __shared__ unsigned long long spb_mask[];             // [SPB_WAVES][mask_words]
-    const int c = blockIdx.y;
+    // XCD-contiguous block order (common.h): the keypoints of one cloud go to ONE XCD, whose L2 then holds that cloud's
+    // cell-ordered points (every keypoint tests ~2000 of them) instead of all eight L2s fetching every cloud
+    const int lb = xcd_contiguous_block(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int c = lb / (int)gridDim.x;
     const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-    const int q = blockIdx.x * SPB_WAVES + w;
+    const int q = (lb - c * (int)gridDim.x) * SPB_WAVES + w;
     if (q >= m) return;
     const int lo = s_off[c], n = s_off[c + 1] - lo;              // scalar loads: the cloud's rows in the stacked array
     const float* P = pts + 3 * (size_t)lo;
@@ -732,9 +735,13 @@ __global__ void __launch_bounds__(256) k_nn1(const float* __restrict__ ref, cons
 {
     __shared__ float4 tile[NN1_SPLIT * (D / 4)];
     __shared__ unsigned long long red[4][WAVE];
-    const int b = blockIdx.z, lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    const int q = blockIdx.x * WAVE + lane;
-    const int base = blockIdx.y * NN1_SPLIT;
+    // XCD-contiguous block order: the blocks of one batch element (a cloud pair's descriptors, 640 KB) share an L2
+    const int gxy = gridDim.x * gridDim.y;
+    const int lb = xcd_contiguous_block((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gxy * gridDim.z);
+    const int b = lb / gxy, by = (lb - b * gxy) / (int)gridDim.x, bx = lb - b * gxy - by * (int)gridDim.x;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int q = bx * WAVE + lane;
+    const int base = by * NN1_SPLIT;
     const int cnt = min(NN1_SPLIT, n - base);
     const float4* R4 = reinterpret_cast<const float4*>(ref + ((size_t)b * n + base) * D);
     for (int t = threadIdx.x; t < cnt * (D / 4); t += 256) tile[t] = R4[t];
