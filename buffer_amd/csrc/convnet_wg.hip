@@ -236,7 +236,7 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
     // the lane's four biases per N-tile: fetched per round and only alive through pass 0, when no partial output exists yet
     wgf4 bv[NN];
 #pragma unroll
-    for (int n = 0; n < NN; n++) bv[n] = *reinterpret_cast<const wgf4*>(bias_lane + n * 16);
+    for (int n = 0; n < NN; n++) bv[n] = bias_lane ? *reinterpret_cast<const wgf4*>(bias_lane + n * 16) : (wgf4){ 0.f, 0.f, 0.f, 0.f };
     wgf4 acc[NN][3][4];
 #pragma unroll
     for (int n = 0; n < NN; n++)
@@ -373,6 +373,43 @@ __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* 
     wg_store<T0, T1, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
 }
 
+// One layer with 32 output channels (two N-tiles, four wavefronts): wavefront w owns N-tile w & 1 over ALL three M-tiles and the
+// K half w >> 1; the upper half hands its partial sums (40 registers) to the lower one through the rows of the channels >= 64
+// (free: Cin <= 64), which adds them and stores.  Round 2 split the M-tiles {0} | {1, 2} over the wavefront pair instead: 16 against
+// 28 tile-components, i.e. the layer took 28 / 22 of its balanced time -- these two layers are 6.5 % of the MFMAs and were 11 % of
+// the kernel.  The bias rides in the lower half's accumulators.
+#define WG_XCH_C 64
+template <bool GLB>
+__device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
+                                                const float* __restrict__ bias, int cin, int cout, int relu, int w)
+{
+    int lane = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    const int nt = w & 1, half = w >> 1;
+    const int k4 = cin >> 2, kn = k4 >> 1, k0 = half * kn, wstride = 256;
+    unsigned RA[3][4];
+    wg_addresses(act, k0, li, lk, RA);
+    const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
+    const unsigned wp = (unsigned)nt * (16 * cin * 16) + (unsigned)k0 * wstride;
+    const unsigned lofs = lane * 16;
+    wgf4 W[1][2];
+    wg_first_weights<1, 0, 2>(rs, wp, lofs, wstride, W);
+    wgf4 Y[1][3][2][2];
+    wg_round<1, 0, 3>(RA, rs, wp, wp, lofs, kn >> 2, wstride, (unsigned)(k4 * wstride), half ? nullptr : bias + nt * 16 + lk * 4, W, Y);
+    wgf4* slot = reinterpret_cast<wgf4*>(act + WG_XCH_C * WG_CS) + nt * 640 + lane;                  // 10 x 64 float4 per N-tile
+    if (half) {
+#pragma unroll
+        for (int q = 0; q < 10; q++) slot[q * 64] = Y[0][q >> 2][(q >> 1) & 1][q & 1];              // t = q / 4, u, column; t = 2 has u = 0 only
+    }
+    WG_SYNC();                                       // partial sums are in place AND every wavefront has finished reading the input
+    if (!half) {
+#pragma unroll
+        for (int q = 0; q < 10; q++) Y[0][q >> 2][(q >> 1) & 1][q & 1] += slot[q * 64];
+        wg_store<0, 3, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
+    }
+}
+
 // N-tiles per wavefront of a layer: 2 (the paired form below) or 1.  The filter tiling follows it (buf_winograd_tile_weights).
 // Pairs for the 64-channel layers too (two wavefronts per pair, K split between them, partial sums exchanged through the dead
 // half of the buffer) measured 1 % slower, before and after the filter stream became cheap: short K loops, a third barrier.
@@ -453,14 +490,8 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
         if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (cout == 64) {
             wg_layer_single<0, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-        } else if (l < WG_LAYERS - 1) {
-            if (w & 1)       wg_layer_single<1, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-        } else {
-            float* glb = y + (size_t)patch * cout * 140;
-            if (w & 1)       wg_layer_single<1, 3, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-            else             wg_layer_single<0, 1, true>(act, glb, P.wt[l], P.bias[l], cin, cout, P.relu[l], w >> 1);
-        }
+        } else if (l < WG_LAYERS - 1) wg_layer_ksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        else wg_layer_ksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         WG_STAMP_AT(2 * l + 1)
         WG_SYNC();
         WG_STAMP_AT(2 * l + 2)
@@ -514,6 +545,8 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
                     BUF_EINVAL, "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d", l, P.cin[l], P.cout[l]);
         BUF_REQUIRE(P.cout[l] != 128 || P.cin[l] % 32 == 0, BUF_EINVAL,
                     "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (128 output channels need Cin %% 32 == 0)", l, P.cin[l], P.cout[l]);
+        BUF_REQUIRE(P.cout[l] != 32 || (P.cin[l] % 32 == 0 && P.cin[l] <= 64), BUF_EINVAL,
+                    "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (32 output channels need Cin = 32 or 64)", l, P.cin[l], P.cout[l]);
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net_wg: layer %d width mismatch", l);
     }
     BUF_REQUIRE(P.cout[WG_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_wg: the last layer must have 32 channels");
