@@ -65,9 +65,12 @@ struct CylWgParams {
 #endif
 };
 #ifdef WG_STAMP
+__device__ long long* wg_stamp_ptr;
+#define WG_STAMP_IN(SLOT) if ((threadIdx.x & 63) == 0) wg_stamp_ptr[((size_t)blockIdx.x * 4 + threadIdx.x / 64) * 20 + (SLOT)] = __builtin_amdgcn_s_memtime();
 #define WG_STAMP_AT(SLOT) if ((threadIdx.x & 63) == 0) P.stamps[((size_t)blockIdx.x * 4 + w) * 20 + (SLOT)] = __builtin_amdgcn_s_memtime();
 #else
 #define WG_STAMP_AT(SLOT)
+#define WG_STAMP_IN(SLOT)
 #endif
 
 // tile (ty, tx) held by row idx of M-tile t (branch-free)
@@ -402,7 +405,9 @@ __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* 
 #pragma unroll
         for (int q = 0; q < 10; q++) slot[q * 64] = Y[0][q >> 2][(q >> 1) & 1][q & 1];              // t = q / 4, u, column; t = 2 has u = 0 only
     }
+    WG_STAMP_IN(18)
     WG_SYNC();                                       // partial sums are in place AND every wavefront has finished reading the input
+    WG_STAMP_IN(19)
     if (!half) {
 #pragma unroll
         for (int q = 0; q < 10; q++) Y[0][q >> 2][(q >> 1) & 1][q & 1] += slot[q * 64];
@@ -559,6 +564,7 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
     bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * 140 * macs * npatch, BUF_TIMED_CYL_NET);
 #ifdef WG_STAMP
     BUF_CHECK_HIP(hipMalloc(&P.stamps, (size_t)npatch * 4 * 20 * sizeof(long long)));
+    BUF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(wg_stamp_ptr), &P.stamps, sizeof(P.stamps)));
 #endif
     k_cyl_net_wg<<<npatch, WG_THREADS, lds, (hipStream_t)stream>>>(x, P, y);
     if (timed) timing_end((hipStream_t)stream, &span);
@@ -576,6 +582,14 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
                 if (w == 0) { tot += (double)(q[2 * WG_LAYERS] - q[0]); pre += (double)(q[0] - q[17]); }
             }
         if (n && npatch >= 1024) {
+            double c7[4] = {}, b7[4] = {}, s7[4] = {};
+            for (int b = npatch / 2; b < npatch; b++)
+                for (int w = 0; w < 4; w++) {
+                    const long long* q = h + ((size_t)b * 4 + w) * 20;
+                    c7[w] += (double)(q[18] - q[14]); b7[w] += (double)(q[19] - q[18]); s7[w] += (double)(q[15] - q[19]);
+                }
+            fprintf(stderr, "  last layer per wave: K loops %6.0f %6.0f %6.0f %6.0f | barrier %5.0f %5.0f %5.0f %5.0f | add + store %5.0f %5.0f %5.0f %5.0f\n",
+                    c7[0] / n, c7[1] / n, c7[2] / n, c7[3] / n, b7[0] / n, b7[1] / n, b7[2] / n, b7[3] / n, s7[0] / n, s7[1] / n, s7[2] / n, s7[3] / n);
             fprintf(stderr, "WG_STAMP: %ld workgroups, layers total %.0f cycles per patch, input phase %.0f\n", n, tot / n, pre / n);
             for (int l = 0; l < WG_LAYERS; l++) {
                 const double mf = 44.0 * (P.cin[l] / 4) * (P.cout[l] / 16) / 4;     // MFMAs per wave
