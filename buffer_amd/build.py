@@ -28,6 +28,9 @@ def build(force=False, verbose=False, out=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+           # MFMA accumulators stay VGPRs: k_cyl_net_wg parks held outputs in AGPRs by hand (no scratch); with AGPR-form
+           # accumulators the compiler rotates them through v_accvgpr copies inside the pass-0 loops (+3 % on that kernel)
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1",
            "-o", out, SRC] + os.environ.get("BUF_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -241,12 +241,16 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
 #pragma unroll
     for (int n = 0; n < NN; n++) bv[n] = bias_lane ? *reinterpret_cast<const wgf4*>(bias_lane + n * 16) : (wgf4){ 0.f, 0.f, 0.f, 0.f };
     wgf4 acc[NN][3][4];
+    // (an opaque zero: folded into the first MFMA as the constant C = 0, the accumulators -- accumulation registers since the
+    // paired layers park their outputs there -- become loop-carried copies: 36-68 v_accvgpr moves per iteration of every pass 0)
+    float zero = 0.f;
+    asm volatile("" : "+v"(zero));
 #pragma unroll
     for (int n = 0; n < NN; n++)
 #pragma unroll
         for (int t = T0; t < T1; t++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[n][t][j] = (wgf4){ 0.f, 0.f, 0.f, 0.f };
+            for (int j = 0; j < 4; j++) acc[n][t][j] = (wgf4){ zero, zero, zero, zero };
     auto run = [&](auto ic) __attribute__((always_inline)) {
         constexpr int I = decltype(ic)::value;
         // component 3 does nothing for a round that only has M-tile 2: the pass before it hands over to whatever runs next
@@ -420,6 +424,17 @@ __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* 
 // half of the buffer) measured 1 % slower, before and after the filter stream became cheap: short K loops, a third barrier.
 __host__ __device__ constexpr int wg_group(int cin, int cout) { return cout == 128 ? 2 : 1; }
 
+// Outputs of M-tile T of both N-tiles of a pair -> accumulation registers (see wg_layer_pair)
+template <int T>
+__device__ __forceinline__ void wg_park(const wgf4 (&Y)[2][3][2][2], float (&park)[2][3][16])
+{
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int q = 0; q < (T == 2 ? 8 : 16); q++)
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(park[n][T][q]) : "v"(Y[n][T][q >> 3][(q >> 2) & 1][q & 3]));
+}
+
 // One layer with 128 output channels: wavefront w owns the N-tile pair 2w, 2w+1 over the whole K, and the transform of a step
 // feeds 8 MFMAs.  The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs (80): three rounds of
 // one M-tile each (the weights of the pair are fetched once per round: 3 x 1 KB per k-step and wavefront from L2).
@@ -444,14 +459,28 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
     const float* bv = bias + (2 * pair) * 16 + lk * 4;
     wgf4 W1[2][2];
     wg_first_weights<2, 0, 2>(rs, wp, lofs, wstride, W1);
+    // The outputs of a finished round wait for the in-place barrier in ACCUMULATION registers (v_accvgpr_write / _read: the unified
+    // file gives a wavefront 256 registers of either kind): left in VGPRs the compiler parked 19 of the 20 quads in scratch memory
+    // (264 KB of HBM traffic per patch); the rounds then run in ~130 VGPRs with no scratch at all.
+    float park[2][3][16];
     wg_round<2, 0, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    wg_park<0>(Y, park);
     wg_round<2, 1, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    wg_park<1>(Y, park);
     wg_round<2, 2, 3>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    wg_park<2>(Y, park);
     WG_SYNC();                                       // every wavefront has finished reading the layer's input
     int lane_s = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane_s));                 // the store offsets are formed here, not kept (spilled) from the layer's start
-    wg_store<0, 3, false>(Y[0], 2 * pair, relu, act, nullptr, lane_s & 15, lane_s >> 4);
-    wg_store<0, 3, false>(Y[1], 2 * pair + 1, relu, act, nullptr, lane_s & 15, lane_s >> 4);
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int q = 0; q < (t == 2 ? 8 : 16); q++)
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(Y[n][t][q >> 3][(q >> 2) & 1][q & 3]) : "a"(park[n][t][q]));
+        wg_store<0, 3, false>(Y[n], 2 * pair + n, relu, act, nullptr, lane_s & 15, lane_s >> 4);
+    }
 }
 
 __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __restrict__ x, CylWgParams P, float* __restrict__ y)
@@ -461,6 +490,9 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
     const int patch = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WG_STAMP_AT(17)
+#ifdef WG_STAMP
+    if (threadIdx.x == 0) { P.stamps[(size_t)gridDim.x * 80 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime(); P.stamps[(size_t)gridDim.x * 80 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     {   // input [48][140] -> rows of 22 with the halo columns.  A row is five float4: every load of the patch is issued before the
         // first LDS store (one load at a time, each behind the previous one's stores, took 40 k cycles per patch: 5 % of the kernel)
         const wgf4* src = reinterpret_cast<const wgf4*>(x + (size_t)patch * P.cin[0] * 140);
@@ -501,6 +533,9 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
         WG_SYNC();
         WG_STAMP_AT(2 * l + 2)
     }
+#ifdef WG_STAMP
+    if (threadIdx.x == 0) { P.stamps[(size_t)gridDim.x * 80 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime(); P.stamps[(size_t)gridDim.x * 80 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 
@@ -563,7 +598,7 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
     TimedSpan span;
     bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * 140 * macs * npatch, BUF_TIMED_CYL_NET);
 #ifdef WG_STAMP
-    BUF_CHECK_HIP(hipMalloc(&P.stamps, (size_t)npatch * 4 * 20 * sizeof(long long)));
+    BUF_CHECK_HIP(hipMalloc(&P.stamps, (size_t)npatch * (4 * 20 + 4) * sizeof(long long)));
     BUF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(wg_stamp_ptr), &P.stamps, sizeof(P.stamps)));
 #endif
     k_cyl_net_wg<<<npatch, WG_THREADS, lds, (hipStream_t)stream>>>(x, P, y);
@@ -572,8 +607,8 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
 #ifdef WG_STAMP
     {   // per-layer wave cycles (to the wave's arrival at the closing barrier | wait there), second half of the workgroups
         BUF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-        long long* h = (long long*)malloc((size_t)npatch * 4 * 20 * sizeof(long long));
-        BUF_CHECK_HIP(hipMemcpy(h, P.stamps, (size_t)npatch * 4 * 20 * sizeof(long long), hipMemcpyDeviceToHost));
+        long long* h = (long long*)malloc((size_t)npatch * (4 * 20 + 4) * sizeof(long long));
+        BUF_CHECK_HIP(hipMemcpy(h, P.stamps, (size_t)npatch * (4 * 20 + 4) * sizeof(long long), hipMemcpyDeviceToHost));
         double comp[WG_LAYERS][4] = {}, wait[WG_LAYERS][4] = {}, tot = 0, pre = 0; long n = 0;
         for (int b = npatch / 2; b < npatch; b++, n++)
             for (int w = 0; w < 4; w++) {
@@ -582,6 +617,9 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
                 if (w == 0) { tot += (double)(q[2 * WG_LAYERS] - q[0]); pre += (double)(q[0] - q[17]); }
             }
         if (n && npatch >= 1024) {
+            double dc = 0, dr = 0;
+            for (int b = npatch / 2; b < npatch; b++) { const long long* q = h + (size_t)npatch * 80 + (size_t)b * 4; dc += (double)(q[2] - q[0]); dr += (double)(q[3] - q[1]); }
+            fprintf(stderr, "  WG_STAMP in-kernel clock: %.0f shader cycles per workgroup over %.0f ticks of the 100 MHz counter -> %.3f GHz\n", dc / n, dr / n, dc / dr * 0.1);
             double c7[4] = {}, b7[4] = {}, s7[4] = {};
             for (int b = npatch / 2; b < npatch; b++)
                 for (int w = 0; w < 4; w++) {
