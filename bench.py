@@ -37,9 +37,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 COST_NET_DENSE_FLOPS_PER_MATCH = 159994880.0      # 0.160 GFLOP/match, every layer as a dense convolution
 COST_NET_FLOPS_PER_MATCH = 109085696.0            # executed by csrc/costnet.hip: layer 0 separated into its S- and T-terms
-CYL_NET_EXECUTED_FRACTION = 44 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs the stack in the Winograd F(2x2,3x3) domain:
-#                                          44 MFMAs of 16x16x4 per (4 input channels, 16 output channels) instead of the
-#                                          9 x 140 x 4 x 16 MACs of the direct form = 0.559 of the dense count
+CYL_NET_EXECUTED_FRACTION = 40 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs the stack in the Winograd F(2x2,3x3) domain:
+#                                          40 MFMAs of 16x16x4 per (4 input channels, 16 output channels) instead of the
+#                                          9 x 140 x 4 x 16 MACs of the direct form = 0.508 of the dense count
 
 # library timing ids (include/buffer_hip.h BUF_TIMED_*)
 TIMED = {'grid_query': 0, 'cyl_net': 1, 'cost_net': 2, 'select_patches': 3, 'patch_voxelize': 4, 'fps': 5, 'nn1': 6,
@@ -147,14 +147,14 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
                       executed_fraction_of_dense=CYL_NET_EXECUTED_FRACTION)
     if main:
         # What the hardware did: the kernel evaluates the reference's convolutions in the Winograd F(2x2,3x3) domain in fp32 and
-        # EXECUTES 0.559 of their dense count on the matrix pipe.  achieved / frac = executed flops (matrix-pipe utilisation);
+        # EXECUTES 0.508 of their dense count on the matrix pipe.  achieved / frac = executed flops (matrix-pipe utilisation);
         # the dense algorithmic count of SURVEY 8d (0.1187 GFLOP/patch) over the same time is reported beside it.
         dense = main['achieved']
         main['dense_equivalent_tflops'] = dense
         main['achieved'] = dense * CYL_NET_EXECUTED_FRACTION
         main['frac'] = main['achieved'] / MFMA_F32_PEAK_TFLOPS
         main['avg_executed_flops'] = main['avg_algorithmic_flops'] * CYL_NET_EXECUTED_FRACTION
-        main['flops'] = ('achieved = flops EXECUTED on the matrix pipe (44 v_mfma_f32_16x16x4_f32 per 4 input x 16 output channels = 0.559 '
+        main['flops'] = ('achieved = flops EXECUTED on the matrix pipe (40 v_mfma_f32_16x16x4_f32 per 4 input x 16 output channels = 0.508 '
                          'of the dense count) / HIP-event time on the launch stream; dense_equivalent_* = the algorithmic count of the '
                          'reference convolutions (SURVEY 8d: 0.1187 GFLOP/patch) over the same time')
         main['traffic_source'] = ('replayed: HBM bytes per patch of profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '

@@ -5,10 +5,11 @@
 // into 48 input channels), circular in azimuth and zero-padded in elevation (utils/common.py:265-310).  With the map cut
 // into 4 x 10 tiles of 2 x 2 outputs,
 //     Y = A^T [ sum_c (G g G^T)[c] (.) (B^T d[c] B) ] A          (d: the tile's 4 x 4 input window)
-// turns the 9-tap implicit GEMM (9 x 144 rows per channel pair) into 16 component GEMMs over 40 tile rows (16 x 48): 44/75
-// of the matrix instructions of the direct form (the fourth row component of the bottom tile row only feeds the discarded
-// output row 7 and is skipped for the M-tile that holds nothing else).  All arithmetic stays fp32 (v_mfma_f32_16x16x4_f32);
-// the filter transform is done once on the host in fp64.
+// turns the 9-tap implicit GEMM (9 x 144 rows per channel pair) into 16 component GEMMs over tile rows.  The bottom tile row
+// (output row 6; row 7 does not exist and window rows 7, 8 are padding) is the plain two-tap form in elevation for the M-tile
+// that holds nothing else: 8 components (wg_round_bottom).  16 + 16 + 8 = 40 matrix instructions per (4 input, 16 output
+// channels) against 75 of the direct form.  All arithmetic stays fp32 (v_mfma_f32_16x16x4_f32); the filter transform is done
+// once on the host in fp64.
 //
 // One workgroup owns one patch for the whole stack.  Activations live in ONE LDS buffer [128][160] (rows of 22 = 20 azimuth
 // columns + the two circular halo columns, so a window row is one address + immediate offsets; 4 zeros per channel serve
@@ -46,6 +47,7 @@
 #define WG_THREADS 256
 #define WG_BUF (WG_MAXC * WG_CS)
 #define WG_KSTEP (16 * WG_CS)  // bytes between k-steps (4 channels)
+#define WG_BLOCKS 20          // filter components per (input, output) channel: 16 Winograd + 4 of the bottom-row form
 #ifdef WG_EXP_NOBAR
 #define WG_SYNC() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -124,6 +126,19 @@ __host__ __device__ constexpr bool wg_chains(int I, int T0, int T1)
         asm volatile("" : "+v"(A1_));                                                                     \
     }
 
+// one window row only (the bottom-row form)
+#define WG_LOAD1(DST, A0, OFS)                                                                            \
+    {                                                                                                     \
+        DST[0] = *(wg_lds_f2)(size_t)((A0) + (OFS));                                                      \
+        asm volatile("" : "+v"(A0));                                                                      \
+        DST[1] = *(wg_lds_f2)(size_t)((A0) + (OFS) + 8);                                                  \
+        asm volatile("" : "+v"(A0));                                                                      \
+    }
+#define WG_LOAD(BOT_, DST, A0, A1_, OFS)                                                                  \
+    {                                                                                                     \
+        if constexpr (BOT_) WG_LOAD1(DST, A0, OFS) else WG_LOAD2(DST, A0, A1_, OFS)                       \
+    }
+
 // A lane's 16 bytes of a weight block through a buffer resource: wavefront-uniform byte offset (SGPR) + the lane's 32-bit offset.
 // The form matters: global_load_dwordx4 with a 64-bit VGPR address costs ~50 cycles of the SIMD's issue beside MFMAs, an
 // SGPR-based address ~10 (tools/micro/mfma_vmem.hip) -- with per-lane pointers the filter stream took 8 % of the kernel.
@@ -150,16 +165,16 @@ __device__ __forceinline__ wgf4 wg_ldw(__amdgpu_buffer_rsrc_t rs, unsigned unifo
 // Weights: W[n][k-step & 1], a ring of TWO k-steps per N-tile -- the registers of a k-step are reloaded with the k-step two
 // further on (of this pass, or of whatever runs next: wp_next) as soon as its MFMAs are through, so every load is issued two
 // k-steps before its use with half the registers of a whole-iteration buffer (the paired layers were spilling their outputs).
-template <int I, int NN, int T0, int T1, bool PRIMED, int INEXT>
+template <int I, int NN, int T0, int T1, bool PRIMED, int INEXT, bool BOT = false>
 __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_next, unsigned lofs, int niter,
                                         int wstride, wgf4 (&W)[NN][2], wgf4 (&acc)[NN][3][4], wgf2 (&D)[2][4])
 {
-    constexpr int A1 = wg_a1(I), A2 = wg_a2(I);
-    constexpr int TE = wg_te(I, T1);
+    constexpr int A1 = BOT ? I : wg_a1(I), A2 = BOT ? I : wg_a2(I);      // bottom-row form: I is the filter row = window row, no second row
+    constexpr int TE = BOT ? T1 : wg_te(I, T1);
     constexpr int NT = TE > T0 ? TE - T0 : 1;
     if constexpr (TE <= T0) return;
-    constexpr int A1N = wg_a1(INEXT < 0 ? 0 : INEXT), A2N = wg_a2(INEXT < 0 ? 0 : INEXT);
-    constexpr int NTN = INEXT < 0 ? NT : (wg_te(INEXT, T1) - T0);
+    constexpr int A1N = BOT ? (INEXT < 0 ? 0 : INEXT) : wg_a1(INEXT < 0 ? 0 : INEXT), A2N = BOT ? A1N : wg_a2(INEXT < 0 ? 0 : INEXT);
+    constexpr int NTN = (INEXT < 0 || BOT) ? NT : (wg_te(INEXT, T1) - T0);
     static_assert(INEXT < 0 || (NTN >= 1 && (1 / NT) == (1 / NTN) && (1 % NT) == (1 % NTN)), "steps 0 and 1 of the chained pass have this pass's shape");
     float V[2][4];
     unsigned P[NT][2];
@@ -167,15 +182,19 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
     for (int t = 0; t < NT; t++) { P[t][0] = RA[T0 + t][A1]; P[t][1] = RA[T0 + t][A2]; }
     if constexpr (!PRIMED) {
 #pragma unroll
-        for (int g = 0; g < 2; g++) WG_LOAD2(D[g], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+        for (int g = 0; g < 2; g++) WG_LOAD(BOT, D[g], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
     }
     // row component (d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3), then the four column components
 #define WG_XFORM(BUF)                                                                                     \
     {                                                                                                     \
         float r_[4];                                                                                      \
         _Pragma("unroll") for (int b = 0; b < 4; b++) {                                                   \
-            const float da_ = D[BUF][b >> 1][b & 1], db_ = D[BUF][2 + (b >> 1)][b & 1];                   \
-            r_[b] = I == 1 ? wg_add(da_, db_) : (I == 2 ? wg_sub(db_, da_) : wg_sub(da_, db_));           \
+            const float da_ = D[BUF][b >> 1][b & 1];                                                      \
+            if constexpr (BOT) r_[b] = da_;                                                               \
+            else {                                                                                        \
+                const float db_ = D[BUF][2 + (b >> 1)][b & 1];                                            \
+                r_[b] = I == 1 ? wg_add(da_, db_) : (I == 2 ? wg_sub(db_, da_) : wg_sub(da_, db_));       \
+            }                                                                                             \
         }                                                                                                 \
         V[BUF][0] = wg_sub(r_[0], r_[2]); V[BUF][1] = wg_add(r_[1], r_[2]);                               \
         V[BUF][2] = wg_sub(r_[2], r_[1]); V[BUF][3] = wg_sub(r_[1], r_[3]);                               \
@@ -191,15 +210,15 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
 #pragma unroll
         for (int s = 0; s < 4 * NT; s++) {
             const int t = T0 + s % NT, kk = s / NT, g = s + 2;
-            if (g < 4 * NT) WG_LOAD2(D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+            if (g < 4 * NT) WG_LOAD(BOT, D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
             else {
                 const int t2 = (g - 4 * NT) % NT;                // the next iteration's base from here on (this one no longer reads through it)
                 if ((g - 4 * NT) / NT == 0) { P[t2][0] += adv; P[t2][1] += adv; }
                 if constexpr (INEXT >= 0) {                      // last iteration: the next pass's first steps instead
                     unsigned q0 = more ? P[t2][0] : RA[T0 + t2][A1N], q1 = more ? P[t2][1] : RA[T0 + t2][A2N];
-                    WG_LOAD2(D[s & 1], q0, q1, ((g - 4 * NT) / NT) * WG_KSTEP)
+                    WG_LOAD(BOT, D[s & 1], q0, q1, ((g - 4 * NT) / NT) * WG_KSTEP)
                 } else
-                    WG_LOAD2(D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * WG_KSTEP)
+                    WG_LOAD(BOT, D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * WG_KSTEP)
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -289,6 +308,34 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
     run(integral_constant<int, 3>{});
 }
 
+// M-tile 2 is the bottom tile row: its window rows 2 and 3 are elevation padding and its second output row (7) does not
+// exist, so its one output row is the plain two-tap form in elevation
+//     y[6] = A^T-columns of sum_c ( colB(d[5]) (.) colG(g[0]) + colB(d[6]) (.) colG(g[1]) ),
+// two passes of four column components (8 tile-components instead of the 12 the row components 0..2 took, and no row
+// combination in the input transform).  colG(g[0]) is the Winograd block i = 0; colG(g[1]) = U_1 - U_2 is a fifth block of
+// the tiling.  The four accumulators run through both taps; the bias starts in component 1.
+template <int NN>
+__device__ __forceinline__ void wg_round_bottom(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_after, unsigned lofs, int niter,
+                                                int wstride, unsigned pstride, const float* __restrict__ bias_lane, wgf4 (&W)[NN][2], wgf4 (&Y)[NN][3][2][2])
+{
+    wgf2 D[2][4];
+    wgf4 acc[NN][3][4];
+    float zero = 0.f;
+    asm volatile("" : "+v"(zero));
+#pragma unroll
+    for (int n = 0; n < NN; n++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            acc[n][2][j] = (j == 1 && bias_lane) ? *reinterpret_cast<const wgf4*>(bias_lane + n * 16) : (wgf4){ zero, zero, zero, zero };
+    wg_pass<0, NN, 2, 3, false, 1, true>(RA, rs, wp, wp + 4 * pstride, lofs, niter, wstride, W, acc, D);
+    wg_pass<1, NN, 2, 3, true, -1, true>(RA, rs, wp + 4 * pstride, wp_after, lofs, niter, wstride, W, acc, D);
+#pragma unroll
+    for (int n = 0; n < NN; n++) {
+        Y[n][2][0][0] = acc[n][2][0] + acc[n][2][1] + acc[n][2][2];
+        Y[n][2][0][1] = acc[n][2][1] - acc[n][2][2] - acc[n][2][3];
+    }
+}
+
 // ReLU + store of one N-tile's outputs: into the activation buffer (with the circular halo copies) or to y[32][140].
 // The weights are the MFMA's first operand, so the C/D layout has lane column li = the tile and rows lk * 4 + r = the
 // output channel: a store instruction writes 16 different positions of a channel (distinct banks), not 16 channels at one
@@ -370,12 +417,14 @@ __device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* 
     const int k4 = cin >> 2, wstride = 256;
 #endif
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
-    const unsigned wp = (unsigned)nt * (16 * cin * 16);                   // [N-tile][i][k-step][lane][j]: a wavefront streams its own block
+    const unsigned wp = (unsigned)nt * (WG_BLOCKS * cin * 16);            // [N-tile][i][k-step][lane][j]: a wavefront streams its own block
     const unsigned lofs = lane * 16;
     wgf4 W[1][2];
     wg_first_weights<1, 0, 2>(rs, wp, lofs, wstride, W);
     wgf4 Y[1][3][2][2];
-    wg_round<1, T0, T1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bias + nt * 16 + lk * 4, W, Y);
+    static_assert(T0 == 0 && T1 == 3, "M-tiles 0, 1 in the Winograd form, M-tile 2 in the bottom-row form");
+    wg_round<1, 0, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bias + nt * 16 + lk * 4, W, Y);
+    wg_round_bottom<1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bias + nt * 16 + lk * 4, W, Y);
     WG_SYNC();                                 // every wavefront has finished reading the layer's input
     wg_store<T0, T1, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
 }
@@ -398,12 +447,13 @@ __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* 
     unsigned RA[3][4];
     wg_addresses(act, k0, li, lk, RA);
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
-    const unsigned wp = (unsigned)nt * (16 * cin * 16) + (unsigned)k0 * wstride;
+    const unsigned wp = (unsigned)nt * (WG_BLOCKS * cin * 16) + (unsigned)k0 * wstride;
     const unsigned lofs = lane * 16;
     wgf4 W[1][2];
     wg_first_weights<1, 0, 2>(rs, wp, lofs, wstride, W);
     wgf4 Y[1][3][2][2];
-    wg_round<1, 0, 3>(RA, rs, wp, wp, lofs, kn >> 2, wstride, (unsigned)(k4 * wstride), half ? nullptr : bias + nt * 16 + lk * 4, W, Y);
+    wg_round<1, 0, 2>(RA, rs, wp, wp, lofs, kn >> 2, wstride, (unsigned)(k4 * wstride), half ? nullptr : bias + nt * 16 + lk * 4, W, Y);
+    wg_round_bottom<1>(RA, rs, wp, wp, lofs, kn >> 2, wstride, (unsigned)(k4 * wstride), half ? nullptr : bias + nt * 16 + lk * 4, W, Y);
     wgf4* slot = reinterpret_cast<wgf4*>(act + WG_XCH_C * WG_CS) + nt * 640 + lane;                  // 10 x 64 float4 per N-tile
     if (half) {
 #pragma unroll
@@ -452,7 +502,7 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
     unsigned RA[3][4];
     wg_addresses(act, 0, li, lk, RA);
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
-    const unsigned wp = (unsigned)pair * (16 * cin * 32);                  // [pair][i][k-step][n2][lane][j]
+    const unsigned wp = (unsigned)pair * (WG_BLOCKS * cin * 32);           // [pair][i][k-step][n2][lane][j]
     const unsigned lofs = lane * 16;
     const unsigned pstride = (unsigned)(k4 * wstride);
     wgf4 Y[2][3][2][2];
@@ -467,7 +517,7 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
     wg_park<0>(Y, park);
     wg_round<2, 1, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
     wg_park<1>(Y, park);
-    wg_round<2, 2, 3>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
+    wg_round_bottom<2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
     wg_park<2>(Y, park);
     WG_SYNC();                                       // every wavefront has finished reading the layer's input
     int lane_s = threadIdx.x & (WAVE - 1);
@@ -540,7 +590,8 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
 
 
 // Host helper: filters w [Cout][Cin][3][3] (BN folded) -> U = G g G^T in fp64, rounded once, in the kernel's A-operand tiling
-//     out[16 * Cout * Cin] = [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk]
+//     out[20 * Cout * Cin] = [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk]       (i = 0..4)
+// where block i = 4 holds g[1] G^T = U_1 - U_2, the second elevation tap of the bottom-row form (wg_round_bottom),
 // with N-groups of NG = 2 N-tiles for 128 output channels (a wavefront owns a pair there) and NG = 1 otherwise: the
 // k-steps of a wavefront follow each other in memory (round 2 had the N-tile inside the k-step: every 1 KB fetch of a
 // wavefront then sat on another 4-8 KB page, and the filter stream cost 8 % of the kernel in translation misses).  No device work.
@@ -554,12 +605,12 @@ extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin,
         for (int c = 0; c < cin; c++) {
             const float* g = w_host + ((size_t)o * cin + c) * 9;
             const int n = o / 16;
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < WG_BLOCKS / 4; i++)
                 for (int j = 0; j < 4; j++) {
                     double u = 0;
                     for (int a = 0; a < 3; a++)
-                        for (int b = 0; b < 3; b++) u += G[i][a] * (double)g[3 * a + b] * G[j][b];
-                    const size_t idx = ((((((size_t)(n / ng) * 4 + i) * k4 + c / 4) * ng + n % ng) * 4 + c % 4) * 16 + o % 16);
+                        for (int b = 0; b < 3; b++) u += (i < 4 ? G[i][a] : (a == 1 ? 1.0 : 0.0)) * (double)g[3 * a + b] * G[j][b];
+                    const size_t idx = ((((((size_t)(n / ng) * (WG_BLOCKS / 4) + i) * k4 + c / 4) * ng + n % ng) * 4 + c % 4) * 16 + o % 16);
                     out_host[idx * 4 + j] = (float)u;
                 }
         }
@@ -630,7 +681,7 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
                     c7[0] / n, c7[1] / n, c7[2] / n, c7[3] / n, b7[0] / n, b7[1] / n, b7[2] / n, b7[3] / n, s7[0] / n, s7[1] / n, s7[2] / n, s7[3] / n);
             fprintf(stderr, "WG_STAMP: %ld workgroups, layers total %.0f cycles per patch, input phase %.0f\n", n, tot / n, pre / n);
             for (int l = 0; l < WG_LAYERS; l++) {
-                const double mf = 44.0 * (P.cin[l] / 4) * (P.cout[l] / 16) / 4;     // MFMAs per wave
+                const double mf = 40.0 * (P.cin[l] / 4) * (P.cout[l] / 16) / 4;     // MFMAs per wave
                 fprintf(stderr, "  layer %d %3d->%3d: MFMAs/wave %5.0f | to barrier %7.0f %7.0f %7.0f %7.0f | wait %6.0f %6.0f %6.0f %6.0f | cycles per MFMA slot %.1f\n",
                         l, P.cin[l], P.cout[l], mf, comp[l][0] / n, comp[l][1] / n, comp[l][2] / n, comp[l][3] / n, wait[l][0] / n, wait[l][1] / n,
                         wait[l][2] / n, wait[l][3] / n, (comp[l][0] + wait[l][0]) / n / (2 * mf));

@@ -239,15 +239,16 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
 
 /* A11 (dense)  Cylindrical_Net (models/patchnet.py:15-85): Conv3d(16->64, 3x3x3) + 7 x Conv2d 3x3, BatchNorms folded, circular
  * azimuth / zero elevation padding (utils/common.py:265-310), as ONE kernel in the Winograd F(2x2,3x3) domain, all fp32
- * (csrc/convnet_wg.hip: 44 instead of 75 matrix instructions per 4 input x 16 output channels; a different fp32 summation
+ * (csrc/convnet_wg.hip: 40 instead of 75 matrix instructions per 4 input x 16 output channels; a different fp32 summation
  * order, within 1e-6 of the output scale of a direct-form evaluation: tests/native/convnet_direct.hip is that cross-check).
  * x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140] (= [np,32,7,20]); bias_host[l]: DEVICE pointers to [Cout].
  * wt_host[l]: DEVICE pointers to U = G g G^T of the BN-folded filters ([Cout,Cin,3,3]; layer 0: Cin = c16*3 + depth) in the
  * tiling [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk] with NG = buf_winograd_group(Cin, Cout)
- * N-tiles per group (the N-tiles one wavefront owns: its k-steps are contiguous in memory), as buf_winograd_tile_weights lays
- * them out (fp64 on the host).  Cin a multiple of 16 (of 32 for Cout 128), Cout in {32, 64, 128}, last layer 32. */
+ * N-tiles per group (the N-tiles one wavefront owns: its k-steps are contiguous in memory) and i = 0..4, block 4 being
+ * g[1] G^T (= U_1 - U_2: the bottom tile row, whose window ends in the elevation padding, runs as a two-tap form in
+ * elevation -- 8 instead of 12 matrix instructions), as buf_winograd_tile_weights lays them out (fp64 on the host).  Cin a multiple of 16 (of 32 for Cout 128), Cout in {32, 64, 128}, last layer 32. */
 int     buf_winograd_group(int cin, int cout);                                                   /* host only: NG of a layer */
-int     buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host);   /* host only: [Cout,Cin,3,3] -> 16*Cout*Cin floats */
+int     buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host);   /* host only: [Cout,Cin,3,3] -> 20*Cout*Cin floats */
 int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
 
