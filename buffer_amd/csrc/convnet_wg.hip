@@ -160,12 +160,13 @@ __device__ __forceinline__ wgf4 wg_ldw(__amdgpu_buffer_rsrc_t rs, unsigned unifo
 // offsets ride in the instructions, the weights (W[n][k-step]: one 16-byte load per lane) are reloaded in place half an
 // iteration ahead, and the last iteration fetches the weights of whatever runs next (wp_next) instead of its own.  Every
 // pass reads its own first two steps.  The N-tiles of a pair are neighbours in the weight tiling (256 floats apart).
+// KSTEP: LDS bytes between k-steps (4 channels) -- k_cost_net's Winograd layers run the same passes over other map sizes.
 // PRIMED: the previous pass already fetched this pass's first two steps into D; INEXT >= 0: this pass fetches those of the row
 // component INEXT in its last iteration (the LDS latency of a pass start is then covered by the previous pass's MFMAs).
 // Weights: W[n][k-step & 1], a ring of TWO k-steps per N-tile -- the registers of a k-step are reloaded with the k-step two
 // further on (of this pass, or of whatever runs next: wp_next) as soon as its MFMAs are through, so every load is issued two
 // k-steps before its use with half the registers of a whole-iteration buffer (the paired layers were spilling their outputs).
-template <int I, int NN, int T0, int T1, bool PRIMED, int INEXT, bool BOT = false>
+template <int I, int NN, int T0, int T1, bool PRIMED, int INEXT, bool BOT = false, unsigned KSTEP = WG_KSTEP>
 __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_next, unsigned lofs, int niter,
                                         int wstride, wgf4 (&W)[NN][2], wgf4 (&acc)[NN][3][4], wgf2 (&D)[2][4])
 {
@@ -182,7 +183,7 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
     for (int t = 0; t < NT; t++) { P[t][0] = RA[T0 + t][A1]; P[t][1] = RA[T0 + t][A2]; }
     if constexpr (!PRIMED) {
 #pragma unroll
-        for (int g = 0; g < 2; g++) WG_LOAD(BOT, D[g], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+        for (int g = 0; g < 2; g++) WG_LOAD(BOT, D[g], P[g % NT][0], P[g % NT][1], (g / NT) * KSTEP)
     }
     // row component (d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3), then the four column components
 #define WG_XFORM(BUF)                                                                                     \
@@ -205,20 +206,20 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
         const bool more = it + 1 < niter;
         const unsigned wcur = wp + 4 * it * wstride;            // this iteration's k-steps 2, 3 ...
         const unsigned wn = more ? wcur + 4 * wstride : wp_next;   // ... and the k-steps 0, 1 of the next one (or of the next pass)
-        const unsigned adv = more ? 4u * WG_KSTEP : 0u;         // past the end: the iteration's own first steps again (unused)
+        const unsigned adv = more ? 4u * KSTEP : 0u;         // past the end: the iteration's own first steps again (unused)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4 * NT; s++) {
             const int t = T0 + s % NT, kk = s / NT, g = s + 2;
-            if (g < 4 * NT) WG_LOAD(BOT, D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * WG_KSTEP)
+            if (g < 4 * NT) WG_LOAD(BOT, D[s & 1], P[g % NT][0], P[g % NT][1], (g / NT) * KSTEP)
             else {
                 const int t2 = (g - 4 * NT) % NT;                // the next iteration's base from here on (this one no longer reads through it)
                 if ((g - 4 * NT) / NT == 0) { P[t2][0] += adv; P[t2][1] += adv; }
                 if constexpr (INEXT >= 0) {                      // last iteration: the next pass's first steps instead
                     unsigned q0 = more ? P[t2][0] : RA[T0 + t2][A1N], q1 = more ? P[t2][1] : RA[T0 + t2][A2N];
-                    WG_LOAD(BOT, D[s & 1], q0, q1, ((g - 4 * NT) / NT) * WG_KSTEP)
+                    WG_LOAD(BOT, D[s & 1], q0, q1, ((g - 4 * NT) / NT) * KSTEP)
                 } else
-                    WG_LOAD(BOT, D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * WG_KSTEP)
+                    WG_LOAD(BOT, D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * KSTEP)
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -249,7 +250,7 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
 // -- three accumulator clears and half of the output-transform adds less per N-tile.  The bias (when this wavefront carries
 // it: K-split layers add it once) enters component (1, 1)'s accumulator before pass 1: F_1, F_2, F_3 then carry it once in
 // both columns.
-template <int NN, int T0, int T1>
+template <int NN, int T0, int T1, unsigned KSTEP = WG_KSTEP>
 __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_after, unsigned lofs, int niter,
                                          int wstride, unsigned pstride, const float* __restrict__ bias_lane, wgf4 (&W)[NN][2], wgf4 (&Y)[NN][3][2][2])
 {
@@ -281,7 +282,7 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
                 for (int t = T0; t < T1; t++) acc[n][t][1] += bv[n];
         }
         constexpr int ICHAIN = (INEXT != 0 && wg_chains(I, T0, T1)) ? INEXT : -1;      // the next row component of this round, if any
-        wg_pass<I, NN, T0, T1, wg_chains(I - 1, T0, T1), ICHAIN>(RA, rs, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, lofs, niter, wstride, W, acc, D);
+        wg_pass<I, NN, T0, T1, wg_chains(I - 1, T0, T1), ICHAIN, false, KSTEP>(RA, rs, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, lofs, niter, wstride, W, acc, D);
 #pragma unroll
         for (int n = 0; n < NN; n++)
 #pragma unroll
@@ -340,26 +341,24 @@ __device__ __forceinline__ void wg_round_bottom(unsigned (&RA)[3][4], __amdgpu_b
 // The weights are the MFMA's first operand, so the C/D layout has lane column li = the tile and rows lk * 4 + r = the
 // output channel: a store instruction writes 16 different positions of a channel (distinct banks), not 16 channels at one
 // position (one bank: the channel stride is a multiple of 32 words).
-template <int T0, int T1, bool GLB>
-__device__ __forceinline__ void wg_store(const wgf4 (&Y)[3][2][2], int nt, int relu, float* __restrict__ act, float* __restrict__ out_glb,
-                                         int li, int lk)
+template <bool GLB, int NU = 2>
+__device__ __forceinline__ void wg_store_tile(const wgf4 (&Yt)[2][2], int t, int nt, int relu, float* __restrict__ act, float* __restrict__ out_glb,
+                                              int li, int lk)
 {
     const int n0 = nt * 16 + lk * 4;
     const float lo = relu ? 0.f : -__builtin_inff();
-#pragma unroll
-    for (int t = T0; t < T1; t++) {
+    {
         int ty, tx;
         const bool valid = wg_tile(t, li, ty, tx);
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (t == 2 && u == 1) continue;                       // M-tile 2 is tile row 3: its second output row is row 7
-            const bool ok = valid && (t != 1 || u == 0 || ty < 3);
+        for (int u = 0; u < NU; u++) {                            // (M-tile 2 is tile row 3: NU = 1, its second output row is row 7)
             const int row = 2 * ty + u;
+            const bool ok = valid && row < 7;
             if constexpr (GLB) {
                 if (ok) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float v0 = fmaxf(Y[t][u][0][r], lo), v1 = fmaxf(Y[t][u][1][r], lo);
+                        const float v0 = fmaxf(Yt[u][0][r], lo), v1 = fmaxf(Yt[u][1][r], lo);
                         *reinterpret_cast<wgf2*>(out_glb + (size_t)(n0 + r) * 140 + row * 20 + 2 * tx) = (wgf2){ v0, v1 };
                     }
                 }
@@ -372,12 +371,23 @@ __device__ __forceinline__ void wg_store(const wgf4 (&Y)[3][2][2], int nt, int r
                 float* p = act + n0 * WG_CS;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float v0 = fmaxf(Y[t][u][0][r], lo), v1 = fmaxf(Y[t][u][1][r], lo);
+                    const float v0 = fmaxf(Yt[u][0][r], lo), v1 = fmaxf(Yt[u][1][r], lo);
                     p[r * WG_CS + pos] = v0; p[r * WG_CS + pos + 1] = v1;
                     p[r * WG_CS + h0] = v0; p[r * WG_CS + h1] = v1;
                 }
             }
         }
+    }
+}
+
+template <int T0, int T1, bool GLB>
+__device__ __forceinline__ void wg_store(const wgf4 (&Y)[3][2][2], int nt, int relu, float* __restrict__ act, float* __restrict__ out_glb,
+                                         int li, int lk)
+{
+#pragma unroll
+    for (int t = T0; t < T1; t++) {
+        if (t == 2) wg_store_tile<GLB, 1>(Y[t], t, nt, relu, act, out_glb, li, lk);
+        else wg_store_tile<GLB, 2>(Y[t], t, nt, relu, act, out_glb, li, lk);
     }
 }
 
@@ -469,10 +479,46 @@ __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* 
     }
 }
 
+// One layer with 64 output channels (four N-tiles, four wavefronts): wavefront w owns the N-tile pair w & 1 for ONE of the
+// M-tiles 0, 1 (w >> 1) -- the transform of a step feeds 8 MFMAs, as in the 128-channel layers -- and the bottom-row form of
+// ONE N-tile of its pair: 32 + 8 = 40 matrix instructions per k-step for every wavefront, no partial sums to exchange.
+// (One N-tile per wavefront over all M-tiles, the round-2 form, pays 1.8 transform instructions per MFMA instead of 1.0.)
+__device__ __forceinline__ void wg_layer_msplit(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                int cin, int cout, int relu, int w)
+{
+    int lane = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    const int pair = w & 1, h = w >> 1;
+    const int k4 = cin >> 2, wstride = 512;
+    unsigned RA[3][4];
+    {
+        const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)act;
+#pragma unroll
+        for (int a = 0; a < 4; a++) { RA[0][a] = wg_row_addr(act_addr, h, a, li, lk); RA[1][a] = RA[0][a]; RA[2][a] = wg_row_addr(act_addr, 2, a, li, lk); }
+    }
+    const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
+    const unsigned wp = (unsigned)pair * (WG_BLOCKS * cin * 32);           // [pair][i][k-step][n2][lane][j]
+    const unsigned wpb = wp + (unsigned)h * 256;                           // the N-tile of the pair whose bottom row is this wavefront's
+    const unsigned lofs = lane * 16;
+    const unsigned pstride = (unsigned)(k4 * wstride);
+    wgf4 Y[2][3][2][2];
+    wgf4 W2[2][2];
+    wg_first_weights<2, 0, 2>(rs, wp, lofs, wstride, W2);
+    wg_round<2, 0, 1>(RA, rs, wp, wpb, lofs, k4 >> 2, wstride, pstride, bias + (2 * pair) * 16 + lk * 4, W2, Y);     // slot 0 = M-tile h
+    wgf4 W1[1][2] = { { W2[0][0], W2[0][1] } };
+    wgf4 Yb[1][3][2][2];
+    wg_round_bottom<1>(RA, rs, wpb, wpb, lofs, k4 >> 2, wstride, pstride, bias + (2 * pair + h) * 16 + lk * 4, W1, Yb);
+    WG_SYNC();                                       // every wavefront has finished reading the layer's input
+    wg_store_tile<false, 2>(Y[0][0], h, 2 * pair, relu, act, nullptr, li, lk);
+    wg_store_tile<false, 2>(Y[1][0], h, 2 * pair + 1, relu, act, nullptr, li, lk);
+    wg_store_tile<false, 1>(Yb[0][2], 2, 2 * pair + h, relu, act, nullptr, li, lk);
+}
+
 // N-tiles per wavefront of a layer: 2 (the paired form below) or 1.  The filter tiling follows it (buf_winograd_tile_weights).
 // Pairs for the 64-channel layers too (two wavefronts per pair, K split between them, partial sums exchanged through the dead
 // half of the buffer) measured 1 % slower, before and after the filter stream became cheap: short K loops, a third barrier.
-__host__ __device__ constexpr int wg_group(int cin, int cout) { return cout == 128 ? 2 : 1; }
+__host__ __device__ constexpr int wg_group(int cin, int cout) { return cout >= 64 ? 2 : 1; }
 
 // Outputs of M-tile T of both N-tiles of a pair -> accumulation registers (see wg_layer_pair)
 template <int T>
@@ -576,7 +622,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
         const int cin = P.cin[l], cout = P.cout[l];
         if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (cout == 64) {
-            wg_layer_single<0, 3, false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+            wg_layer_msplit(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         } else if (l < WG_LAYERS - 1) wg_layer_ksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else wg_layer_ksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         WG_STAMP_AT(2 * l + 1)
@@ -595,26 +641,36 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
 // with N-groups of NG = 2 N-tiles for 128 output channels (a wavefront owns a pair there) and NG = 1 otherwise: the
 // k-steps of a wavefront follow each other in memory (round 2 had the N-tile inside the k-step: every 1 KB fetch of a
 // wavefront then sat on another 4-8 KB page, and the filter stream cost 8 % of the kernel in translation misses).  No device work.
-extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host)
+// General form: N-groups of ng N-tiles, nblk = 4 (the Winograd components only: k_cost_net's unpadded layers) or 5 blocks;
+// out[4 nblk * Cout * Cin].
+extern "C" int buf_winograd_tile_filters(const float* w_host, int cout, int cin, int ng, int nblk, float* out_host)
 {
-    BUF_REQUIRE(w_host && out_host, BUF_EINVAL, "buf_winograd_tile_weights: null argument");
-    BUF_REQUIRE(cout > 0 && cin > 0 && cout % 16 == 0 && cin % 4 == 0, BUF_EINVAL, "buf_winograd_tile_weights: widths %d -> %d", cin, cout);
+    BUF_REQUIRE(w_host && out_host, BUF_EINVAL, "buf_winograd_tile_filters: null argument");
+    BUF_REQUIRE(cout > 0 && cin > 0 && cout % 16 == 0 && cin % 4 == 0, BUF_EINVAL, "buf_winograd_tile_filters: widths %d -> %d", cin, cout);
+    BUF_REQUIRE(ng >= 1 && (cout / 16) % ng == 0 && (nblk == 4 || nblk == 5), BUF_EINVAL, "buf_winograd_tile_filters: %d N-tiles in groups of %d, %d blocks",
+                cout / 16, ng, nblk);
     static const double G[4][3] = { { 1, 0, 0 }, { .5, .5, .5 }, { .5, -.5, .5 }, { 0, 0, 1 } };
-    const int k4 = cin / 4, ng = wg_group(cin, cout);
+    const int k4 = cin / 4;
     for (int o = 0; o < cout; o++)
         for (int c = 0; c < cin; c++) {
             const float* g = w_host + ((size_t)o * cin + c) * 9;
             const int n = o / 16;
-            for (int i = 0; i < WG_BLOCKS / 4; i++)
+            for (int i = 0; i < nblk; i++)
                 for (int j = 0; j < 4; j++) {
                     double u = 0;
                     for (int a = 0; a < 3; a++)
                         for (int b = 0; b < 3; b++) u += (i < 4 ? G[i][a] : (a == 1 ? 1.0 : 0.0)) * (double)g[3 * a + b] * G[j][b];
-                    const size_t idx = ((((((size_t)(n / ng) * (WG_BLOCKS / 4) + i) * k4 + c / 4) * ng + n % ng) * 4 + c % 4) * 16 + o % 16);
+                    const size_t idx = ((((((size_t)(n / ng) * nblk + i) * k4 + c / 4) * ng + n % ng) * 4 + c % 4) * 16 + o % 16);
                     out_host[idx * 4 + j] = (float)u;
                 }
         }
     return BUF_OK;
+}
+
+extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host)
+{
+    BUF_REQUIRE(cout > 0 && cin > 0 && cout % 16 == 0 && cin % 4 == 0, BUF_EINVAL, "buf_winograd_tile_weights: widths %d -> %d", cin, cout);
+    return buf_winograd_tile_filters(w_host, cout, cin, wg_group(cin, cout), WG_BLOCKS / 4, out_host);
 }
 
 // N-tiles per group in the filter tiling of a layer with these widths (the Python side asks instead of restating the rule)

@@ -508,18 +508,20 @@ def mfma_tile_weights(wt, lk_major=False):
     return np.ascontiguousarray(np.transpose(t, perm), dtype=np.float32).reshape(-1)              # [g, n, lk, li, p]
 
 
-def winograd_tile_weights(w):
+def winograd_tile_weights(w, ng=None, blocks=5):
     """[Cout, Cin, 3, 3] -> the F(2x2, 3x3) filter transform U = G g G^T (fp64, rounded once to fp32) in the A-operand tiling
     of csrc/convnet_wg.hip: [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk], N-groups of NG = 2
     N-tiles for 128 output channels and 1 otherwise; i = 0..4, the fifth block being g[1] G^T = U_1 - U_2 (the second elevation
-    tap of the kernel's bottom-row form).  20 * Cout * Cin floats (buf_winograd_tile_weights is the same function on the C side)."""
+    tap of the kernel's bottom-row form).  20 * Cout * Cin floats (buf_winograd_tile_weights is the same function on the C side).
+    ng / blocks: the general form (buf_winograd_tile_filters) -- csrc/costnet.hip's unpadded layers take blocks = 4."""
     cout, cin = w.shape[0], w.shape[1]
     assert cin % 4 == 0 and cout % 16 == 0
-    ng = _lib.lib().buf_winograd_group(cin, cout)                  # N-tiles per wavefront for these widths: the kernel's rule
+    if ng is None:
+        ng = _lib.lib().buf_winograd_group(cin, cout)              # N-tiles per wavefront for these widths: the kernel's rule
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     G5 = np.concatenate([G, [[0, 1, 0]]])                                              # row 4: the filter's middle row as it is
     U = np.einsum('ia,ocab,jb->ijoc', G5, np.asarray(w, np.float64), G)                # [i, j, Cout, Cin]
-    U = U.reshape(5, 4, cout // (16 * ng), ng, 16, cin // 4, 4)                        # [i, j, g, n2, li, ks, lk]
+    U = U[:blocks].reshape(blocks, 4, cout // (16 * ng), ng, 16, cin // 4, 4)          # [i, j, g, n2, li, ks, lk]
     return np.ascontiguousarray(np.transpose(U, (2, 0, 5, 3, 6, 4, 1)), dtype=np.float32).reshape(-1)
 
 

@@ -249,6 +249,8 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
  * elevation -- 8 instead of 12 matrix instructions), as buf_winograd_tile_weights lays them out (fp64 on the host).  Cin a multiple of 16 (of 32 for Cout 128), Cout in {32, 64, 128}, last layer 32. */
 int     buf_winograd_group(int cin, int cout);                                                   /* host only: NG of a layer */
 int     buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host);   /* host only: [Cout,Cin,3,3] -> 20*Cout*Cin floats */
+int     buf_winograd_tile_filters(const float* w_host, int cout, int cin, int ng, int nblk, float* out_host);
+                                                   /* host only: the same tiling with N-groups of ng and nblk = 4 | 5 blocks -> 4*nblk*Cout*Cin floats */
 int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
 

@@ -211,7 +211,7 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
     assert rc == 0 and np.array_equal(got, ops.winograd_tile_weights(w2))
     assert _lib.lib().buf_winograd_tile_weights(w2.ctypes.data_as(C.c_void_p), 30, 16, got.ctypes.data_as(C.c_void_p)) == -1
     # layers in the paired form (buf_winograd_group == 2): [pair][i][ks][n2][lk][li][j]
-    assert _lib.lib().buf_winograd_group(32, 128) == 2 and _lib.lib().buf_winograd_group(48, 64) == 1 and _lib.lib().buf_winograd_group(64, 32) == 1
+    assert _lib.lib().buf_winograd_group(32, 128) == 2 and _lib.lib().buf_winograd_group(48, 64) == 2 and _lib.lib().buf_winograd_group(64, 32) == 1
     w3 = np.ascontiguousarray(rng.standard_normal((128, 32, 3, 3)).astype(np.float32))
     t3 = ops.winograd_tile_weights(w3)
     U3 = np.transpose(t3.reshape(4, 5, 8, 2, 4, 16, 4), (1, 6, 0, 3, 5, 2, 4)).reshape(5, 4, 128, 32)
