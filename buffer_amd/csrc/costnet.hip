@@ -26,7 +26,7 @@
 #include <type_traits>
 
 #define CV_THREADS 256
-#define CV_BUF 19200              // floats per ping-pong buffer (largest map: 144 positions x (128 + 4) channels = 19008)
+#define CV_BUF 20480              // floats of the one LDS buffer (largest map: 128 channels x 160, the 12 x 12 map of layers 3 / 4)
 #define CV_LAYERS 10
 #define CV_C32 36                 // position-row strides (floats) of maps with 32 / 64 / 128 channels
 #define CV_C64 68
@@ -178,7 +178,9 @@ __device__ __forceinline__ void cv_conv_layer(const float* in, float* out, const
     constexpr int WOUT = WIN - KW + 1, P = WOUT * WOUT, GPT = CIN / 16, TAPS = KW * KW, NTOT = COUT / 16;
     constexpr int CSI = CIN + 4, CSO = COUT + 4;                        // position-row strides of the two maps
     static_assert(GPT % 2 == 0, "two pipeline slots alternate per channel group");
-    const int lane = threadIdx.x & (WAVE - 1), li = lane & 15, lk = lane >> 4;
+    int lane = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane));       // lane-derived addresses are formed per layer (hoisted to the kernel's start they are spilled)
+    const int li = lane & 15, lk = lane >> 4;
     const float* pa[MT];                 // lane's 4 channels (4lk..4lk+3 of group 0) of tile t at tap (0,0)
 #pragma unroll
     for (int t = 0; t < MT; t++) {
@@ -257,6 +259,104 @@ __device__ __forceinline__ void cv_conv_layer(const float* in, float* out, const
     }
 }
 
+// ---- layers 2..5 in the Winograd F(2x2, 3x3) domain (round 3) -------------------------------------------------------------
+// The (3,1,3) layers are unpadded 3x3 correlations over the (n, l) map: 16 -> 14 -> 12 -> 10 -> 8.  With the output cut into 2 x 2
+// tiles they run as the 16 component GEMMs of csrc/convnet_wg.hip (wg_round: the same passes, input transform, weight ring and
+// filter tiling) over M-tiles of whole tile rows -- 64 / 48 / 32 / 16 tile rows instead of 13 / 9 / 7 / 4 M-tiles x 9 taps:
+// 0.55 / 0.59 / 0.51 / 0.44 of the direct form's matrix instructions, 69 % of the kernel's before.  These maps are
+// CHANNEL-major, [C][CS] with rows of RS floats (a window row of a tile = two ds_read_b64); CS is chosen per map so that the two
+// channels a half-wave reads land on different banks.  A wavefront owns an N-tile pair where the layer has 8 N-tiles or can
+// split its M-tiles evenly (one transform feeds 8 MFMAs), and holds its outputs in registers until every wavefront has read.
+template <int HIN, int TYPM>
+__device__ __forceinline__ bool cw_tile(int t, int li, int& ty, int& tx)
+{
+    constexpr int NTY = (HIN - 2) / 2;                   // tiles per row and per column
+    const int q = li / NTY;
+    ty = t * TYPM + q; tx = li - q * NTY;
+    return q < TYPM && ty < NTY;
+}
+
+// outputs of one M-tile of one N-tile: ReLU, then into the channel-major map [C][CSO] (rows of RSO) or, for the layer that
+// feeds the direct-form layers again, position-major [(row, col)][CSO]
+template <int HIN, int TYPM, int RSO, int CSO, bool POSMAJOR>
+__device__ __forceinline__ void cw_store_tile(const wgf4 (&Yt)[2][2], int t, int nt, float* __restrict__ out, int li, int lk)
+{
+    int ty, tx;
+    if (!cw_tile<HIN, TYPM>(t, li, ty, tx)) return;
+    const int n0 = nt * 16 + lk * 4;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int row = 2 * ty + u, col = 2 * tx;
+        if constexpr (POSMAJOR) {
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                wgf4 y;
+#pragma unroll
+                for (int r = 0; r < 4; r++) y[r] = fmaxf(Yt[u][v][r], 0.f);
+                *reinterpret_cast<wgf4*>(out + (row * (HIN - 2) + col + v) * CSO + n0) = y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                *reinterpret_cast<wgf2*>(out + (n0 + r) * CSO + row * RSO + col) = (wgf2){ fmaxf(Yt[u][0][r], 0.f), fmaxf(Yt[u][1][r], 0.f) };
+        }
+    }
+}
+
+// One Winograd layer over the map in `map` (HIN x HIN, rows of RS, channel stride CS), rewritten in place: this wavefront's
+// N-group `ng` (NN N-tiles) over the M-tiles t0 .. t0 + MT - 1 in one round and MT2 more in a second one.
+template <int HIN, int RS, int CS, int TYPM, int CIN, int NN, int MT, int MT2, int RSO, int CSO, bool POSMAJOR>
+__device__ __forceinline__ void cw_layer(float* __restrict__ map, const float* __restrict__ wt, const float* __restrict__ bias, int ng, int t0)
+{
+    static_assert(MT >= 1 && MT <= 2 && MT2 >= 0 && MT2 <= 1 && RS % 2 == 0 && CS % 2 == 0, "");
+    constexpr unsigned KSTEP = 16u * CS;
+    constexpr int k4 = CIN / 4, wstride = 256 * NN;
+    int lane = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)map;
+    auto rows = [&](int t, unsigned (&ra)[4]) __attribute__((always_inline)) {
+        int ty, tx;
+        if (!cw_tile<HIN, TYPM>(t, li, ty, tx)) { ty = 0; tx = 0; }              // idle lanes recompute tile (0, 0), never stored
+#pragma unroll
+        for (int a = 0; a < 4; a++) ra[a] = base + 4u * (unsigned)(lk * CS + (2 * ty + a) * RS + 2 * tx);
+    };
+    unsigned RA[3][4];
+    rows(t0, RA[0]);
+    rows(t0 + (MT > 1 ? 1 : 0), RA[1]);
+    rows(t0, RA[2]);
+    const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
+    const unsigned wp = (unsigned)ng * (CIN * NN * 256);          // [N-group][i 0..3][k-step][n2][lane][j]
+    const unsigned lofs = lane * 16;
+    const float* bl = bias + ng * NN * 16 + lk * 4;
+    wgf4 W[NN][2];
+    wg_first_weights<NN, 0, 2>(rs, wp, lofs, wstride, W);
+    wgf4 Y[NN][3][2][2];
+    wg_round<NN, 0, MT, KSTEP>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bl, W, Y);
+    wgf4 Y2[NN][3][2][2];
+    if constexpr (MT2 > 0) {
+        rows(t0 + MT, RA[0]);
+        wg_round<NN, 0, 1, KSTEP>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bl, W, Y2);
+    }
+    __syncthreads();                         // every wavefront has finished reading the map
+#pragma unroll
+    for (int n = 0; n < NN; n++) {
+#pragma unroll
+        for (int t = 0; t < MT; t++) cw_store_tile<HIN, TYPM, RSO, CSO, POSMAJOR>(Y[n][t], t0 + t, ng * NN + n, map, li, lk);
+        if constexpr (MT2 > 0) cw_store_tile<HIN, TYPM, RSO, CSO, POSMAJOR>(Y2[n][0], t0 + MT, ng * NN + n, map, li, lk);
+    }
+}
+#define CW_CS1 272        // channel strides of the maps after layers 1, 2 (= 16 mod 64: the two tile rows of an M-tile leave the
+#define CW_CS2 208        //   banks 16..31 / 48..63 to the half-wave's second channel), 3 and 4 (= 32 mod 64)
+#define CW_CS3 160
+
+#ifdef CV_STAMP
+__device__ long long* cv_stamp_ptr;       // development build (-DCV_STAMP): s_memtime of wavefront 0 at the phase boundaries
+#define CV_STAMP_AT(SLOT) if (threadIdx.x == 0) cv_stamp_ptr[(size_t)blockIdx.x * 16 + (SLOT)] = __builtin_amdgcn_s_memtime();
+#else
+#define CV_STAMP_AT(SLOT)
+#endif
+
 __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restrict__ s_eq, const float* __restrict__ t_eq, CostNetParams P,
                                                         float* __restrict__ ind_out)
 {
@@ -268,7 +368,8 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
     float* SM = bufB + CVA_SM;
     float* TB = bufB + CVA_TB;
     const int match = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE, li = lane & 15, lk = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), li = lane & 15, lk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid / WAVE);        // wavefront-uniform for the compiler too (scalar weight offsets)
     {   // both maps, transposed on the way in: global [c][k][l] -> LDS [k][l][c]; S with its two wrap-around columns per side
         const float* a = s_eq + (P.s_rows ? (size_t)P.s_rows[match] * P.row_floats + P.skip_floats : (size_t)match * 3200);
         const float* b = t_eq + (P.t_rows ? (size_t)P.t_rows[match] * P.row_floats + P.skip_floats : (size_t)match * 3200);
@@ -287,6 +388,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
         }
     }
     __syncthreads();
+    CV_STAMP_AT(0)
 
     // ---- phase A.1: the two small GEMMs of the separated layer 0; wave w owns M-tile w (16 positions), both N-tiles ----
     {
@@ -313,6 +415,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
             }
     }
     __syncthreads();                         // SM/TB complete; SP/TP dead from here on (chunk buffer R0 takes their place)
+    CV_STAMP_AT(1)
 
     // ---- phase A.2: layer 1 over chunks of three layer-0 rows; wave w owns N-tile w (16 of the 64 output channels) ----
     // Row ra = 3j + t of chunk j feeds output row ra - dn through slab dn: accumulators acc5[ra - dn - (3j - 2)] hold the five
@@ -361,24 +464,30 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
         chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
         chunk(std::integral_constant<int, 3>{}); chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
 #pragma unroll
-        for (int n2 = 0; n2 < 16; n2++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) bufA[(n2 * 16 + lk * 4 + r) * CV_C64 + w * 16 + li] = done[n2][r];
+        for (int n2 = 0; n2 < 16; n2++)                      // channel-major for the Winograd layers: [64][CW_CS1], rows of 16
+            *reinterpret_cast<cvx4*>(bufA + (w * 16 + li) * CW_CS1 + n2 * 16 + lk * 4) = done[n2];
         __syncthreads();
+    CV_STAMP_AT(2)
 #undef CV_SLAB
     }
 
     // ---- phase B: layers 2..6 rewrite the buffer in place; the three tiny last layers hop through its free parts -----------
-    cv_conv_layer<13, 1, 64, 64, 16, 3, true>(bufA, bufA, P.wt[2], P.bias[2], w, true);          // 16x16 -> 14x14
+    //                                 in: size rows stride | tile rows per M-tile | Cin | N-tiles, M-tiles per wavefront | out
+    cw_layer<16, 16, CW_CS1, 2, 64, 2, 2, 0, 14, CW_CS2, false>(bufA, P.wt[2], P.bias[2], w & 1, 2 * (w >> 1));   // 16x16 -> 14x14, 64 ch
     __syncthreads();
-    cv_conv_layer<9, 2, 64, 128, 14, 3, true>(bufA, bufA, P.wt[3], P.bias[3], 2 * w, true);      // -> 12x12
+    CV_STAMP_AT(3)
+    cw_layer<14, 14, CW_CS2, 2, 64, 2, 2, 1, 12, CW_CS3, false>(bufA, P.wt[3], P.bias[3], w, 0);                  // -> 12x12, 128 ch
     __syncthreads();
-    cv_conv_layer<7, 2, 128, 128, 12, 3, true>(bufA, bufA, P.wt[4], P.bias[4], 2 * w, true);     // -> 10x10
+    CV_STAMP_AT(4)
+    cw_layer<12, 12, CW_CS3, 3, 128, 2, 2, 0, 12, CW_CS3, false>(bufA, P.wt[4], P.bias[4], w, 0);                 // -> 10x10 (rows of 12)
     __syncthreads();
-    cv_conv_layer<4, 1, 128, 64, 10, 3, true>(bufA, bufA, P.wt[5], P.bias[5], w, true);          // -> 8x8
+    CV_STAMP_AT(5)
+    cw_layer<10, 12, CW_CS3, 4, 128, 1, 1, 0, 0, CV_C64, true>(bufA, P.wt[5], P.bias[5], w, 0);                   // -> 8x8, position-major
     __syncthreads();
+    CV_STAMP_AT(6)
     cv_conv_layer<3, 1, 64, 64, 8, 3, true>(bufA, bufA, P.wt[6], P.bias[6], w, true);            // -> 6x6 (36 x 68 floats)
     __syncthreads();
+    CV_STAMP_AT(7)
     float* hop1 = lds + 4096;
     float* hop2 = lds + 8192;
     float* hop3 = lds + 12288;
@@ -388,6 +497,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
     __syncthreads();
     if (w < 2) cv_conv_layer<1, 1, 32, 32, 2, 2, false>(hop2, hop3, P.wt[9], P.bias[9], w, false);   // -> 1x1, 20 (+12 zero) logits
     __syncthreads();
+    CV_STAMP_AT(8)
     if (w == 0) {                            // softmax over the 20 logits, expected index (BUFFER.py:63-65)
         float v = lane < 20 ? hop3[lane] : -3.4e38f;               // the 1x1 map: position 0, channels 0..19
         float mx = v;
@@ -419,13 +529,33 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
     // 2 * sum(out positions * K * Cout) = 0.109 GFLOP.  The dense algorithmic count of SURVEY 8d is 0.160 GFLOP/match
     // (bench.py reports both; the roofline fraction is taken on the executed count).
     static const double macs_per_match =
-        60.0 * 480 * 32 + 54.0 * 288 * 32 + 256.0 * 864 * 64 + 196.0 * 576 * 64 + 144.0 * 576 * 128 + 100.0 * 1152 * 128 + 64.0 * 1152 * 64 +
+        60.0 * 480 * 32 + 54.0 * 288 * 32 + 256.0 * 864 * 64 +
+        16.0 * (49.0 * 64 * 64 + 36.0 * 64 * 128 + 25.0 * 128 * 128 + 16.0 * 128 * 64) +        // layers 2..5: 16 components per 2 x 2 tile
         36.0 * 576 * 64 + 16.0 * 576 * 32 + 4.0 * 288 * 32 + 1.0 * 128 * 20;
     TimedSpan span;
     bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * macs_per_match * m, BUF_TIMED_COST_NET);
+#ifdef CV_STAMP
+    long long* stamps = nullptr;
+    BUF_CHECK_HIP(hipMalloc(&stamps, (size_t)m * 16 * sizeof(long long)));
+    BUF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cv_stamp_ptr), &stamps, sizeof(stamps)));
+#endif
     k_cost_net<<<m, CV_THREADS, lds, (hipStream_t)stream>>>(s_eq, t_eq, P, ind_out);
     if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
+#ifdef CV_STAMP
+    if (m >= 2048) {
+        BUF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        long long* h = (long long*)malloc((size_t)m * 16 * sizeof(long long));
+        BUF_CHECK_HIP(hipMemcpy(h, stamps, (size_t)m * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+        static const char* name[8] = { "A.1 (layer 0 maps)", "A.2 (layer 1)", "layer 2", "layer 3", "layer 4", "layer 5", "layer 6", "layers 7-9" };
+        double d[8] = {};
+        for (int b = m / 2; b < m; b++)
+            for (int i = 0; i < 8; i++) d[i] += (double)(h[(size_t)b * 16 + i + 1] - h[(size_t)b * 16 + i]);
+        for (int i = 0; i < 8; i++) fprintf(stderr, "  CV_STAMP %-20s %8.0f cycles per match\n", name[i], d[i] / (m - m / 2));
+        free(h);
+    }
+    (void)hipFree(stamps);
+#endif
     return BUF_OK;
 }
 

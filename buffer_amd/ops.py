@@ -592,7 +592,8 @@ def separate_cost_layer0(w):
 
 class CostVolumeNet:
     """Device weights of CostNet re-laid for csrc/costnet.hip: layer 0 in its separated form (separate_cost_layer0: Ws then
-    Wt in one buffer), layers 1..9 as Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout]; all MFMA-tiled."""
+    Wt in one buffer), layers 1 and 6..9 as Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout], MFMA-tiled; layers 2..5 as U = G g G^T in the
+    Winograd tiling (winograd_tile_weights with 4 blocks; N-tile pairs for layers 2..4)."""
 
     def __init__(self, layers, device):
         """layers: 10 x (w [Cout,Cin,KD,KH,KW] np.float32 with BN folded, b [Cout])"""
@@ -604,6 +605,12 @@ class CostVolumeNet:
             if i == 0:
                 assert tuple(w.shape) == (32, 32, 3, 3, 3), w.shape
                 tiled = np.concatenate([mfma_tile_weights(m, lk_major=True) for m in separate_cost_layer0(w)])
+                self.wt.append(torch.from_numpy(tiled).to(device))
+                self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
+                continue
+            if 2 <= i <= 5:                               # the (3,1,3) layers 16 -> 14 -> 12 -> 10 -> 8 run in the Winograd domain
+                assert tuple(w.shape[2:]) == (3, 1, 3), w.shape
+                tiled = winograd_tile_weights(np.ascontiguousarray(w[:, :, :, 0, :]), ng=(1 if i == 5 else 2), blocks=4)
                 self.wt.append(torch.from_numpy(tiled).to(device))
                 self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
                 continue
