@@ -14,11 +14,14 @@
 // on n': 54 positions, K = 288): 1.4 M MAC instead of the 26.9 M of the dense layer 0.  The two small maps are two MFMA GEMMs;
 // a layer-0 row is then relu(Smap + (b - Tmap)) formed by VALU, three rows (n') at a time into an LDS chunk that layer 1
 // consumes at once -- its output rows are accumulator tiles in registers (sliding window over n'), so the 124 KB layer-0
-// activation never exists either.  Layers 2..9 ping-pong between two 75 KB LDS buffers.
-// All GEMMs run on v_mfma_f32_16x16x4_f32 (exact fp32), weights ([K][Cout] MFMA-tiled, BN folded) stream from L2.
-// FLOP accounting: bench.py credits the DENSE algorithmic count of SURVEY 8d (0.160 GFLOP/match); executed: 0.109 GFLOP.
+// activation never exists either.  Layers 2..6 rewrite ONE 80 KB LDS buffer in place (two workgroups per CU); layers 2..5 -- the
+// unpadded 3x3 correlations 16 -> 14 -> 12 -> 10 -> 8, 69 % of the kernel's matrix instructions in the direct form -- run in the
+// Winograd F(2x2, 3x3) domain on the pass machinery of csrc/convnet_wg.hip (cw_layer below: 0.53 of their direct-form MFMAs).
+// All GEMMs run on v_mfma_f32_16x16x4_f32 (fp32), weights (BN folded; [K][Cout] MFMA-tiled, or G g G^T in the Winograd tiling)
+// stream from L2.
+// FLOP accounting: bench.py credits the DENSE algorithmic count of SURVEY 8d (0.160 GFLOP/match); executed: 0.0676 GFLOP.
 //
-// Every LDS map is POSITION-major, [position][channels + 4]: the four k-steps of a 16-channel group that a lane feeds
+// The LDS maps of the direct-form layers are POSITION-major, [position][channels + 4]: the four k-steps of a 16-channel group that a lane feeds
 // to the MFMA A operand (channels 16g + 4lk + 0..3 at its position) are one 16-byte ds_read_b128, and the +4 padding
 // (row stride = 4 mod 32 banks) keeps eight neighbouring positions on distinct bank quads.  With one wavefront per SIMD
 // the number of memory instructions per MFMA, not their bytes, sets the MFMA duty: 1 LDS + 1-2 global loads per group.
@@ -526,7 +529,7 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
     if (int rc = grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
     // EXECUTED flops per match: layer 0 in its separated form (S-term 60 x 480 x 32, T-term 54 x 288 x 32 MAC instead of the
     // dense 972 x 864 x 32), then the valid convolutions 18x3x18 -> 16x1x16 -> 14 -> 12 -> 10 -> 8 -> 6 -> 4 -> 2 -> 1:
-    // 2 * sum(out positions * K * Cout) = 0.109 GFLOP.  The dense algorithmic count of SURVEY 8d is 0.160 GFLOP/match
+    // 2 * sum(out positions * K * Cout), layers 2..5 with 16 products per 2 x 2 output tile (Winograd) = 0.0676 GFLOP.  The dense algorithmic count of SURVEY 8d is 0.160 GFLOP/match
     // (bench.py reports both; the roofline fraction is taken on the executed count).
     static const double macs_per_match =
         60.0 * 480 * 32 + 54.0 * 288 * 32 + 256.0 * 864 * 64 +
