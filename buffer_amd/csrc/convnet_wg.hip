@@ -47,6 +47,9 @@
 #define WG_THREADS 256
 #define WG_BUF (WG_MAXC * WG_CS)
 #define WG_KSTEP (16 * WG_CS)  // bytes between k-steps (4 channels)
+#ifndef WG_PIN_FOLD
+#define WG_PIN_FOLD 1         // pin the folded outputs after every pass (0: k_cyl_net_wg leaves them to the compiler, +0.8 %)
+#endif
 #define WG_BLOCKS 20          // filter components per (input, output) channel: 16 Winograd + 4 of the bottom-row form
 #ifdef WG_EXP_NOBAR
 #define WG_SYNC() __builtin_amdgcn_sched_barrier(0)
@@ -250,7 +253,7 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
 // -- three accumulator clears and half of the output-transform adds less per N-tile.  The bias (when this wavefront carries
 // it: K-split layers add it once) enters component (1, 1)'s accumulator before pass 1: F_1, F_2, F_3 then carry it once in
 // both columns.
-template <int NN, int T0, int T1, unsigned KSTEP = WG_KSTEP>
+template <int NN, int T0, int T1, unsigned KSTEP = WG_KSTEP, bool FENCE = false>
 __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_after, unsigned lofs, int niter,
                                          int wstride, unsigned pstride, const float* __restrict__ bias_lane, wgf4 (&W)[NN][2], wgf4 (&Y)[NN][3][2][2])
 {
@@ -283,6 +286,7 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
         }
         constexpr int ICHAIN = (INEXT != 0 && wg_chains(I, T0, T1)) ? INEXT : -1;      // the next row component of this round, if any
         wg_pass<I, NN, T0, T1, wg_chains(I - 1, T0, T1), ICHAIN, false, KSTEP>(RA, rs, wp + I * pstride, INEXT == 0 ? wp_after : wp + (I + 1) * pstride, lofs, niter, wstride, W, acc, D);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);     // k_cost_net: the fold is not mixed into the next pass's start (spills)
 #pragma unroll
         for (int n = 0; n < NN; n++)
 #pragma unroll
@@ -301,6 +305,12 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
                 }
                 else if constexpr (I == 2) { Y[n][t][0][0] = f0; Y[n][t][0][1] = f1; }
                 else { Y[n][t][1][0] -= f0; Y[n][t][1][1] -= f1; }
+                // the folded values exist HERE: left free, the compiler sinks these sums below the next pass's loop and carries
+                // the accumulators of this pass (twice the registers) through it instead -- copies and, in k_cost_net, spills
+                if constexpr (FENCE || WG_PIN_FOLD) {
+                    if constexpr (I == 2) asm volatile("" : "+v"(Y[n][t][0][0]), "+v"(Y[n][t][0][1]));
+                    else asm volatile("" : "+v"(Y[n][t][1][0]), "+v"(Y[n][t][1][1]));
+                }
             }
     };
     run(integral_constant<int, 0>{});

@@ -335,11 +335,11 @@ __device__ __forceinline__ void cw_layer(float* __restrict__ map, const float* _
     wgf4 W[NN][2];
     wg_first_weights<NN, 0, 2>(rs, wp, lofs, wstride, W);
     wgf4 Y[NN][3][2][2];
-    wg_round<NN, 0, MT, KSTEP>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bl, W, Y);
+    wg_round<NN, 0, MT, KSTEP, true>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bl, W, Y);
     wgf4 Y2[NN][3][2][2];
     if constexpr (MT2 > 0) {
         rows(t0 + MT, RA[0]);
-        wg_round<NN, 0, 1, KSTEP>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bl, W, Y2);
+        wg_round<NN, 0, 1, KSTEP, true>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bl, W, Y2);
     }
     __syncthreads();                         // every wavefront has finished reading the map
 #pragma unroll
