@@ -73,6 +73,7 @@ _SIGNATURES = {
     "buf_cylindrical_net_wg": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_winograd_tile_weights": (_i, [_vp, _i, _i, _vp]),
     "buf_winograd_group": (_i, [_i, _i]),
+    "buf_cost_winograd_group": (_i, [_i]),
     "buf_winograd_tile_filters": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "buf_voxel_downsample_ws_bytes": (_sz, [_i, _i64]),
     "buf_voxel_downsample": (_i, [_vp, _vp, _i, _i, C.c_double, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),

@@ -313,7 +313,12 @@ __device__ __forceinline__ void cw_layer(float* __restrict__ map, const float* _
 {
     static_assert(MT >= 1 && MT <= 2 && MT2 >= 0 && MT2 <= 1 && RS % 2 == 0 && CS % 2 == 0, "");
     constexpr unsigned KSTEP = 16u * CS;
+#ifdef CW_EXP_SAMEW
+    constexpr int k4 = CIN / 4;
+    const int wstride = (int)(blockDim.x >> 10);              // timing experiment: a run-time zero (every k-step fetches the same KB: L1 hits)
+#else
     constexpr int k4 = CIN / 4, wstride = 256 * NN;
+#endif
     int lane = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane));
     const int li = lane & 15, lk = lane >> 4;
@@ -349,6 +354,12 @@ __device__ __forceinline__ void cw_layer(float* __restrict__ map, const float* _
         if constexpr (MT2 > 0) cw_store_tile<HIN, TYPM, RSO, CSO, POSMAJOR>(Y2[n][0], t0 + MT, ng * NN + n, map, li, lk);
     }
 }
+#ifndef CW_NN2
+#define CW_NN2 2          // N-tiles per wavefront in layers 2 and 4 (the filter tiling follows: buf_cost_winograd_group)
+#endif
+#ifndef CW_NN4
+#define CW_NN4 2
+#endif
 #define CW_CS1 272        // channel strides of the maps after layers 1, 2 (= 16 mod 64: the two tile rows of an M-tile leave the
 #define CW_CS2 208        //   banks 16..31 / 48..63 to the half-wave's second channel), 3 and 4 (= 32 mod 64)
 #define CW_CS3 160
@@ -476,13 +487,21 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
 
     // ---- phase B: layers 2..6 rewrite the buffer in place; the three tiny last layers hop through its free parts -----------
     //                                 in: size rows stride | tile rows per M-tile | Cin | N-tiles, M-tiles per wavefront | out
+#if CW_NN2 == 4
+    cw_layer<16, 16, CW_CS1, 2, 64, 4, 1, 0, 14, CW_CS2, false>(bufA, P.wt[2], P.bias[2], 0, w);                  // 16x16 -> 14x14, 64 ch: M-tile w, all N-tiles
+#else
     cw_layer<16, 16, CW_CS1, 2, 64, 2, 2, 0, 14, CW_CS2, false>(bufA, P.wt[2], P.bias[2], w & 1, 2 * (w >> 1));   // 16x16 -> 14x14, 64 ch
+#endif
     __syncthreads();
     CV_STAMP_AT(3)
     cw_layer<14, 14, CW_CS2, 2, 64, 2, 2, 1, 12, CW_CS3, false>(bufA, P.wt[3], P.bias[3], w, 0);                  // -> 12x12, 128 ch
     __syncthreads();
     CV_STAMP_AT(4)
+#if CW_NN4 == 4
+    cw_layer<12, 12, CW_CS3, 3, 128, 4, 1, 0, 12, CW_CS3, false>(bufA, P.wt[4], P.bias[4], w & 1, w >> 1);        // -> 10x10 (rows of 12): N-tile quad, one M-tile
+#else
     cw_layer<12, 12, CW_CS3, 3, 128, 2, 2, 0, 12, CW_CS3, false>(bufA, P.wt[4], P.bias[4], w, 0);                 // -> 10x10 (rows of 12)
+#endif
     __syncthreads();
     CV_STAMP_AT(5)
     cw_layer<10, 12, CW_CS3, 4, 128, 1, 1, 0, 0, CV_C64, true>(bufA, P.wt[5], P.bias[5], w, 0);                   // -> 8x8, position-major
@@ -510,6 +529,12 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
         for (int d = WAVE / 2; d > 0; d >>= 1) { se += __shfl_xor(se, d, WAVE); sw += __shfl_xor(sw, d, WAVE); }
         if (lane == 0) ind_out[match] = sw / se;
     }
+}
+
+// N-tiles per group in the Winograd filter tiling of layer l (2..5): what buf_winograd_tile_filters is to be called with
+extern "C" int buf_cost_winograd_group(int layer)
+{
+    return layer == 2 ? CW_NN2 : layer == 3 ? 2 : layer == 4 ? CW_NN4 : layer == 5 ? 1 : 0;
 }
 
 static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const float* const* wt_host, const float* const* bias_host,

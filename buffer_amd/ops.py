@@ -610,7 +610,7 @@ class CostVolumeNet:
                 continue
             if 2 <= i <= 5:                               # the (3,1,3) layers 16 -> 14 -> 12 -> 10 -> 8 run in the Winograd domain
                 assert tuple(w.shape[2:]) == (3, 1, 3), w.shape
-                tiled = winograd_tile_weights(np.ascontiguousarray(w[:, :, :, 0, :]), ng=(1 if i == 5 else 2), blocks=4)
+                tiled = winograd_tile_weights(np.ascontiguousarray(w[:, :, :, 0, :]), ng=_lib.lib().buf_cost_winograd_group(i), blocks=4)
                 self.wt.append(torch.from_numpy(tiled).to(device))
                 self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
                 continue

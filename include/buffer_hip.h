@@ -267,12 +267,13 @@ int     buf_descriptor_head(const float* y, int npatch, const float* params, flo
  * pointers, BN folded; layers 1 and 6..9: weights W[K][Cout] with K = ((dn*KH + dk)*KW + dl)*Cin + c, the last layer (20
  * outputs) zero-padded to 32 columns / biases.  Layers 2..5 (the (3,1,3) filters [Cout,Cin,3(dn),3(dl)] over the 16 x 16 ..
  * 10 x 10 maps) run in the Winograd F(2x2,3x3) domain: buf_winograd_tile_filters(w, Cout, Cin, ng, 4, out) with
- * ng = 2 N-tiles per group for layers 2..4 and 1 for layer 5 (16*Cout*Cin floats each).  Layer 0 is linear in cost = S(shifted) - T and is passed SEPARATED
+ * ng = buf_cost_winograd_group(layer) N-tiles per group (16*Cout*Cin floats each).  Layer 0 is linear in cost = S(shifted) - T and is passed SEPARATED
  * (exact up to fp32 re-association): wt_host[0] = Ws[480][32] followed by Wt[288][32],
  *   Ws[(dk*5 + e+2)*32 + c][o] = sum over dl-dn=e of W0[o][c][dn][dk][dl],  Wt[(dk*3 + dl)*32 + c][o] = sum over dn of W0
  * (buffer_amd.ops.separate_cost_layer0).  Every [K][Cout] matrix is stored in the MFMA B-operand tiling: blocks
  * [K/16][Cout/16] of 256 floats, block (g, n) laid out [lk 0..3][li 0..15][p 0..3] = W[16g + 4lk + p][16n + li]
  * (buffer_amd.ops.mfma_tile_weights(w, lk_major=True) is the host-side re-layout). */
+int     buf_cost_winograd_group(int layer);           /* host only: ng of layers 2..5 (0 for the others) */
 int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
                             const float* const* bias_host, float* ind_out, void* stream);
 /* The same with the row gather of models/BUFFER.py:285-292 (ss_equi = src_equi[s_mids], [:, :, 1:ele_n-1]) fused in:
