@@ -50,7 +50,7 @@
 #ifndef WG_PIN_FOLD
 #define WG_PIN_FOLD 1         // pin the folded outputs after every pass (0: k_cyl_net_wg leaves them to the compiler, +0.8 %)
 #endif
-#define WG_BLOCKS 20          // filter components per (input, output) channel: 16 Winograd + 4 of the bottom-row form
+#define WG_BLOCKS 16          // filter components per (input, output) channel
 #ifdef WG_EXP_NOBAR
 #define WG_SYNC() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -169,9 +169,9 @@ __device__ __forceinline__ wgf4 wg_ldw(__amdgpu_buffer_rsrc_t rs, unsigned unifo
 // Weights: W[n][k-step & 1], a ring of TWO k-steps per N-tile -- the registers of a k-step are reloaded with the k-step two
 // further on (of this pass, or of whatever runs next: wp_next) as soon as its MFMAs are through, so every load is issued two
 // k-steps before its use with half the registers of a whole-iteration buffer (the paired layers were spilling their outputs).
-template <int I, int NN, int T0, int T1, bool PRIMED, int INEXT, bool BOT = false, unsigned KSTEP = WG_KSTEP>
+template <int I, int NN, int T0, int T1, bool PRIMED, int INEXT, bool BOT = false, unsigned KSTEP = WG_KSTEP, bool DIFF = false>
 __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_next, unsigned lofs, int niter,
-                                        int wstride, wgf4 (&W)[NN][2], wgf4 (&acc)[NN][3][4], wgf2 (&D)[2][4])
+                                        int wstride, wgf4 (&W)[NN][2], wgf4 (&acc)[NN][3][4], wgf2 (&D)[2][4], wgf4 (*Wb)[2] = nullptr, unsigned bofs = 0)
 {
     constexpr int A1 = BOT ? I : wg_a1(I), A2 = BOT ? I : wg_a2(I);      // bottom-row form: I is the filter row = window row, no second row
     constexpr int TE = BOT ? T1 : wg_te(I, T1);
@@ -225,17 +225,36 @@ __device__ __forceinline__ void wg_pass(unsigned (&RA)[3][4], __amdgpu_buffer_rs
                     WG_LOAD(BOT, D[s & 1], P[t2][0], P[t2][1], ((g - 4 * NT) / NT) * KSTEP)
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DIFF) {                                // the filter block is the difference of two stored ones (wg_round_bottom)
+                wgf4 wd[NN];
 #pragma unroll
-            for (int n = 0; n < NN; n++)
+                for (int n = 0; n < NN; n++)
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][kk & 1][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
+                    for (int j = 0; j < 4; j++) wd[n][j] = wg_sub(W[n][kk & 1][j], Wb[n][kk & 1][j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < NN; n++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[n][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NN; n++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[n][t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[n][kk & 1][j], V[s & 1][j], acc[n][t][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             WG_XFORM((s + 1) & 1)
             if (s % NT == NT - 1) {                              // k-step kk is through: its registers take the k-step two further on
 #pragma unroll
                 for (int n = 0; n < NN; n++)
                     W[n][kk & 1] = kk < 2 ? wg_ldw(rs, wcur + n * 256 + (kk + 2) * wstride, lofs) : wg_ldw(rs, wn + n * 256 + (kk - 2) * wstride, lofs);
+                if constexpr (DIFF) {                            // (past the pass: the same offset behind whatever runs next -- unused, in bounds)
+#pragma unroll
+                    for (int n = 0; n < NN; n++)
+                        Wb[n][kk & 1] = kk < 2 ? wg_ldw(rs, wcur + bofs + n * 256 + (kk + 2) * wstride, lofs) : wg_ldw(rs, wn + bofs + n * 256 + (kk - 2) * wstride, lofs);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -323,8 +342,10 @@ __device__ __forceinline__ void wg_round(unsigned (&RA)[3][4], __amdgpu_buffer_r
 // exist, so its one output row is the plain two-tap form in elevation
 //     y[6] = A^T-columns of sum_c ( colB(d[5]) (.) colG(g[0]) + colB(d[6]) (.) colG(g[1]) ),
 // two passes of four column components (8 tile-components instead of the 12 the row components 0..2 took, and no row
-// combination in the input transform).  colG(g[0]) is the Winograd block i = 0; colG(g[1]) = U_1 - U_2 is a fifth block of
-// the tiling.  The four accumulators run through both taps; the bias starts in component 1.
+// combination in the input transform).  colG(g[0]) is the Winograd block i = 0; colG(g[1]) = U_1 - U_2 is formed in registers
+// from the blocks 1 and 2 as they arrive (4 subtractions per N-tile and k-step, a second weight ring): stored as a fifth
+// block it made the filter set 3.8 MB -- more than the 4 MB L2 of an XCD holds beside the activation stream, and the kernel's
+// HBM-side traffic went from 47 to 85 KB per patch.  The four accumulators run through both taps; the bias starts in component 1.
 template <int NN>
 __device__ __forceinline__ void wg_round_bottom(unsigned (&RA)[3][4], __amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned wp_after, unsigned lofs, int niter,
                                                 int wstride, unsigned pstride, const float* __restrict__ bias_lane, wgf4 (&W)[NN][2], wgf4 (&Y)[NN][3][2][2])
@@ -338,8 +359,13 @@ __device__ __forceinline__ void wg_round_bottom(unsigned (&RA)[3][4], __amdgpu_b
 #pragma unroll
         for (int j = 0; j < 4; j++)
             acc[n][2][j] = (j == 1 && bias_lane) ? *reinterpret_cast<const wgf4*>(bias_lane + n * 16) : (wgf4){ zero, zero, zero, zero };
-    wg_pass<0, NN, 2, 3, false, 1, true>(RA, rs, wp, wp + 4 * pstride, lofs, niter, wstride, W, acc, D);
-    wg_pass<1, NN, 2, 3, true, -1, true>(RA, rs, wp + 4 * pstride, wp_after, lofs, niter, wstride, W, acc, D);
+    wgf4 Wb[NN][2];                                             // block 2's first two k-steps (block 1's arrive through tap 0's look-ahead)
+#pragma unroll
+    for (int n = 0; n < NN; n++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) Wb[n][k] = wg_ldw(rs, wp + 2 * pstride + n * 256 + k * wstride, lofs);
+    wg_pass<0, NN, 2, 3, false, 1, true>(RA, rs, wp, wp + pstride, lofs, niter, wstride, W, acc, D);
+    wg_pass<1, NN, 2, 3, true, -1, true, WG_KSTEP, true>(RA, rs, wp + pstride, wp_after, lofs, niter, wstride, W, acc, D, Wb, pstride);
 #pragma unroll
     for (int n = 0; n < NN; n++) {
         Y[n][2][0][0] = acc[n][2][0] + acc[n][2][1] + acc[n][2][2];
@@ -369,6 +395,8 @@ __device__ __forceinline__ void wg_store_tile(const wgf4 (&Yt)[2][2], int t, int
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const float v0 = fmaxf(Yt[u][0][r], lo), v1 = fmaxf(Yt[u][1][r], lo);
+                        // (plain stores: the L2 combines these 8-byte pieces into lines; as non-temporal stores they left as partial
+                        // writes, 38 instead of 17.5 KB of WRITE_SIZE per patch)
                         *reinterpret_cast<wgf2*>(out_glb + (size_t)(n0 + r) * 140 + row * 20 + 2 * tx) = (wgf2){ v0, v1 };
                     }
                 }
@@ -646,13 +674,12 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
 
 
 // Host helper: filters w [Cout][Cin][3][3] (BN folded) -> U = G g G^T in fp64, rounded once, in the kernel's A-operand tiling
-//     out[20 * Cout * Cin] = [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk]       (i = 0..4)
-// where block i = 4 holds g[1] G^T = U_1 - U_2, the second elevation tap of the bottom-row form (wg_round_bottom),
+//     out[16 * Cout * Cin] = [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk]
 // with N-groups of NG = 2 N-tiles for 128 output channels (a wavefront owns a pair there) and NG = 1 otherwise: the
 // k-steps of a wavefront follow each other in memory (round 2 had the N-tile inside the k-step: every 1 KB fetch of a
 // wavefront then sat on another 4-8 KB page, and the filter stream cost 8 % of the kernel in translation misses).  No device work.
-// General form: N-groups of ng N-tiles, nblk = 4 (the Winograd components only: k_cost_net's unpadded layers) or 5 blocks;
-// out[4 nblk * Cout * Cin].
+// General form: N-groups of ng N-tiles; nblk = 4, or 5 with g[1] G^T (= U_1 - U_2, the filter row a window that ends in the
+// padding sees: the kernels form it in registers) as block 4; out[4 nblk * Cout * Cin].
 extern "C" int buf_winograd_tile_filters(const float* w_host, int cout, int cin, int ng, int nblk, float* out_host)
 {
     BUF_REQUIRE(w_host && out_host, BUF_EINVAL, "buf_winograd_tile_filters: null argument");

@@ -389,8 +389,9 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
         const float* b = t_eq + (P.t_rows ? (size_t)P.t_rows[match] * P.row_floats + P.skip_floats : (size_t)match * 3200);
         for (int i = tid; i < 800; i += CV_THREADS) {
             const int c = i / 25, rem = i - c * 25, k = rem / 5, l0 = (rem - k * 5) * 4;
-            const cvx4 sv = *reinterpret_cast<const cvx4*>(a + c * P.chan_floats + rem * 4);      // 100 contiguous floats per channel
-            const cvx4 tv = *reinterpret_cast<const cvx4*>(b + c * P.chan_floats + rem * 4);
+            // (read once: streamed past the L2, which is for the 2.9 MB of filters every workgroup walks)
+            const cvx4 sv = __builtin_nontemporal_load(reinterpret_cast<const cvx4*>(a + c * P.chan_floats + rem * 4));      // 100 contiguous floats per channel
+            const cvx4 tv = __builtin_nontemporal_load(reinterpret_cast<const cvx4*>(b + c * P.chan_floats + rem * 4));
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int l = l0 + q;

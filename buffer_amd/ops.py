@@ -508,12 +508,11 @@ def mfma_tile_weights(wt, lk_major=False):
     return np.ascontiguousarray(np.transpose(t, perm), dtype=np.float32).reshape(-1)              # [g, n, lk, li, p]
 
 
-def winograd_tile_weights(w, ng=None, blocks=5):
+def winograd_tile_weights(w, ng=None, blocks=4):
     """[Cout, Cin, 3, 3] -> the F(2x2, 3x3) filter transform U = G g G^T (fp64, rounded once to fp32) in the A-operand tiling
     of csrc/convnet_wg.hip: [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk], N-groups of NG = 2
-    N-tiles for 128 output channels and 1 otherwise; i = 0..4, the fifth block being g[1] G^T = U_1 - U_2 (the second elevation
-    tap of the kernel's bottom-row form).  20 * Cout * Cin floats (buf_winograd_tile_weights is the same function on the C side).
-    ng / blocks: the general form (buf_winograd_tile_filters) -- csrc/costnet.hip's unpadded layers take blocks = 4."""
+    N-tiles for 64 / 128 output channels and 1 otherwise.  16 * Cout * Cin floats (buf_winograd_tile_weights is the same function
+    on the C side).  ng / blocks: the general form (buf_winograd_tile_filters); blocks = 5 appends g[1] G^T = U_1 - U_2."""
     cout, cin = w.shape[0], w.shape[1]
     assert cin % 4 == 0 and cout % 16 == 0
     if ng is None:
@@ -610,7 +609,7 @@ class CostVolumeNet:
                 continue
             if 2 <= i <= 5:                               # the (3,1,3) layers 16 -> 14 -> 12 -> 10 -> 8 run in the Winograd domain
                 assert tuple(w.shape[2:]) == (3, 1, 3), w.shape
-                tiled = winograd_tile_weights(np.ascontiguousarray(w[:, :, :, 0, :]), ng=_lib.lib().buf_cost_winograd_group(i), blocks=4)
+                tiled = winograd_tile_weights(np.ascontiguousarray(w[:, :, :, 0, :]), ng=_lib.lib().buf_cost_winograd_group(i))
                 self.wt.append(torch.from_numpy(tiled).to(device))
                 self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
                 continue

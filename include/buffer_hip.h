@@ -244,11 +244,11 @@ int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, 
  * x f32[np,48,140] (= [np,16,3,7,20]) -> y f32[np,32,140] (= [np,32,7,20]); bias_host[l]: DEVICE pointers to [Cout].
  * wt_host[l]: DEVICE pointers to U = G g G^T of the BN-folded filters ([Cout,Cin,3,3]; layer 0: Cin = c16*3 + depth) in the
  * tiling [N-group][i][k-step][n2][lk][li][j] = U[i][j][16 (NG g + n2) + li][4 ks + lk] with NG = buf_winograd_group(Cin, Cout)
- * N-tiles per group (the N-tiles one wavefront owns: its k-steps are contiguous in memory) and i = 0..4, block 4 being
- * g[1] G^T (= U_1 - U_2: the bottom tile row, whose window ends in the elevation padding, runs as a two-tap form in
- * elevation -- 8 instead of 12 matrix instructions), as buf_winograd_tile_weights lays them out (fp64 on the host).  Cin a multiple of 16 (of 32 for Cout 128), Cout in {32, 64, 128}, last layer 32. */
+ * N-tiles per group (the N-tiles one wavefront owns: its k-steps are contiguous in memory), as buf_winograd_tile_weights lays
+ * them out (fp64 on the host; the bottom tile row, whose window ends in the elevation padding, runs as a two-tap form in
+ * elevation -- 8 instead of 12 matrix instructions -- on U_0 and U_1 - U_2, the latter formed in registers).  Cin a multiple of 16 (of 32 for Cout 128), Cout in {32, 64, 128}, last layer 32. */
 int     buf_winograd_group(int cin, int cout);                                                   /* host only: NG of a layer */
-int     buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host);   /* host only: [Cout,Cin,3,3] -> 20*Cout*Cin floats */
+int     buf_winograd_tile_weights(const float* w_host, int cout, int cin, float* out_host);   /* host only: [Cout,Cin,3,3] -> 16*Cout*Cin floats */
 int     buf_winograd_tile_filters(const float* w_host, int cout, int cin, int ng, int nblk, float* out_host);
                                                    /* host only: the same tiling with N-groups of ng and nblk = 4 | 5 blocks -> 4*nblk*Cout*Cin floats */
 int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,

@@ -175,11 +175,12 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
     cin, cout = 8, 16
     w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
     x = rng.standard_normal((cin, 7, 20))
-    U = ops.winograd_tile_weights(w).reshape(cout // 16, 5, cin // 4, 4, 16, 4)          # [n, i, ks, lk, li, j]
+    U = ops.winograd_tile_weights(w, blocks=5).reshape(cout // 16, 5, cin // 4, 4, 16, 4)          # [n, i, ks, lk, li, j]
     U = np.transpose(U, (1, 5, 0, 4, 2, 3)).reshape(5, 4, cout, cin).astype(np.float64)   # [i, j, Cout, Cin]
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
     assert np.abs(U[:4] - np.einsum('ia,ocab,jb->ijoc', G, w.astype(np.float64), G)).max() < 1e-6
-    # block 4 = the filter's middle row, column-transformed = U_1 - U_2: the second tap of the bottom-row form
+    # optional block 4 = the filter's middle row, column-transformed = U_1 - U_2: the second tap of the kernel's bottom-row form
+    # (formed in registers from blocks 1 and 2 there)
     assert np.abs(U[4] - np.einsum('ocb,jb->joc', w[:, :, 1].astype(np.float64), G)).max() < 1e-6
     assert np.abs(U[4] - (U[1] - U[2])).max() < 1e-6
     Ub, U = U[4], U[:4]
@@ -206,7 +207,7 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
     import ctypes as C
     from buffer_amd import _lib
     w2 = np.ascontiguousarray(rng.standard_normal((32, 16, 3, 3)).astype(np.float32))
-    got = np.empty(20 * 32 * 16, np.float32)
+    got = np.empty(16 * 32 * 16, np.float32)
     rc = _lib.lib().buf_winograd_tile_weights(w2.ctypes.data_as(C.c_void_p), 32, 16, got.ctypes.data_as(C.c_void_p))
     assert rc == 0 and np.array_equal(got, ops.winograd_tile_weights(w2))
     assert _lib.lib().buf_winograd_tile_weights(w2.ctypes.data_as(C.c_void_p), 30, 16, got.ctypes.data_as(C.c_void_p)) == -1
@@ -214,9 +215,14 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
     assert _lib.lib().buf_winograd_group(32, 128) == 2 and _lib.lib().buf_winograd_group(48, 64) == 2 and _lib.lib().buf_winograd_group(64, 32) == 1
     w3 = np.ascontiguousarray(rng.standard_normal((128, 32, 3, 3)).astype(np.float32))
     t3 = ops.winograd_tile_weights(w3)
-    U3 = np.transpose(t3.reshape(4, 5, 8, 2, 4, 16, 4), (1, 6, 0, 3, 5, 2, 4)).reshape(5, 4, 128, 32)
-    assert np.abs(U3[:4] - np.einsum('ia,ocab,jb->ijoc', G, w3.astype(np.float64), G)).max() < 1e-6
-    assert np.abs(U3[4] - np.einsum('ocb,jb->joc', w3[:, :, 1].astype(np.float64), G)).max() < 1e-6
-    got3 = np.empty(20 * 128 * 32, np.float32)
+    U3 = np.transpose(t3.reshape(4, 4, 8, 2, 4, 16, 4), (1, 6, 0, 3, 5, 2, 4)).reshape(4, 4, 128, 32)
+    assert np.abs(U3 - np.einsum('ia,ocab,jb->ijoc', G, w3.astype(np.float64), G)).max() < 1e-6
+    t5 = ops.winograd_tile_weights(w3, blocks=5)
+    U5 = np.transpose(t5.reshape(4, 5, 8, 2, 4, 16, 4), (1, 6, 0, 3, 5, 2, 4)).reshape(5, 4, 128, 32)
+    assert np.array_equal(U5[:4], U3) and np.abs(U5[4] - np.einsum('ocb,jb->joc', w3[:, :, 1].astype(np.float64), G)).max() < 1e-6
+    got5 = np.empty(20 * 128 * 32, np.float32)
+    assert _lib.lib().buf_winograd_tile_filters(w3.ctypes.data_as(C.c_void_p), 128, 32, 2, 5, got5.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(got5, t5)
+    got3 = np.empty(16 * 128 * 32, np.float32)
     assert _lib.lib().buf_winograd_tile_weights(w3.ctypes.data_as(C.c_void_p), 128, 32, got3.ctypes.data_as(C.c_void_p)) == 0
     assert np.array_equal(got3, t3)
