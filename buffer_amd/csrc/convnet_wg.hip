@@ -517,6 +517,53 @@ __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* 
     }
 }
 
+// The same 32-channel layer with the M-split pair form inside each K half (WG_KSPLIT_PAIRS): wavefront (h, half) owns BOTH N-tiles
+// for the Winograd M-tile h and the bottom row of N-tile h, over its half of K -- one transform per 8 MFMAs instead of 4, the same
+// ten quads of partial sums to hand over.
+template <bool GLB>
+__device__ __forceinline__ void wg_layer_mksplit(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
+                                                 const float* __restrict__ bias, int cin, int cout, int relu, int w)
+{
+    int lane = threadIdx.x & (WAVE - 1);
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = w & 1, half = w >> 1;
+    const int k4 = cin >> 2, kn = k4 >> 1, k0 = half * kn, wstride = 512;
+    unsigned RA[3][4];
+    {
+        const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)act + (unsigned)k0 * WG_KSTEP;
+#pragma unroll
+        for (int a = 0; a < 4; a++) { RA[0][a] = wg_row_addr(act_addr, h, a, li, lk); RA[1][a] = RA[0][a]; RA[2][a] = wg_row_addr(act_addr, 2, a, li, lk); }
+    }
+    const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
+    const unsigned wp = (unsigned)k0 * wstride;                            // [pair 0][i][k-step][n2][lane][j]
+    const unsigned wpb = wp + (unsigned)h * 256;
+    const unsigned lofs = lane * 16;
+    const unsigned pstride = (unsigned)(k4 * wstride);
+    wgf4 Y[2][3][2][2];
+    wgf4 W2[2][2];
+    wg_first_weights<2, 0, 2>(rs, wp, lofs, wstride, W2);
+    wg_round<2, 0, 1>(RA, rs, wp, wpb, lofs, kn >> 2, wstride, pstride, half ? nullptr : bias + lk * 4, W2, Y);               // slot 0 = M-tile h
+    wgf4 W1[1][2] = { { W2[0][0], W2[0][1] } };
+    wgf4 Yb[1][3][2][2];
+    wg_round_bottom<1>(RA, rs, wpb, wpb, lofs, kn >> 2, wstride, pstride, half ? nullptr : bias + h * 16 + lk * 4, W1, Yb);
+    wgf4* slot = reinterpret_cast<wgf4*>(act + WG_XCH_C * WG_CS) + h * 640 + lane;                   // 10 x 64 float4 per wavefront pair
+    if (half) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) slot[q * 64] = Y[q >> 2][0][(q >> 1) & 1][q & 1];
+        slot[8 * 64] = Yb[0][2][0][0]; slot[9 * 64] = Yb[0][2][0][1];
+    }
+    WG_SYNC();                                       // partial sums are in place AND every wavefront has finished reading the input
+    if (!half) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) Y[q >> 2][0][(q >> 1) & 1][q & 1] += slot[q * 64];
+        Yb[0][2][0][0] += slot[8 * 64]; Yb[0][2][0][1] += slot[9 * 64];
+        wg_store_tile<GLB, 2>(Y[0][0], h, 0, relu, act, out_glb, li, lk);
+        wg_store_tile<GLB, 2>(Y[1][0], h, 1, relu, act, out_glb, li, lk);
+        wg_store_tile<GLB, 1>(Yb[0][2], 2, h, relu, act, out_glb, li, lk);
+    }
+}
+
 // One layer with 64 output channels (four N-tiles, four wavefronts): wavefront w owns the N-tile pair w & 1 for ONE of the
 // M-tiles 0, 1 (w >> 1) -- the transform of a step feeds 8 MFMAs, as in the 128-channel layers -- and the bottom-row form of
 // ONE N-tile of its pair: 32 + 8 = 40 matrix instructions per k-step for every wavefront, no partial sums to exchange.
@@ -556,7 +603,10 @@ __device__ __forceinline__ void wg_layer_msplit(float* __restrict__ act, const f
 // N-tiles per wavefront of a layer: 2 (the paired form below) or 1.  The filter tiling follows it (buf_winograd_tile_weights).
 // Pairs for the 64-channel layers too (two wavefronts per pair, K split between them, partial sums exchanged through the dead
 // half of the buffer) measured 1 % slower, before and after the filter stream became cheap: short K loops, a third barrier.
-__host__ __device__ constexpr int wg_group(int cin, int cout) { return cout >= 64 ? 2 : 1; }
+#ifndef WG_KSPLIT_PAIRS
+#define WG_KSPLIT_PAIRS 1
+#endif
+__host__ __device__ constexpr int wg_group(int cin, int cout) { return (cout >= 64 || WG_KSPLIT_PAIRS) ? 2 : 1; }
 
 // Outputs of M-tile T of both N-tiles of a pair -> accumulation registers (see wg_layer_pair)
 template <int T>
@@ -661,8 +711,14 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
         if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else if (cout == 64) {
             wg_layer_msplit(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-        } else if (l < WG_LAYERS - 1) wg_layer_ksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        }
+#if WG_KSPLIT_PAIRS
+        else if (l < WG_LAYERS - 1) wg_layer_mksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        else wg_layer_mksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+#else
+        else if (l < WG_LAYERS - 1) wg_layer_ksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
         else wg_layer_ksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+#endif
         WG_STAMP_AT(2 * l + 1)
         WG_SYNC();
         WG_STAMP_AT(2 * l + 2)
