@@ -36,8 +36,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32) = fp32 vector peak
 COST_NET_DENSE_FLOPS_PER_MATCH = 159994880.0      # 0.160 GFLOP/match, every layer as a dense convolution
-COST_NET_FLOPS_PER_MATCH = 67634176.0             # executed by csrc/costnet.hip: layer 0 separated into its S- and T-terms,
-#                                                   layers 2..5 in the Winograd domain (16 products per 2 x 2 output tile instead of 36)
+COST_NET_FLOPS_PER_MATCH = 51905536.0             # executed by csrc/costnet.hip: layer 0 separated into its S- and T-terms,
+#                                                   layers 1..5 in the Winograd domain (16 products per 2 x 2 output tile instead of 36)
 CYL_NET_EXECUTED_FRACTION = 40 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs the stack in the Winograd F(2x2,3x3) domain:
 #                                          40 MFMAs of 16x16x4 per (4 input channels, 16 output channels) instead of the
 #                                          9 x 140 x 4 x 16 MACs of the direct form = 0.508 of the dense count
@@ -164,8 +164,8 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
     other = [
         roof_entry(timed, 'cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
                    traffic_of(pmc, 'k_cost_net', matches),
-                   flops='executed count (0.0676 GFLOP/match: layer 0 separated exactly into an S-term and a T-term, 1.4 M MAC '
-                         'instead of 26.9 M; layers 2..5 as Winograd F(2x2,3x3) component GEMMs, 16.6 M MAC instead of 37.3 M); '
+                   flops='executed count (0.0519 GFLOP/match: layer 0 separated exactly into an S-term and a T-term, 1.4 M MAC '
+                         'instead of 26.9 M; layers 1..5 as Winograd F(2x2,3x3) component GEMMs, 22.9 M MAC instead of 51.5 M); '
                          'the dense count of SURVEY 8d is 0.160 GFLOP/match',
                    dense_equivalent_tflops=(COST_NET_DENSE_FLOPS_PER_MATCH * matches) / (timed['cost_net'][1] / max(timed['cost_net'][0], 1) * 1e-3) / 1e12),
         roof_entry(timed, 'grid_query', 'k_grid_query_wave (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,

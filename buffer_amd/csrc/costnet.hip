@@ -12,14 +12,16 @@
 //     Tterm[o][k'][l'] = sum_{c,dk,dl} Wt[o][c][dk][dl] T[c][k'+dk][l'+dl],          Wt        = sum_dn      W0[o][c][dn][dk][dl]
 // (the S-term of output (n',k',l') depends on (k', (l'-n') mod 20) only: 60 positions, K = 480; the T-term does not depend
 // on n': 54 positions, K = 288): 1.4 M MAC instead of the 26.9 M of the dense layer 0.  The two small maps are two MFMA GEMMs;
-// a layer-0 row is then relu(Smap + (b - Tmap)) formed by VALU, three rows (n') at a time into an LDS chunk that layer 1
-// consumes at once -- its output rows are accumulator tiles in registers (sliding window over n'), so the 124 KB layer-0
-// activation never exists either.  Layers 2..6 rewrite ONE 80 KB LDS buffer in place (two workgroups per CU); layers 2..5 -- the
-// unpadded 3x3 correlations 16 -> 14 -> 12 -> 10 -> 8, 69 % of the kernel's matrix instructions in the direct form -- run in the
-// Winograd F(2x2, 3x3) domain on the pass machinery of csrc/convnet_wg.hip (cw_layer below: 0.53 of their direct-form MFMAs).
+// a layer-0 row is then relu(Smap + (b - Tmap)) formed by VALU, six rows (n') at a time into an LDS chunk that layer 1
+// consumes at once, so the 124 KB layer-0 activation never exists either.  Layers 2..6 rewrite ONE 80 KB LDS buffer in place
+// (two workgroups per CU).  Layers 1..5 are unpadded 3 x 3 correlations over (n, l) -- layer 1 collapses k' (3 -> 1): its three
+// k' planes are 96 input channels; 18 -> 16 -> 14 -> 12 -> 10 -> 8; together 92 % of the kernel's matrix instructions in the
+// direct form -- and run in the Winograd F(2x2, 3x3) domain on the pass machinery of csrc/convnet_wg.hip (phase A.2 and cw_layer
+// below: 0.49 of their direct-form MFMAs).  -DCV_L1_DIRECT=1 keeps layer 1 in the direct form (three-row chunks, a sliding
+// window of accumulator rows: 0.83 of the matrix peak executed, and 14 % slower).
 // All GEMMs run on v_mfma_f32_16x16x4_f32 (fp32), weights (BN folded; [K][Cout] MFMA-tiled, or G g G^T in the Winograd tiling)
 // stream from L2.
-// FLOP accounting: bench.py credits the DENSE algorithmic count of SURVEY 8d (0.160 GFLOP/match); executed: 0.0676 GFLOP.
+// FLOP accounting: bench.py credits the DENSE algorithmic count of SURVEY 8d (0.160 GFLOP/match); executed: 0.0519 GFLOP.
 //
 // The LDS maps of the direct-form layers are POSITION-major, [position][channels + 4]: the four k-steps of a 16-channel group that a lane feeds
 // to the MFMA A operand (channels 16g + 4lk + 0..3 at its position) are one 16-byte ds_read_b128, and the +4 padding
@@ -104,8 +106,18 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
 // LDS regions of phase A inside the bufB half (floats):
 #define CVA_SP 0          // [5][24][36]  source map, azimuth padded circularly by 2 on both sides (column = l + 2)
 #define CVA_TP 4320       // [5][20][36]  target map
+#ifndef CV_L1_DIRECT
+#define CV_L1_DIRECT 0    // 1: layer 1 in the direct form (round 2 / early round 3: three-row chunks, sliding accumulator window)
+#endif
+#if CV_L1_DIRECT
 #define CVA_SM 7920       // [3][20][36]  Sterm[k'][j][o]
 #define CVA_TB 10080      // [3][18][36]  b[o] - Tterm[k'][l'][o]
+#else
+#define CVA_SM 16376      // the two maps sit at the END of the buffer: the six-row chunk of the Winograd layer 1 takes its start
+#define CVA_TB 18536      //   (18536 + 3 * 18 * 36 = 20480 = CV_BUF)
+#define CVA_XC 0          // [96 = (k', c)][CW_CSX]: six layer-0 rows n' of 18 columns, channel-major
+#define CW_CSX 112
+#endif
 #define CVA_R0 0          // [3][54][36]  chunk of three layer-0 rows (aliases SP/TP once the two small GEMMs are done)
 #define CVA_R1 12024      // second chunk buffer; ends at 17856 <= CV_BUF
 #define CVA_RROW (54 * CV_C32)
@@ -364,6 +376,24 @@ __device__ __forceinline__ void cw_layer(float* __restrict__ map, const float* _
 #define CW_CS2 208        //   banks 16..31 / 48..63 to the half-wave's second channel), 3 and 4 (= 32 mod 64)
 #define CW_CS3 160
 
+#if !CV_L1_DIRECT
+// six layer-0 rows n' = r0 .. r0+5 into the channel-major chunk: X[(k', o)][t * 18 + l'] = relu(Smap[k'][(l'-n') mod 20][o] + Tb[k'][l'][o])
+__device__ __forceinline__ void form_rows_cm(float* __restrict__ X, const float* __restrict__ SM, const float* __restrict__ TB, int r0)
+{
+    for (int i = threadIdx.x; i < 6 * 54 * 8; i += CV_THREADS) {
+        const int c4 = i & 7, rem = i >> 3, t = rem / 54, pos = rem - t * 54;
+        const int kq = pos / 18, lq = pos - kq * 18;
+        int j = lq - (r0 + t);
+        j = j < 0 ? j + 20 : j;
+        const cvx4 sv = *reinterpret_cast<const cvx4*>(SM + (kq * 20 + j) * CV_C32 + c4 * 4);
+        const cvx4 tv = *reinterpret_cast<const cvx4*>(TB + pos * CV_C32 + c4 * 4);
+        float* d = X + (kq * 32 + c4 * 4) * CW_CSX + t * 18 + lq;
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q * CW_CSX] = fmaxf(sv[q] + tv[q], 0.f);
+    }
+}
+#endif
+
 #ifdef CV_STAMP
 __device__ long long* cv_stamp_ptr;       // development build (-DCV_STAMP): s_memtime of wavefront 0 at the phase boundaries
 #define CV_STAMP_AT(SLOT) if (threadIdx.x == 0) cv_stamp_ptr[(size_t)blockIdx.x * 16 + (SLOT)] = __builtin_amdgcn_s_memtime();
@@ -432,6 +462,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
     __syncthreads();                         // SM/TB complete; SP/TP dead from here on (chunk buffer R0 takes their place)
     CV_STAMP_AT(1)
 
+#if CV_L1_DIRECT
     // ---- phase A.2: layer 1 over chunks of three layer-0 rows; wave w owns N-tile w (16 of the 64 output channels) ----
     // Row ra = 3j + t of chunk j feeds output row ra - dn through slab dn: accumulators acc5[ra - dn - (3j - 2)] hold the five
     // live output rows 3j-2 .. 3j+2; rows 3j-2, 3j-1, 3j are complete after chunk j.  Tiles whose output row falls outside 0..15
@@ -486,6 +517,43 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
 #undef CV_SLAB
     }
 
+#else
+    // ---- phase A.2: layer 1 in the Winograd domain.  Its 3 x 3 x 3 filter collapses k' (3 -> 1), so it is a 3 x 3 correlation over
+    // (n', l') with the three k' planes as input channels (96): 8 x 8 tiles of 2 x 2 outputs.  The 124 KB layer-0 map never
+    // exists: four chunks of six rows n' = 4j .. 4j+5 (two tile rows = one M-tile of 16 tiles) are formed channel-major one after
+    // the other; wave w owns N-tile w and holds its 4 x 16 output registers until the last chunk has been read.
+    // 64 tile rows x 16 components x 96 channels = 0.44 of the direct form's matrix instructions (3 456 -> 1 536 per wavefront).
+    {
+        int lane_ = threadIdx.x & (WAVE - 1);
+        asm volatile("" : "+v"(lane_));
+        const int li_ = lane_ & 15, lk_ = lane_ >> 4;
+        float* XC = bufB + CVA_XC;
+        constexpr unsigned KSTEP = 16u * CW_CSX;
+        const __amdgpu_buffer_rsrc_t rs = wg_weights(P.wt[1]);
+        const unsigned wp = (unsigned)w * (96 * 256);                      // [N-tile][i 0..3][k-step 0..23][lane][j]
+        const unsigned lofs = lane_ * 16;
+        unsigned RA[3][4];
+        {
+            const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)XC;
+#pragma unroll
+            for (int a = 0; a < 4; a++) RA[0][a] = RA[1][a] = RA[2][a] = base + 4u * (unsigned)(lk_ * CW_CSX + (2 * (li_ >> 3) + a) * 18 + 2 * (li_ & 7));
+        }
+        wgf4 W[1][2];
+        wg_first_weights<1, 0, 2>(rs, wp, lofs, 256, W);
+        wgf4 Y1[4][1][3][2][2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            form_rows_cm(XC, SM, TB, 4 * j);
+            __syncthreads();
+            wg_round<1, 0, 1, KSTEP, true>(RA, rs, wp, wp, lofs, 6, 256, 24u * 256u, P.bias[1] + w * 16 + lk_ * 4, W, Y1[j]);
+            __syncthreads();                 // the chunk may be overwritten
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) cw_store_tile<18, 2, 16, CW_CS1, false>(Y1[j][0][0], j, w, bufA, li_, lk_);
+        __syncthreads();
+        CV_STAMP_AT(2)
+    }
+#endif
     // ---- phase B: layers 2..6 rewrite the buffer in place; the three tiny last layers hop through its free parts -----------
     //                                 in: size rows stride | tile rows per M-tile | Cin | N-tiles, M-tiles per wavefront | out
 #if CW_NN2 == 4
@@ -535,7 +603,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
 // N-tiles per group in the Winograd filter tiling of layer l (2..5): what buf_winograd_tile_filters is to be called with
 extern "C" int buf_cost_winograd_group(int layer)
 {
-    return layer == 2 ? CW_NN2 : layer == 3 ? 2 : layer == 4 ? CW_NN4 : layer == 5 ? 1 : 0;
+    return layer == 1 ? (CV_L1_DIRECT ? 0 : 1) : layer == 2 ? CW_NN2 : layer == 3 ? 2 : layer == 4 ? CW_NN4 : layer == 5 ? 1 : 0;
 }
 
 static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const float* const* wt_host, const float* const* bias_host,
@@ -555,10 +623,10 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
     if (int rc = grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
     // EXECUTED flops per match: layer 0 in its separated form (S-term 60 x 480 x 32, T-term 54 x 288 x 32 MAC instead of the
     // dense 972 x 864 x 32), then the valid convolutions 18x3x18 -> 16x1x16 -> 14 -> 12 -> 10 -> 8 -> 6 -> 4 -> 2 -> 1:
-    // 2 * sum(out positions * K * Cout), layers 2..5 with 16 products per 2 x 2 output tile (Winograd) = 0.0676 GFLOP.  The dense algorithmic count of SURVEY 8d is 0.160 GFLOP/match
+    // 2 * sum(out positions * K * Cout), layers 1..5 with 16 products per 2 x 2 output tile (Winograd) = 0.0519 GFLOP.  The dense algorithmic count of SURVEY 8d is 0.160 GFLOP/match
     // (bench.py reports both; the roofline fraction is taken on the executed count).
     static const double macs_per_match =
-        60.0 * 480 * 32 + 54.0 * 288 * 32 + 256.0 * 864 * 64 +
+        60.0 * 480 * 32 + 54.0 * 288 * 32 + (CV_L1_DIRECT ? 256.0 * 864 * 64 : 16.0 * 64 * 96 * 64) +
         16.0 * (49.0 * 64 * 64 + 36.0 * 64 * 128 + 25.0 * 128 * 128 + 16.0 * 128 * 64) +        // layers 2..5: 16 components per 2 x 2 tile
         36.0 * 576 * 64 + 16.0 * 576 * 32 + 4.0 * 288 * 32 + 1.0 * 128 * 20;
     TimedSpan span;

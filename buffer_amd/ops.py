@@ -591,8 +591,8 @@ def separate_cost_layer0(w):
 
 class CostVolumeNet:
     """Device weights of CostNet re-laid for csrc/costnet.hip: layer 0 in its separated form (separate_cost_layer0: Ws then
-    Wt in one buffer), layers 1 and 6..9 as Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout], MFMA-tiled; layers 2..5 as U = G g G^T in the
-    Winograd tiling (winograd_tile_weights with 4 blocks; N-tile pairs for layers 2..4)."""
+    Wt in one buffer), layers 6..9 as Wt[((dn*KH+dk)*KW+dl)*Cin + c][Cout], MFMA-tiled; layers 1..5 as U = G g G^T in the
+    Winograd tiling (winograd_tile_weights; groups per buf_cost_winograd_group; layer 1 with its three k planes as channels)."""
 
     def __init__(self, layers, device):
         """layers: 10 x (w [Cout,Cin,KD,KH,KW] np.float32 with BN folded, b [Cout])"""
@@ -605,6 +605,13 @@ class CostVolumeNet:
                 assert tuple(w.shape) == (32, 32, 3, 3, 3), w.shape
                 tiled = np.concatenate([mfma_tile_weights(m, lk_major=True) for m in separate_cost_layer0(w)])
                 self.wt.append(torch.from_numpy(tiled).to(device))
+                self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
+                continue
+            if i == 1 and _lib.lib().buf_cost_winograd_group(1):
+                # layer 1 collapses k' (3 -> 1): a 3 x 3 correlation over (n', l') with the three k' planes as input channels
+                assert tuple(w.shape) == (64, 32, 3, 3, 3), w.shape
+                w2d = np.ascontiguousarray(np.transpose(w, (0, 3, 1, 2, 4)).reshape(64, 96, 3, 3))     # [o][(dk, c)][dn][dl]
+                self.wt.append(torch.from_numpy(winograd_tile_weights(w2d, ng=_lib.lib().buf_cost_winograd_group(1))).to(device))
                 self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
                 continue
             if 2 <= i <= 5:                               # the (3,1,3) layers 16 -> 14 -> 12 -> 10 -> 8 run in the Winograd domain

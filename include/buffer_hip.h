@@ -264,16 +264,17 @@ int     buf_descriptor_head(const float* y, int npatch, const float* params, flo
  * A13  CostVolume + CostNet (models/BUFFER.py:37-66, models/patchnet.py:88-147) fused on fp32 MFMA: the
  * [m,32,20,5,20] cost tensor is never built.  s_eq,t_eq f32[m,32,5,20] (elevation rows 1..ele_n-2 of the
  * equivariant maps) -> ind f32[m] (expected azimuth shift).  wt_host/bias_host: HOST arrays of 10 DEVICE
- * pointers, BN folded; layers 1 and 6..9: weights W[K][Cout] with K = ((dn*KH + dk)*KW + dl)*Cin + c, the last layer (20
- * outputs) zero-padded to 32 columns / biases.  Layers 2..5 (the (3,1,3) filters [Cout,Cin,3(dn),3(dl)] over the 16 x 16 ..
- * 10 x 10 maps) run in the Winograd F(2x2,3x3) domain: buf_winograd_tile_filters(w, Cout, Cin, ng, 4, out) with
- * ng = buf_cost_winograd_group(layer) N-tiles per group (16*Cout*Cin floats each).  Layer 0 is linear in cost = S(shifted) - T and is passed SEPARATED
+ * pointers, BN folded; layers 6..9: weights W[K][Cout] with K = ((dn*KH + dk)*KW + dl)*Cin + c, the last layer (20
+ * outputs) zero-padded to 32 columns / biases.  Layers 1..5 run in the Winograd F(2x2,3x3) domain as 3x3 correlations over
+ * (n, l): buf_winograd_tile_filters(w2d, Cout, Cin2d, ng, 4, out) with ng = buf_cost_winograd_group(layer) N-tiles per group
+ * (16*Cout*Cin2d floats each; a layer whose group is 0 takes the [K][Cout] form), w2d = the (3,1,3) filters [Cout,Cin,3(dn),3(dl)]
+ * for layers 2..5 and, for layer 1 (which collapses k: 3 -> 1), [64][dk*32 + c][dn][dl] = W1[o][c][dn][dk][dl], Cin2d = 96.  Layer 0 is linear in cost = S(shifted) - T and is passed SEPARATED
  * (exact up to fp32 re-association): wt_host[0] = Ws[480][32] followed by Wt[288][32],
  *   Ws[(dk*5 + e+2)*32 + c][o] = sum over dl-dn=e of W0[o][c][dn][dk][dl],  Wt[(dk*3 + dl)*32 + c][o] = sum over dn of W0
  * (buffer_amd.ops.separate_cost_layer0).  Every [K][Cout] matrix is stored in the MFMA B-operand tiling: blocks
  * [K/16][Cout/16] of 256 floats, block (g, n) laid out [lk 0..3][li 0..15][p 0..3] = W[16g + 4lk + p][16n + li]
  * (buffer_amd.ops.mfma_tile_weights(w, lk_major=True) is the host-side re-layout). */
-int     buf_cost_winograd_group(int layer);           /* host only: ng of layers 2..5 (0 for the others) */
+int     buf_cost_winograd_group(int layer);           /* host only: ng of layers 1..5 (0 for the others) */
 int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const float* const* wt_host,
                             const float* const* bias_host, float* ind_out, void* stream);
 /* The same with the row gather of models/BUFFER.py:285-292 (ss_equi = src_equi[s_mids], [:, :, 1:ele_n-1]) fused in:

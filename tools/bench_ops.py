@@ -104,7 +104,7 @@ if which == 'cost':
         cv(a, b)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 5
-    print(f'cost_net 2500 matches: {dt*1e3:.2f} ms  {2500*0.06763/dt/1e3:.1f} TFLOP/s executed ({2500*0.160/dt/1e3:.1f} dense-equivalent)')
+    print(f'cost_net 2500 matches: {dt*1e3:.2f} ms  {2500*0.05191/dt/1e3:.1f} TFLOP/s executed ({2500*0.160/dt/1e3:.1f} dense-equivalent)')
 if which == 'prep':
     from buffer_amd import preprocess
     sample = synth.make_pair(seed=0)

@@ -26,4 +26,4 @@ for _ in range(5):
     cv(a, b)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 5
-print(f'cost_net: {M} matches {dt*1e3:.2f} ms  {M*0.06763/dt/1e3:.1f} TFLOP/s executed ({M*0.160/dt/1e3:.1f} dense-equivalent)')
+print(f'cost_net: {M} matches {dt*1e3:.2f} ms  {M*0.05191/dt/1e3:.1f} TFLOP/s executed ({M*0.160/dt/1e3:.1f} dense-equivalent)')

@@ -31,7 +31,7 @@ cfg = bench['config']
 pairs = cfg['pairs_per_step_per_gpu']
 patches = 2 * cfg['keypoints_per_fragment'] * pairs
 cost = [o for o in bench['roofline_other'] if o['kernel'].startswith('k_cost_net')][0]
-matches = cost['avg_algorithmic_flops'] / 67634176.0
+matches = cost['avg_algorithmic_flops'] / 51905536.0
 # unit of work per launch and the algorithmic bytes per unit (SURVEY 8d formulas)
 units = {
     'k_cyl_net_wg': (patches, 'patch', 48 * 140 * 4 + 32 * 140 * 4),
