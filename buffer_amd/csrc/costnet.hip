@@ -115,8 +115,11 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
 #else
 #define CVA_SM 16376      // the two maps sit at the END of the buffer: the six-row chunk of the Winograd layer 1 takes its start
 #define CVA_TB 18536      //   (18536 + 3 * 18 * 36 = 20480 = CV_BUF)
-#define CVA_XC 0          // [96 = (k', c)][CW_CSX]: six layer-0 rows n' of 18 columns, channel-major
-#define CW_CSX 112
+#define CVA_XC 0          // [96 = (k', c)][CW_CSX]: six layer-0 rows n' of 18 columns in rows of CW_RSX, channel-major
+#ifndef CW_RSX
+#define CW_RSX 18         // (rows of 24 and channels 160 apart -- the two tile rows of an M-tile and the two channels of a half-wave on
+#define CW_CSX 112        //   the four quarters of the 64 banks, conflict-free -- measured +-0 against this compact layout)
+#endif
 #endif
 #define CVA_R0 0          // [3][54][36]  chunk of three layer-0 rows (aliases SP/TP once the two small GEMMs are done)
 #define CVA_R1 12024      // second chunk buffer; ends at 17856 <= CV_BUF
@@ -387,7 +390,7 @@ __device__ __forceinline__ void form_rows_cm(float* __restrict__ X, const float*
         j = j < 0 ? j + 20 : j;
         const cvx4 sv = *reinterpret_cast<const cvx4*>(SM + (kq * 20 + j) * CV_C32 + c4 * 4);
         const cvx4 tv = *reinterpret_cast<const cvx4*>(TB + pos * CV_C32 + c4 * 4);
-        float* d = X + (kq * 32 + c4 * 4) * CW_CSX + t * 18 + lq;
+        float* d = X + (kq * 32 + c4 * 4) * CW_CSX + t * CW_RSX + lq;
 #pragma unroll
         for (int q = 0; q < 4; q++) d[q * CW_CSX] = fmaxf(sv[q] + tv[q], 0.f);
     }
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
         {
             const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)XC;
 #pragma unroll
-            for (int a = 0; a < 4; a++) RA[0][a] = RA[1][a] = RA[2][a] = base + 4u * (unsigned)(lk_ * CW_CSX + (2 * (li_ >> 3) + a) * 18 + 2 * (li_ & 7));
+            for (int a = 0; a < 4; a++) RA[0][a] = RA[1][a] = RA[2][a] = base + 4u * (unsigned)(lk_ * CW_CSX + (2 * (li_ >> 3) + a) * CW_RSX + 2 * (li_ & 7));
         }
         wgf4 W[1][2];
         wg_first_weights<1, 0, 2>(rs, wp, lofs, 256, W);
