@@ -603,6 +603,9 @@ __device__ __forceinline__ void wg_layer_msplit(float* __restrict__ act, const f
 // N-tiles per wavefront of a layer: 2 (the paired form below) or 1.  The filter tiling follows it (buf_winograd_tile_weights).
 // Pairs for the 64-channel layers too (two wavefronts per pair, K split between them, partial sums exchanged through the dead
 // half of the buffer) measured 1 % slower, before and after the filter stream became cheap: short K loops, a third barrier.
+#ifndef WG_PAIR_NT2
+#define WG_PAIR_NT2 1         // 128-channel layers: both Winograd M-tiles of a pair in ONE round (0: a round per M-tile, +0.9 %)
+#endif
 #ifndef WG_KSPLIT_PAIRS
 #define WG_KSPLIT_PAIRS 1
 #endif
@@ -647,10 +650,16 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
     // file gives a wavefront 256 registers of either kind): left in VGPRs the compiler parked 19 of the 20 quads in scratch memory
     // (264 KB of HBM traffic per patch); the rounds then run in ~130 VGPRs with no scratch at all.
     float park[2][3][16];
+#if WG_PAIR_NT2
+    wg_round<2, 0, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);     // both Winograd M-tiles in one round
+    wg_park<0>(Y, park);
+    wg_park<1>(Y, park);
+#else
     wg_round<2, 0, 1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
     wg_park<0>(Y, park);
     wg_round<2, 1, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
     wg_park<1>(Y, park);
+#endif
     wg_round_bottom<2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, pstride, bv, W1, Y);
     wg_park<2>(Y, park);
     WG_SYNC();                                       // every wavefront has finished reading the layer's input
