@@ -21,9 +21,11 @@
 // B^T d B costs 8 adds per 4 component operands, i.e. 2.0 VALU per MFMA if every N-tile (16 output channels) transforms for itself.
 //   * 128 output channels (52 % of the MFMAs): a wavefront owns an N-tile PAIR and one transform feeds the 8 MFMAs of both
 //     (1.06 VALU per MFMA in the loop).  The layer is in place -- the outputs of a pair (80 registers) wait until every
-//     wavefront has read its input -- so the M-tiles run in three rounds of one tile (32 accumulator registers).
-//   * 64 / 32 output channels: one N-tile per wavefront (M-tiles split over wavefront pairs for 32 channels).  Pairs there
-//     too (two wavefronts per pair, K split, partial sums exchanged through the dead half of the buffer) measured 1 % slower.
+//     wavefront has read its input, in accumulation registers -- and the M-tiles run in two rounds: both Winograd tiles (64
+//     accumulator registers), then the bottom row.
+//   * 64 output channels: pairs as well, by splitting M -- a wavefront owns an N-tile pair for ONE Winograd M-tile plus the bottom
+//     row of one N-tile (32 + 8 MFMAs per k-step for every wavefront, nothing to exchange).  32 output channels: the same inside
+//     each half of K (the two wavefronts of a K split hand their partial sums over through the free upper rows of the buffer).
 // The filter stream: weights come through a buffer resource with wavefront-uniform offsets (a global_load_dwordx4 with a
 // 64-bit VGPR address costs ~50 cycles of SIMD issue beside MFMAs, an SGPR-based one ~10: tools/micro/mfma_vmem.hip), tiled
 // so that a wavefront's k-steps are contiguous, two k-steps of weights in registers per N-tile.
@@ -623,8 +625,9 @@ __device__ __forceinline__ void wg_park(const wgf4 (&Y)[2][3][2][2], float (&par
 }
 
 // One layer with 128 output channels: wavefront w owns the N-tile pair 2w, 2w+1 over the whole K, and the transform of a step
-// feeds 8 MFMAs.  The accumulators of a pair over three M-tiles (96) do not fit beside the held outputs (80): three rounds of
-// one M-tile each (the weights of the pair are fetched once per round: 3 x 1 KB per k-step and wavefront from L2).
+// feeds 8 MFMAs.  The held outputs (80 registers) wait in accumulation registers; the two Winograd M-tiles share one round
+// (64 accumulators; a round per M-tile -- more passes, the pair's filters streamed a third time -- measured 0.9 % slower), the
+// bottom row is the second.
 __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
                                               int cin, int cout, int relu, int pair)
 {
