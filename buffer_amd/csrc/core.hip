@@ -13,7 +13,8 @@ void buf_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* buf_last_error(void) { return g_err; }
-extern "C" int buf_version(void) { return 200; }   // 200: round 2 (batched entry points, Winograd descriptor CNN)
+extern "C" int buf_version(void) { return 300; }   // 200: round 2 (batched entry points, Winograd descriptor CNN); 300: round 3 (filter tilings: N-tile
+                                                   // groups for 32 / 64 channels, Winograd layers 1-5 of the cost net, compact voxel lookup table)
 
 // ------------------------------------------------------------------------------------------
 // Optional per-kernel timing for bench.py's roofline objects: HIP events recorded on the launch stream
