@@ -450,35 +450,6 @@ __device__ __forceinline__ void wg_first_weights(__amdgpu_buffer_rsrc_t rs, unsi
         for (int k = K0; k < K1; k++) W[n][k] = wg_ldw(rs, wp + n * 256 + k * wstride, lofs);
 }
 
-// One layer, one N-tile per wavefront (nt), M-tiles [T0, T1): the round-2 form, kept for the layers the paired forms do not
-// take.  The layer is written in place, so the outputs wait in registers until every wavefront has finished reading.
-template <int T0, int T1, bool GLB>
-__device__ __forceinline__ void wg_layer_single(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
-                                                const float* __restrict__ bias, int cin, int cout, int relu, int nt)
-{
-    int lane = threadIdx.x & (WAVE - 1);
-    asm volatile("" : "+v"(lane));                   // lane-derived values are formed per layer: kept across the layers they are spilled
-    const int li = lane & 15, lk = lane >> 4;
-    unsigned RA[3][4];
-    wg_addresses(act, 0, li, lk, RA);
-#ifdef WG_EXP_SAMEW_SINGLE
-    const int k4 = cin >> 2, wstride = relu >> 4;              // timing experiment: a run-time zero (every k-step fetches the same KB: L1 hits)
-#else
-    const int k4 = cin >> 2, wstride = 256;
-#endif
-    const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
-    const unsigned wp = (unsigned)nt * (WG_BLOCKS * cin * 16);            // [N-tile][i][k-step][lane][j]: a wavefront streams its own block
-    const unsigned lofs = lane * 16;
-    wgf4 W[1][2];
-    wg_first_weights<1, 0, 2>(rs, wp, lofs, wstride, W);
-    wgf4 Y[1][3][2][2];
-    static_assert(T0 == 0 && T1 == 3, "M-tiles 0, 1 in the Winograd form, M-tile 2 in the bottom-row form");
-    wg_round<1, 0, 2>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bias + nt * 16 + lk * 4, W, Y);
-    wg_round_bottom<1>(RA, rs, wp, wp, lofs, k4 >> 2, wstride, (unsigned)(k4 * wstride), bias + nt * 16 + lk * 4, W, Y);
-    WG_SYNC();                                 // every wavefront has finished reading the layer's input
-    wg_store<T0, T1, GLB>(Y[0], nt, relu, act, out_glb, li, lk);
-}
-
 // One layer with 32 output channels (two N-tiles, four wavefronts): wavefront w owns N-tile w & 1 over ALL three M-tiles and the
 // K half w >> 1; the upper half hands its partial sums (40 registers) to the lower one through the rows of the channels >= 64
 // (free: Cin <= 64), which adds them and stores.  Round 2 split the M-tiles {0} | {1, 2} over the wavefront pair instead: 16 against
