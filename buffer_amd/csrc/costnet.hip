@@ -109,6 +109,9 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
 #ifndef CV_L1_DIRECT
 #define CV_L1_DIRECT 0    // 1: layer 1 in the direct form (round 2 / early round 3: three-row chunks, sliding accumulator window)
 #endif
+#ifndef CV_L1_PAIRS
+#define CV_L1_PAIRS 1     // Winograd layer 1: N-tile pairs with K split over the wavefront pair (0: one N-tile per wavefront over all of K)
+#endif
 #if CV_L1_DIRECT
 #define CVA_SM 7920       // [3][20][36]  Sterm[k'][j][o]
 #define CVA_TB 10080      // [3][18][36]  b[o] - Tterm[k'][l'][o]
@@ -120,6 +123,8 @@ __device__ __forceinline__ void cv_gemm_static(cvx4 (&acc)[MT][NT], Loader& L, c
 #define CW_RSX 18         // (rows of 24 and channels 160 apart -- the two tile rows of an M-tile and the two channels of a half-wave on
 #define CW_CSX 112        //   the four quarters of the 64 banks, conflict-free -- measured +-0 against this compact layout)
 #endif
+#define CVA_XCH (96 * CW_CSX)      // 2 x 8 x 64 float4 of partial sums handed over per chunk (CV_L1_PAIRS)
+static_assert(CVA_XCH + 2 * 8 * 64 * 4 <= CVA_SM, "the exchange slots fit between the chunk and the layer-0 maps");
 #endif
 #define CVA_R0 0          // [3][54][36]  chunk of three layer-0 rows (aliases SP/TP once the two small GEMMs are done)
 #define CVA_R1 12024      // second chunk buffer; ends at 17856 <= CV_BUF
@@ -521,6 +526,65 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
     }
 
 #else
+#if CV_L1_PAIRS
+    // ---- phase A.2: layer 1 in the Winograd domain.  Its 3 x 3 x 3 filter collapses k' (3 -> 1), so it is a 3 x 3 correlation over
+    // (n', l') with the three k' planes as input channels (96): 8 x 8 tiles of 2 x 2 outputs.  The 124 KB layer-0 map never
+    // exists: four chunks of six rows n' = 4j .. 4j+5 (two tile rows = one M-tile of 16 tiles) are formed channel-major one after
+    // the other.  Wavefront (p, kh) owns the N-tile PAIR p over half kh of K (48 channels): one input transform feeds 8 MFMAs.  The two
+    // K halves of a pair share the stores (kh = 0: chunks 0, 1; kh = 1: chunks 2, 3): the partial sums of a chunk go from the half
+    // that does not store it to the one that does, which holds its 2 x 32 output registers until the last chunk has been read.
+    // 64 tile rows x 16 components x 96 channels = 0.44 of the direct form's matrix instructions (3 456 -> 1 536 per wavefront).
+    {
+        int lane_ = threadIdx.x & (WAVE - 1);
+        asm volatile("" : "+v"(lane_));
+        const int li_ = lane_ & 15, lk_ = lane_ >> 4;
+        const int p_ = w & 1, kh = w >> 1;
+        float* XC = bufB + CVA_XC;
+        constexpr unsigned KSTEP = 16u * CW_CSX;
+        const __amdgpu_buffer_rsrc_t rs = wg_weights(P.wt[1]);
+        const unsigned wp = (unsigned)p_ * (96 * 512) + (unsigned)(12 * kh) * 512;      // [pair][i 0..3][k-step 0..23][n2][lane][j]
+        const unsigned lofs = lane_ * 16;
+        unsigned RA[3][4];
+        {
+            const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)XC + (unsigned)(12 * kh) * KSTEP;
+#pragma unroll
+            for (int a = 0; a < 4; a++) RA[0][a] = RA[1][a] = RA[2][a] = base + 4u * (unsigned)(lk_ * CW_CSX + (2 * (li_ >> 3) + a) * CW_RSX + 2 * (li_ & 7));
+        }
+        const float* bl = kh ? nullptr : P.bias[1] + p_ * 32 + lk_ * 4;               // the bias rides in the lower K half
+        wgf4 W[2][2];
+        wg_first_weights<2, 0, 2>(rs, wp, lofs, 512, W);
+        // kh = 0 stores chunks 0, 1 and kh = 1 chunks 2, 3: after a chunk's round the other half hands its 8 quads over through the
+        // 16 KB between the chunk buffer and the layer-0 maps, before the barrier that ends the chunk; the owner adds them behind it
+        wgf4* slot = reinterpret_cast<wgf4*>(bufB + CVA_XCH) + (size_t)p_ * 8 * WAVE + lane_;
+        wgf4 Yown[2][2][3][2][2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            form_rows_cm(XC, SM, TB, 4 * j);
+            __syncthreads();
+            wgf4 Yt[2][3][2][2];
+            wg_round<2, 0, 1, KSTEP, true>(RA, rs, wp, wp, lofs, 3, 512, 24u * 512u, bl, W, Yt);
+            const bool own = (j < 2) == (kh == 0);
+            if (!own) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) slot[q * WAVE] = Yt[q >> 2][0][(q >> 1) & 1][q & 1];
+            }
+            __syncthreads();                 // the chunk may be overwritten; the partial sums handed over are in place
+            if (own) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) Yown[j & 1][q >> 2][0][(q >> 1) & 1][q & 1] = Yt[q >> 2][0][(q >> 1) & 1][q & 1] + slot[q * WAVE];
+            }
+        }
+        // (the last take and the next barrier: the map below covers the slots)
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int n = 0; n < 2; n++)
+                cw_store_tile<18, 2, 16, CW_CS1, false>(Yown[jj][n][0], 2 * kh + jj, 2 * p_ + n, bufA, li_, lk_);
+        __syncthreads();
+        CV_STAMP_AT(2)
+    }
+#else
     // ---- phase A.2: layer 1 in the Winograd domain.  Its 3 x 3 x 3 filter collapses k' (3 -> 1), so it is a 3 x 3 correlation over
     // (n', l') with the three k' planes as input channels (96): 8 x 8 tiles of 2 x 2 outputs.  The 124 KB layer-0 map never
     // exists: four chunks of six rows n' = 4j .. 4j+5 (two tile rows = one M-tile of 16 tiles) are formed channel-major one after
@@ -556,6 +620,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
         __syncthreads();
         CV_STAMP_AT(2)
     }
+#endif
 #endif
     // ---- phase B: layers 2..6 rewrite the buffer in place; the three tiny last layers hop through its free parts -----------
     //                                 in: size rows stride | tile rows per M-tile | Cin | N-tiles, M-tiles per wavefront | out
@@ -606,7 +671,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
 // N-tiles per group in the Winograd filter tiling of layer l (2..5): what buf_winograd_tile_filters is to be called with
 extern "C" int buf_cost_winograd_group(int layer)
 {
-    return layer == 1 ? (CV_L1_DIRECT ? 0 : 1) : layer == 2 ? CW_NN2 : layer == 3 ? 2 : layer == 4 ? CW_NN4 : layer == 5 ? 1 : 0;
+    return layer == 1 ? (CV_L1_DIRECT ? 0 : (CV_L1_PAIRS ? 2 : 1)) : layer == 2 ? CW_NN2 : layer == 3 ? 2 : layer == 4 ? CW_NN4 : layer == 5 ? 1 : 0;
 }
 
 static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const float* const* wt_host, const float* const* bias_host,
