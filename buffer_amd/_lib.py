@@ -71,6 +71,9 @@ _SIGNATURES = {
     "buf_patch_voxelize": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _sz, _vp]),
     "buf_cylindrical_net_wg": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_cylindrical_net_split": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_split_filter_count": (C.c_longlong, [_i, _i]),
+    "buf_split_tile_filters": (_i, [_vp, _i, _i, _vp]),
     "buf_winograd_tile_weights": (_i, [_vp, _i, _i, _vp]),
     "buf_winograd_group": (_i, [_i, _i]),
     "buf_cost_winograd_group": (_i, [_i]),

@@ -10,5 +10,6 @@
 #include "registration.hip"
 #include "convnet.hip"
 #include "convnet_wg.hip"
+#include "convnet_h3.hip"
 #include "costnet.hip"
 #include "preprocess.hip"

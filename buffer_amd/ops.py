@@ -553,6 +553,54 @@ class CylindricalNet:
         return y
 
 
+def split_tile_filters(w):
+    """[Cout, Cin, 3, 3] fp32 -> the two f16 planes of csrc/convnet_h3.hip (hi = f16(w), lo' = f16((w - hi) 2^11)) in the kernel's
+    tiling, as uint16 bit patterns (buf_split_tile_filters; host only)."""
+    L = _lib.lib()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = w.shape[0], w.shape[1]
+    out = np.empty(L.buf_split_filter_count(cout, cin), dtype=np.uint16)
+    check(L.buf_split_tile_filters(w.ctypes.data, cout, cin, out.ctypes.data), "buf_split_tile_filters")
+    return out
+
+
+class CylindricalNetSplit:
+    """Cylindrical_Net on the f16 matrix pipe with fp32-equivalent arithmetic (csrc/convnet_h3.hip, "split-f16"): opt-in next to
+    CylindricalNet.  Same call, same [P,32,7,20] fp32 result to fp32 round-off; `check_range()` raises if an activation ever
+    left the f16 range (the kernel sets a device flag; reading it synchronises)."""
+
+    def __init__(self, layers, device):
+        self.wt, self.bias, self.cin, self.cout, self.relu = [], [], [], [], []
+        self.entry = "buf_cylindrical_net_split"
+        for w, b, relu in layers:
+            cout, cin = w.shape[0], w.shape[1]
+            self.wt.append(torch.from_numpy(split_tile_filters(w).view(np.int16)).to(device))
+            self.bias.append(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(device))
+            self.cin.append(cin); self.cout.append(cout); self.relu.append(1 if relu else 0)
+        n = len(layers)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self._wp = (C.c_void_p * n)(*[t.data_ptr() for t in self.wt])
+        self._bp = (C.c_void_p * n)(*[t.data_ptr() for t in self.bias])
+        self._ci = (C.c_int * n)(*self.cin)
+        self._co = (C.c_int * n)(*self.cout)
+        self._re = (C.c_int * n)(*self.relu)
+
+    def __call__(self, x):
+        """x f32[P,16,420] (or [P,48,140]) -> f32[P,32,7,20]"""
+        L = _lib.lib()
+        x = x.contiguous()
+        P = x.shape[0]
+        y = torch.empty((P, self.cout[-1], 7, 20), dtype=torch.float32, device=x.device)
+        check(L.buf_cylindrical_net_split(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(y), _ptr(self.status), _stream()),
+              self.entry)
+        return y
+
+    def check_range(self):
+        if int(self.status.item()) != 0:
+            self.status.zero_()
+            raise FloatingPointError("buf_cylindrical_net_split: an activation left the f16 range (|v| >= 65504); use the fp32 kernel")
+
+
 class DescriptorHead:
     """Attention pooling + normalisation head (patch_embedder.py:66-72,81-84) for csrc/convnet.hip k_desc_head."""
 

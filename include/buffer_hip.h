@@ -58,7 +58,9 @@ int         buf_device_count(void);
 #define BUF_TIMED_VN_GATHER      7   /* A4:  work = 4*N*K + 12*N + 12*N*Cin + 12*N*Cout bytes */
 #define BUF_TIMED_GRID_SUBSAMPLE 8   /* A1:  work = 12*N + 12*M(capacity N) + 4*B bytes; spans the whole kernel sequence */
 #define BUF_TIMED_DESC_HEAD      9   /* A11 tail: work = (2*32*140*4 + 128) bytes per patch */
-#define BUF_TIMED_NKERNELS       10
+#define BUF_TIMED_CYL_NET_SPLIT  10  /* A11 dense, split-f16 form (buf_cylindrical_net_split): work = dense flops, as id 1 */
+#define BUF_TIMED_COST_NET_SPLIT 11  /* A13, split-f16 form */
+#define BUF_TIMED_NKERNELS       12
 void        buf_timing_enable(int on);
 long long   buf_timing_collect(double* total_ms, double* total_bytes);
 long long   buf_timing_collect_kernel(int kernel_id, double* total_ms, double* total_work);
@@ -253,6 +255,23 @@ int     buf_winograd_tile_filters(const float* w_host, int cout, int cin, int ng
                                                    /* host only: the same tiling with N-groups of ng and nblk = 4 | 5 blocks -> 4*nblk*Cout*Cin floats */
 int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
+
+/* A11 (dense), split-f16 form -- the same stack with fp32-EQUIVALENT arithmetic on the f16 matrix pipe (csrc/convnet_h3.hip; opt-in,
+ * the all-fp32 kernel above stays the default): every fp32 operand is split once into hi = f16(x) and lo' = f16((x - hi) 2^11)
+ * (x = hi + 2^-11 lo' to 2^-24 |x|), a product sum is [sum hi hi] + 2^-11 [sum hi lo' + sum lo' hi] in two fp32 accumulators:
+ * three v_mfma_f32_16x16x32_f16 per (16 outputs x 16 positions x 32 channels), direct 9-tap form.  Measured against the float64
+ * stack: not worse than the fp32 kernels (tests/test_model_gpu.py, profiles/r04_f16_split.txt).  Requires every activation and
+ * weight below 65504 in magnitude (f16 range): weights are checked by the tiler, an activation that leaves the range sets bit 0
+ * of *status_dev (DEVICE int32, nullable; the caller clears and reads it).
+ * x f32[np,Cin0,140] -> y f32[np,32,140]; bias_host[l]: DEVICE f32[Cout]; wt_host[l]: DEVICE u16 planes as buf_split_tile_filters
+ * lays them out from the BN-folded filters [Cout,Cin,3,3]:
+ *   out[((((g 9 + tap) KS + ks) 2 + n2) 2 + plane) 512 + (kg 16 + row) 8 + i] = plane(w[32 g + 16 n2 + row][32 ks + 8 kg + i][tap]),
+ *   tap = 3 ky + kx, KS = ceil(Cin / 32) (channels beyond Cin zero), plane 0 = hi, plane 1 = lo'; buf_split_filter_count u16 values.
+ * Cin a multiple of 16, <= 128, not in 65..96; Cout in {32, 64, 128}; last layer 32. */
+long long buf_split_filter_count(int cout, int cin);                                             /* host only */
+int     buf_split_tile_filters(const float* w_host, int cout, int cin, unsigned short* out_host);   /* host only */
+int     buf_cylindrical_net_split(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host,
+                                  const int* cin_host, const int* cout_host, const int* relu_host, float* y, int* status_dev, void* stream);
 
 /* A11 (head)  attention pooling + normalisation (models/patch_embedder.py:66-72,81-84): pool_layer
  * (Conv2d 1x1 32->16 + BN + ReLU, Conv2d 1x1 16->1 + BN + ReLU), desc = normalize(mean(y * w)),
