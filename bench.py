@@ -42,9 +42,15 @@ CYL_NET_EXECUTED_FRACTION = 40 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs
 #                                          40 MFMAs of 16x16x4 per (4 input channels, 16 output channels) instead of the
 #                                          9 x 140 x 4 x 16 MACs of the direct form = 0.508 of the dense count
 
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_16x16x32_f16), ~2.5 PFLOP/s
+CYL_NET_DENSE_FLOPS_PER_PATCH = 118702080.0       # 2 x 140 x sum 9 Cin Cout
+# csrc/convnet_h3.hip issues 3 v_mfma_f32_16x16x32_f16 (16384 flops each) per (16 outputs, 16 positions, 32 channels): 9 position
+# tiles for the 140 positions, layer 0's 48 channels as two k-steps: 22842 matrix instructions per patch
+CYL_NET_SPLIT_ISSUED_FLOPS_PER_PATCH = 22842 * 16384.0
+
 # library timing ids (include/buffer_hip.h BUF_TIMED_*)
 TIMED = {'grid_query': 0, 'cyl_net': 1, 'cost_net': 2, 'select_patches': 3, 'patch_voxelize': 4, 'fps': 5, 'nn1': 6,
-         'vn_gather': 7, 'grid_subsample': 8, 'desc_head': 9}
+         'vn_gather': 7, 'grid_subsample': 8, 'desc_head': 9, 'cyl_net_split': 10, 'cost_net_split': 11}
 
 
 def parse():
@@ -66,6 +72,14 @@ def parse():
     ap.add_argument('--stream-overlaps', default=None,
                     help='overlap classes of the synthetic stream, equal shares (default 0.75,0.6,0.45,0.3; a 3DLoMatch-like set: 0.3,0.25,0.2,0.15)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--arith', choices=['f32', 'split'], default='f32',
+                    help="CNN kernels of the (first) timed region: 'f32' = fp32 MFMA (default, the headline), 'split' = fp32-equivalent split-f16")
+    ap.add_argument('--no-split', action='store_true',
+                    help="skip the second timed region with cnn_arith='split' (fp32-equivalent split-f16 CNN kernels: value_split, roofline_split)")
+    ap.add_argument('--total-pairs', type=int, default=None,
+                    help='pair workload, STRONG scaling: this many pairs per step for the whole job, pair i of a step on rank i mod N '
+                         '(default: --pairs-per-step on every rank = weak scaling)')
+    ap.add_argument('--detail-json', default=None, help='also write the uncompacted record (full roofline_other entries) to this file')
     return ap.parse_args()
 
 
@@ -100,11 +114,11 @@ def cpu_baseline(sample, cfg, limits):
     t_model = sum(v for k, v in tm.items() if k != 'pyramid')
     # the reference overlaps its loader workers with the model process: steady-state rate = the slower of the two legs
     return dict(value=1.0 / max(t_pyr, t_model), unit='pairs/s', cores=torch.get_num_threads(), workers=workers,
-                kind='reference' if use_ref else 'port',
-                sample=f'1 pair of the timed workload at full size ({cfg.num_keypts} keypoints per fragment, nothing scaled): '
-                       f'pyramid by the {"reference cpp_wrappers cores" if use_ref else "plain-C port"} on {workers} concurrent '
-                       f'workers ({t_pyr * 1e3:.1f} ms per pair), model stages on torch-CPU with {torch.get_num_threads()} threads '
-                       f'({t_model:.1f} s per pair; {wall:.1f} s measured); value = 1 / max(loader leg, model leg)',
+                kind='reference cores (pyramid) + restated model' if use_ref else 'port',
+                sample=f'1 pair at full size ({cfg.num_keypts} keypoints/fragment, nothing scaled): pyramid by the '
+                       f'{"reference cpp_wrappers cores" if use_ref else "plain-C port"} on {workers} workers ({t_pyr * 1e3:.1f} ms/pair), '
+                       f'model stages = torch-CPU restatement, {torch.get_num_threads()} threads ({t_model:.1f} s/pair); '
+                       f'value = 1 / max(loader leg, model leg)',
                 stages_s={k: round(v, 3) for k, v in tm.items()}, pyramid_s_per_pair_at_workers=round(t_pyr, 4))
 
 
@@ -145,37 +159,34 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
     """`roofline` (dominant kernel) + `roofline_other` (every other kernel with a roofline class in SURVEY 8d)."""
     main = roof_entry(timed, 'cyl_net', 'k_cyl_net_wg (A11 Cylindrical_Net, fused fp32 MFMA, Winograd F(2x2,3x3))', 'mfma', MFMA_F32_PEAK_TFLOPS,
                       'TFLOP/s', 1e12, traffic_of(pmc, 'k_cyl_net_wg', units.get('patches')),
-                      executed_fraction_of_dense=CYL_NET_EXECUTED_FRACTION)
+                      useful_fraction_of_dense=CYL_NET_EXECUTED_FRACTION)
     if main:
-        # What the hardware did: the kernel evaluates the reference's convolutions in the Winograd F(2x2,3x3) domain in fp32 and
-        # EXECUTES 0.508 of their dense count on the matrix pipe.  achieved / frac = executed flops (matrix-pipe utilisation);
-        # the dense algorithmic count of SURVEY 8d (0.1187 GFLOP/patch) over the same time is reported beside it.
+        # The kernel evaluates the reference's convolutions in the Winograd F(2x2,3x3) domain in fp32: 40 MFMAs of 16x16x4 per (4 input,
+        # 16 output channels) instead of the 9 x 140 x 4 x 16 MACs of the direct form.  achieved / frac = USEFUL Winograd-domain
+        # flops (40 x 1024 MACs per block; the half-empty bottom-row M-tile is inside that count: issued = useful, 8 of the 40 MFMAs
+        # carry 8 of 16 rows); the dense algorithmic count of SURVEY 8d (0.1187 GFLOP/patch) over the same time rides along.
         dense = main['achieved']
         main['dense_equivalent_tflops'] = dense
         main['achieved'] = dense * CYL_NET_EXECUTED_FRACTION
         main['frac'] = main['achieved'] / MFMA_F32_PEAK_TFLOPS
-        main['avg_executed_flops'] = main['avg_algorithmic_flops'] * CYL_NET_EXECUTED_FRACTION
-        main['flops'] = ('achieved = flops EXECUTED on the matrix pipe (40 v_mfma_f32_16x16x4_f32 per 4 input x 16 output channels = 0.508 '
-                         'of the dense count) / HIP-event time on the launch stream; dense_equivalent_* = the algorithmic count of the '
-                         'reference convolutions (SURVEY 8d: 0.1187 GFLOP/patch) over the same time')
-        main['traffic_source'] = ('replayed: HBM bytes per patch of profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
-                                  'passes of this build, gfx950 corrections) x the patches of one launch of this run') if main['traffic'] else None
+        main['avg_issued_flops'] = main['avg_algorithmic_flops'] * CYL_NET_EXECUTED_FRACTION
+        main['flops'] = 'achieved = flops of the ISSUED v_mfma_f32_16x16x4_f32 (0.508 of the dense count) / HIP-event time'
+        main['traffic_source'] = 'replayed from profiles/traffic.json (PMC passes of this build) x patches per launch' if main['traffic'] else None
     matches = timed['cost_net'][2] / max(timed['cost_net'][0], 1) / COST_NET_FLOPS_PER_MATCH
     other = [
         roof_entry(timed, 'cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
                    traffic_of(pmc, 'k_cost_net', matches),
-                   flops='executed count (0.0519 GFLOP/match: layer 0 separated exactly into an S-term and a T-term, 1.4 M MAC '
-                         'instead of 26.9 M; layers 1..5 as Winograd F(2x2,3x3) component GEMMs, 22.9 M MAC instead of 51.5 M); '
-                         'the dense count of SURVEY 8d is 0.160 GFLOP/match',
+                   flops='useful-tile count (0.0519 GFLOP/match: layer 0 separated, layers 1..5 Winograd); dense count of SURVEY 8d: 0.160',
                    dense_equivalent_tflops=(COST_NET_DENSE_FLOPS_PER_MATCH * matches) / (timed['cost_net'][1] / max(timed['cost_net'][0], 1) * 1e-3) / 1e12),
-        roof_entry(timed, 'grid_query', 'k_grid_query_wave (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+        roof_entry(timed, 'grid_query', 'k_grid_query (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_grid_query_wave', units.get('pairs'))),
         roof_entry(timed, 'grid_subsample', 'k_vox_* + scan + k_cell_scatter (A1 grid subsample, whole call)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9),
         roof_entry(timed, 'vn_gather', 'k_vn_gather (A4 fused VN neighbour block)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_vn_gather', units.get('pairs'))),
-        roof_entry(timed, 'select_patches', 'k_select_patches_grid (A8 ball query + grouping, all clouds of a step)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+        roof_entry(timed, 'select_patches', 'k_select_patches_grid (A8 ball query + grouping)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_select_patches_grid', units.get('patches_per_select'))),
-        roof_entry(timed, 'patch_voxelize', 'k_patch_voxelize (A9 + A10 + point MLP)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+        # VALU / LDS-atomic bound (DESIGN 9.3), not HBM bound: the byte rate is reported for reference only
+        roof_entry(timed, 'patch_voxelize', 'k_patch_voxelize (A9 + A10 + point MLP)', 'valu', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_patch_voxelize', units.get('patches'))),
         roof_entry(timed, 'desc_head', 'k_desc_head (A11 attention pooling + normalisation)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_desc_head', units.get('patches'))),
@@ -192,6 +203,35 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
     return main, [e for e in other if e]
 
 
+def roofline_split(timed, pmc, units, err):
+    """`roofline_split`: csrc/convnet_h3.hip in the split region (achieved = flops of the ISSUED f16 matrix instructions)."""
+    n, ms, work = timed['cyl_net_split']
+    if not n:
+        return None
+    patches = work / n / CYL_NET_DENSE_FLOPS_PER_PATCH
+    sec = ms / n * 1e-3
+    issued = CYL_NET_SPLIT_ISSUED_FLOPS_PER_PATCH * patches
+    e = {'kernel': 'k_cyl_net_h3 (A11 Cylindrical_Net, direct 9-tap form on the f16 matrix pipe)',
+         'arithmetic': "f16x3 split (x = hi + 2^-11 lo', 3 v_mfma_f32_16x16x32_f16 into 2 fp32 accumulators), fp32 accumulate, fp32-equivalent",
+         'bound': 'mfma', 'achieved': issued / sec / 1e12, 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+         'frac': issued / sec / 1e12 / MFMA_F16_PEAK_TFLOPS, 'traffic': traffic_of(pmc, 'k_cyl_net_h3', patches),
+         'launches': n, 'avg_us': ms / n * 1e3, 'avg_issued_flops': issued, 'avg_algorithmic_flops': work / n,
+         'dense_equivalent_tflops': work / n / sec / 1e12,
+         'flops': 'achieved = 22842 issued MFMAs per patch x 16384 flops / HIP-event time; dense algorithmic count 0.1187 GFLOP/patch'}
+    e.update(err or {})
+    return e
+
+
+def compact(e, algo_key=None):
+    """one roofline_other entry reduced to what the driver's 2000-character tail must keep"""
+    tr = None
+    by = e.get('avg_algorithmic_bytes')
+    if e.get('traffic') and by:
+        tr = round(e['traffic'] / by, 2)
+    return {'kernel': e['kernel'].split(' ')[0], 'bound': e['bound'], 'frac': None if e.get('frac') is None else round(e['frac'], 4),
+            'avg_us': round(e['avg_us'], 1), 'traffic_ratio': tr}
+
+
 def dgr_ok(poses, gts):
     ok = 0
     for pose, gt in zip(poses, gts):
@@ -203,6 +243,39 @@ def dgr_ok(poses, gts):
 
 
 # ------------------------------------------------------------------------------------------------ main
+def _make_sample(job):
+    kind, seed = job
+    from buffer_amd import synth
+    return (synth.make_kitti_pair if kind == 'kitti' else synth.make_pair)(seed)
+
+
+def make_samples(kind, seeds):
+    """The synthetic pairs of this rank (numpy only), generated by a pool of forked workers BEFORE anything touches the GPU
+    (33 pairs took ~35 s of the untimed set-up when made one after the other)."""
+    import multiprocessing as mp
+    jobs = [(kind, s) for s in seeds]
+    workers = max(1, min(len(jobs), (os.cpu_count() or 1) // max(int(os.environ.get('LOCAL_WORLD_SIZE', 1)), 1), 32))
+    if workers == 1:
+        return [_make_sample(j) for j in jobs]
+    with mp.get_context('fork').Pool(workers) as pool:
+        return pool.map(_make_sample, jobs)
+
+
+def cnn_error_vs_float64(pipe_f32, pipe_split, dev):
+    """max |y - y64| / max |y64| of both descriptor-CNN kernels on 64 post-ReLU-like random patches, the stack in float64 (torch) as truth"""
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = torch.relu(torch.randn((64, 48, 140), generator=g)).to(dev)
+    h = x.double().reshape(-1, 48, 7, 20)
+    for w, b, relu in pipe_f32.desc.layers:
+        h = torch.cat([h[..., -1:], h, h[..., :1]], -1)
+        h = torch.nn.functional.pad(h, (0, 0, 1, 1))
+        h = torch.nn.functional.conv2d(h, torch.from_numpy(w).double().to(dev), torch.from_numpy(b).double().to(dev))
+        h = torch.relu(h) if relu else h
+    sc = h.abs().max().item()
+    return {'error_vs_float64': (pipe_split.desc.fused(x).double() - h).abs().max().item() / sc,
+            'error_vs_float64_fp32_kernel': (pipe_f32.desc.fused(x).double() - h).abs().max().item() / sc}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -222,6 +295,24 @@ def main():
     if world != a.gpus:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with\n  python -m torch.distributed.run --nnodes=1 '
                          f'--nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port <P> bench.py --gpus {a.gpus} ...')
+    t_setup = time.perf_counter()
+    kitti = a.workload == 'kitti'
+    keypts = a.keypts or (1500 if kitti else 5000)
+    strong = a.total_pairs is not None
+    if strong:                                        # STRONG scaling: the job's pairs of a step are dealt i -> rank i mod N
+        if a.workload != 'pair':
+            raise SystemExit('--total-pairs applies to --workload pair')
+        pps = len(range(rank, a.total_pairs, world))
+        job_pairs_per_step = a.total_pairs
+    else:
+        pps = a.pairs_per_step or (16 if kitti else 32)
+        job_pairs_per_step = world * pps
+    samples = None
+    if a.workload != 'stream':                        # host-side synthetic data first: forked workers, no GPU state yet
+        n_distinct = max(a.distinct_pairs or pps, 1)
+        seeds = [1000] + [2000 + rank * 1000 + i for i in range(n_distinct)]
+        made = make_samples('kitti' if kitti else 'pair', seeds)
+        calib, samples = made[0], made[1:]
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
     local = local % torch.cuda.device_count()      # (only matters for the single-GPU gloo run of the N>1 logic, see tests)
@@ -237,28 +328,23 @@ def main():
             dist.init_process_group(backend)
     cdev = dev if backend == 'nccl' else torch.device('cpu')
 
-    from buffer_amd import _lib, synth
+    from buffer_amd import _lib
     from buffer_amd.config import KITTI, THREEDMATCH
     from buffer_amd.pipeline import BufferPipeline
     L = _lib.lib()
     if a.workload == 'stream':
         return run_stream(a, rank, world, dev, cdev, dist, L)
-    kitti = a.workload == 'kitti'
-    keypts = a.keypts or (1500 if kitti else 5000)
-    pps = a.pairs_per_step or (16 if kitti else 32)
-    cfg = replace(KITTI if kitti else THREEDMATCH, num_keypts=keypts)
-    make = synth.make_kitti_pair if kitti else synth.make_pair
+    cfg = replace(KITTI if kitti else THREEDMATCH, num_keypts=keypts, cnn_arith=a.arith)
     pipe = BufferPipeline(cfg, dev)
-    calib = make(1000)                                # same calibration pair on every rank -> identical limits
-    limits = pipe.calibrate([calib])
-    samples = [make(2000 + rank * 1000 + i) for i in range(a.distinct_pairs or pps)]
+    limits = pipe.calibrate([calib])                  # same calibration pair on every rank -> identical limits
     inputs = [pipe.upload(s) for s in samples]
     torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
 
     # optional: the pairs of a step split over several stacked batches, one host thread + HIP stream each
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    nconc = max(1, min(a.streams, pps))
+    nconc = max(1, min(a.streams, max(pps, 1)))
     streams = [torch.cuda.Stream(device=dev) for _ in range(nconc)]
     tls = threading.local()
     slot_lock = threading.Lock()
@@ -271,16 +357,18 @@ def main():
             torch.cuda.set_device(local)
         return streams[tls.slot]
 
-    def one_batch(ks):
-        with torch.cuda.stream(_bind()):
-            return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
-
     pool = ThreadPoolExecutor(max_workers=nconc) if nconc > 1 else None
 
-    def step(i):
+    def step(pp, i):
         ks = [(i * pps + j) % len(inputs) for j in range(pps)]
+        if not ks:
+            return []
         if pool is None:
-            return pipe.register_batch([inputs[k] for k in ks], seeds=ks)
+            return pp.register_batch([inputs[k] for k in ks], seeds=ks)
+
+        def one_batch(kk):
+            with torch.cuda.stream(_bind()):
+                return pp.register_batch([inputs[k] for k in kk], seeds=kk)
         parts = [ks[j::nconc] for j in range(nconc)]
         outs = list(pool.map(one_batch, parts))
         poses = [None] * len(ks)
@@ -288,53 +376,95 @@ def main():
             poses[j::nconc] = o
         return poses
 
-    def run_steps(first, count):
+    def run_steps(pp, first, count):
         """`count` steps -> list of poses.  Default: the steps are software-pipelined over two HIP streams
         (BufferPipeline.register_batches: keypoint stage of step i+1 beside the CNN kernels of step i)."""
+        if pps == 0:
+            return []
         if pool is None and not a.no_pipeline:
             ks = [[((first + i) * pps + j) % len(inputs) for j in range(pps)] for i in range(count)]
-            return [p for ps in pipe.register_batches([[inputs[k] for k in kk] for kk in ks], seeds=ks) for p in ps]
-        return [p for i in range(count) for p in step(first + i)]
+            return [p for ps in pp.register_batches([[inputs[k] for k in kk] for kk in ks], seeds=ks) for p in ps]
+        return [p for i in range(count) for p in step(pp, first + i)]
 
-    run_steps(0, a.warmup)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    L.buf_timing_enable(1)
-    t0 = time.perf_counter()
-    all_poses = run_steps(a.warmup, a.steps)
-    mine = torch.stack(all_poses).to(cdev)
-    gathered = None
-    if dist:                                           # the path's one exchange: poses of every shard
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    L.buf_timing_enable(0)
-    timed = collect_timed(L)
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(pp, warmup):
+        """warm-up, then EXACTLY a.steps steps between barrier + synchronize on both sides; max over ranks."""
+        run_steps(pp, 0, warmup)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        L.buf_timing_enable(1)
+        t0 = time.perf_counter()
+        poses = run_steps(pp, a.warmup, a.steps)
+        mine = (torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)).to(cdev)
+        gathered = None
+        if dist:                                           # the path's one exchange: poses of every shard
+            if strong:                                     # shard sizes differ by one: pad to the largest
+                cap = a.steps * len(range(0, a.total_pairs, world))
+                padded = torch.zeros((cap, 4, 4), dtype=mine.dtype, device=cdev)
+                padded[:mine.shape[0]] = mine
+                gathered = [torch.empty_like(padded) for _ in range(world)]
+                dist.all_gather(gathered, padded)
+            else:
+                gathered = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(gathered, mine)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        L.buf_timing_enable(0)
+        timed = collect_timed(L)
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return poses, mine, gathered, elapsed, timed
+
+    all_poses, mine, gathered, elapsed, timed = timed_region(pipe, a.warmup)
     # Kernel characterisation pass (NOT timed, rank 0): two steps one after the other on one stream, so that every kernel of
     # `roofline_other` is measured alone on the chip.  In the pipelined timed region the short keypoint-stage kernels of step i+1
     # share the chip with the CNN kernels of step i: their event spans there measure the contention, not the kernel.
     timed_alone = timed
-    if rank == 0 and pool is None and not a.no_pipeline:
+    latency = {}
+    if rank == 0 and pool is None and not a.no_pipeline and pps:
         L.buf_timing_enable(1)
         for i in range(2):
-            step(a.warmup + a.steps + i)
+            step(pipe, a.warmup + a.steps + i)
         torch.cuda.synchronize()
         L.buf_timing_enable(0)
         timed_alone = collect_timed(L)
+    if rank == 0 and pps:
+        # what ONE caller of models/BUFFER.py:231-333 sees: one pair, un-batched, un-pipelined, host clock around a synchronised
+        # call (median of 10); and the keypoint stage alone (pyramid, point learner, FPS), for one pair and for a whole step
+        def med(fn, n=10):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts))
+        pipe.register_batch([inputs[0]], seeds=[0])
+        latency['single_pair_latency_ms'] = med(lambda: pipe.register_batch([inputs[0]], seeds=[0]))
+        latency['keypoint_stage_ms'] = {'one_pair': med(lambda: pipe._keypoints([inputs[0]], [0], None)),
+                                        'per_step': med(lambda: pipe._keypoints([inputs[k % len(inputs)] for k in range(pps)], list(range(pps)), None), 3)}
     gts = [samples[(a.warmup * pps + n) % len(samples)]['relt_pose'] for n in range(len(all_poses))]    # step i, slot j -> pair (i*pps + j) mod distinct
     ok = dgr_ok(mine.cpu().numpy(), gts)
 
+    # second timed region: the SAME steps with the opt-in fp32-equivalent split-f16 CNN kernels (cnn_arith='split')
+    split = None
+    if not a.no_split and a.arith == 'f32':
+        pipe_s = BufferPipeline(replace(cfg, cnn_arith='split'), dev, limits=limits)
+        poses_s, mine_s, _, elapsed_s, timed_s = timed_region(pipe_s, 1)
+        pipe_s.desc.fused.check_range()
+        if rank == 0:
+            dpose = float((mine_s - mine).abs().max().item()) if mine.numel() else 0.0
+            split = dict(elapsed=elapsed_s, timed=timed_s, ok=dgr_ok(mine_s.cpu().numpy(), gts), dpose=dpose,
+                         err=cnn_error_vs_float64(pipe, pipe_s, dev))
+
     if rank == 0:
-        pairs = world * a.steps * pps
-        per_launch = pps / nconc                                          # pairs covered by one stacked launch
+        pairs = job_pairs_per_step * a.steps
+        per_launch = max(pps, 1) / nconc                                  # pairs covered by one stacked launch
         pmc = load_traffic()
         n_sel = timed['select_patches'][0]
         units = {'pairs': per_launch, 'patches': 2 * keypts * per_launch,
@@ -342,7 +472,6 @@ def main():
         # A6 bytes: 12 N' + 4 P per cloud; N' (points above the score threshold) <= the sds cloud sizes
         fps_bytes = (sum(12.0 * int(x) for inp in inputs for x in inp['lengths']) / len(inputs) + 8.0 * keypts) * per_launch
         main_roof, _ = rooflines(timed, pmc, fps_bytes, units)                 # dominant kernel: events of the timed region
-        n_sel = timed_alone['select_patches'][0]
         units['patches_per_select'] = 2 * keypts * per_launch
         _, other = rooflines(timed_alone, pmc, fps_bytes, units)              # the others: each kernel alone on the chip
         alone_steps = 2 if timed_alone is not timed else a.steps
@@ -351,25 +480,41 @@ def main():
         out = {
             'metric': 'registration pairs/sec', 'value': pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': label, 'pairs_per_step_per_gpu': pps, 'streams': nconc,
+            'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if a.arith == 'f32' else 'f32 (split-f16 matrix products, fp32 accumulate)', 'data': 'synthetic',
+            'config': {'workload': label, 'pairs_per_step_per_gpu': pps, 'pairs_per_step_job': job_pairs_per_step, 'streams': nconc,
                        'steps_pipelined': bool(pool is None and not a.no_pipeline), 'keypoints_per_fragment': keypts,
                        'distinct_pairs_per_gpu': len(samples),
                        'fds_points': [int(samples[0]['src_fds_pts'].shape[0]), int(samples[0]['tgt_fds_pts'].shape[0])],
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,
                        'weights': ('KITTI 06050001' if kitti else '3DMatch 06132318') + ' (released)', 'parallelism': f'pair-sharded x{world}',
                        'registered_ok': f'{ok}/{len(all_poses)} (rank 0, RTE<0.3 m & RRE<15 deg)',
-                       'gathered_poses': [int(g.shape[0]) for g in gathered] if gathered else None},
-            'roofline': main_roof, 'roofline_other': other,
-            'roofline_other_measured': ('2 un-pipelined steps after the timed region (each kernel alone on the chip)'
-                                        if timed_alone is not timed else 'the timed region'),
-            'timed_kernel_ms_per_step': {k: v[1] / alone_steps for k, v in timed_alone.items() if v[0]},
+                       'gathered_poses': [int(g.shape[0]) for g in gathered] if gathered else None,
+                       'setup_s': round(setup_s, 1)},
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits)
+        out['roofline'] = main_roof
+        detail = dict(out, roofline_other=other, timed_kernel_ms_per_step={k: v[1] / alone_steps for k, v in timed_alone.items() if v[0]})
+        if split:
+            out['roofline_split'] = roofline_split(split['timed'], pmc, units, split['err'])
+            out['value_split'] = pairs / split['elapsed']
+            out['ms_per_step_split'] = split['elapsed'] / a.steps * 1e3
+            out['split'] = {'registered_ok': f"{split['ok']}/{len(all_poses)}", 'max_abs_pose_difference_vs_f32_kernels': split['dpose'],
+                            'headline': "value / dtype stay on the fp32-MFMA kernels; *_split = the same steps with cnn_arith='split'"}
+            detail.update({k: out[k] for k in ('roofline_split', 'value_split', 'ms_per_step_split', 'split')})
+        # compact tail (the driver keeps the last 2000 characters of the line): every other kernel as {kernel, bound, frac, avg_us,
+        # traffic_ratio = PMC HBM bytes / algorithmic bytes}, measured alone on the chip in 2 un-pipelined steps after the timed region
+        out['roofline_other'] = [compact(e) for e in other]
+        out.update(latency)
+        detail.update(latency)
+        if a.detail_json:
+            os.makedirs(os.path.dirname(os.path.abspath(a.detail_json)), exist_ok=True)
+            with open(a.detail_json, 'w') as f:
+                json.dump(detail, f)
         print(json.dumps(out), flush=True)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -380,7 +525,7 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
     from buffer_amd.config import THREEDMATCH
     from buffer_amd.pipeline import BufferPipeline
     from buffer_amd.threedmatch import upload
-    cfg = replace(THREEDMATCH, num_keypts=a.keypts or 1500)
+    cfg = replace(THREEDMATCH, num_keypts=a.keypts or 1500, cnn_arith=a.arith)
     pipe = BufferPipeline(cfg, dev)
     n = a.stream_pairs
     ids = list(bdist.shard_indices(n, rank, world))
@@ -389,6 +534,14 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
     first = stream.prepare(synth.make_raw_pair_device(20000, stream.OVERLAPS[0], dev), cfg, 0)     # same pair on every rank
     limits = pipe.calibrate([{k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in first.items()}])
     batch = a.pairs_per_step or 32
+    extra = None
+    if world > 1:
+        # the path's one exchange carries the ground truth of every pair as well (relative pose + the 6 x 6 information matrix of
+        # the gt.info proxy: 52 floats, formed here, untimed), so rank 0 scores the whole job without regenerating any other
+        # rank's raw clouds
+        extra = torch.tensor(np.stack([np.concatenate([np.asarray(m['relt_pose'], np.float64).reshape(-1),
+                                                       synth.information_matrix(m['overlap_pts'].cpu().numpy()).reshape(-1)]) for m in mine])
+                             if mine else np.zeros((0, 52)), dtype=torch.float32).to(cdev)
     stream.run(pipe, mine[:batch], batch)                                                           # warm-up
     torch.cuda.synchronize()
     if dist:
@@ -399,7 +552,9 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
     makers = [(lambda ch=ch: [upload(x) for x in stream.prepare_batch([mine[j] for j in ch], cfg, [ids[j] for j in ch])]) for ch in chunks]
     poses = [p for ps in pipe.register_batches(makers, seeds=[[ids[j] for j in ch] for ch in chunks]) for p in ps]
     local_poses = torch.stack(poses) if poses else torch.zeros((0, 4, 4), device=dev)
-    all_poses = bdist.gather_poses(ids, local_poses, n, device=cdev) if world > 1 else local_poses      # the path's one exchange
+    all_poses, gt = local_poses, None
+    if world > 1:
+        all_poses, gt = bdist.gather_poses(ids, local_poses, n, device=cdev, extra=extra)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -411,14 +566,12 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        # every pair of the job is scored on rank 0 from the gathered poses; the ground truth of the other ranks' pairs is
-        # regenerated here (untimed: same seeds), keeping only what the evaluator reads
-        meta = {i: m for i, m in zip(ids, mine)}
-        for i in range(n):
-            if i not in meta:
-                r = synth.make_raw_pair_device(20000 + i, overlaps[i % len(overlaps)], dev)
-                meta[i] = {'relt_pose': r['relt_pose'], 'overlap_pts': r['overlap_pts']}
-        quality = stream.evaluate_stream([meta[i] for i in range(n)], all_poses.cpu().numpy())
+        if gt is None:
+            meta = [{'relt_pose': m['relt_pose'], 'overlap_pts': m['overlap_pts']} for m in mine]
+        else:
+            g = gt.cpu().numpy().astype(np.float64)
+            meta = [{'relt_pose': g[i, :16].reshape(4, 4), 'info': g[i, 16:].reshape(6, 6)} for i in range(n)]
+        quality = stream.evaluate_stream(meta, all_poses.cpu().numpy())
         quality['scored'] = f'{n} pairs (all ranks, gathered poses)'
         main_roof, other = rooflines(timed, load_traffic(), None, {})
         print(json.dumps({
@@ -429,8 +582,9 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
                                    f'(BASELINE configs[2]); overlaps {list(overlaps)} in equal shares',
                        'keypoints_per_fragment': cfg.num_keypts, 'pairs_per_launch': batch, 'neighbor_limits': limits,
                        'parallelism': f'pair-sharded x{world}'},
-            'quality': quality, 'roofline': main_roof, 'roofline_other': other}), flush=True)
+            'quality': quality, 'roofline': main_roof, 'roofline_other': [compact(e) for e in other]}), flush=True)
     if dist:
+        dist.barrier()                                  # every rank stays until rank 0 has scored and printed
         dist.destroy_process_group()
 
 

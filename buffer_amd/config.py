@@ -29,6 +29,7 @@ class Config:
     refine_threshold: float = 0.10    # models/BUFFER.py:395-398
     weights: str = '3dmatch'
     ransac_hypotheses: int = 4096     # build-specific: deterministic GPU RANSAC width
+    cnn_arith: str = 'f32'            # build-specific: 'f32' = fp32-MFMA kernels (default) | 'split' = fp32-equivalent split-f16 kernels (opt-in)
 
     @property
     def scale(self):                  # test.scale = voxel_size_0 / voxel_size_1

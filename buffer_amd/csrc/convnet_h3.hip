@@ -4,7 +4,8 @@
 // v_mfma_f32_16x16x4_f32 runs at 1/16 of the chip's f16 / bf16 matrix rate and shares its issue port with the vector ALU.
 // Here every fp32 operand is split ONCE into two f16 numbers
 //     x = hi + 2^-11 lo',    hi = f16(x) (round to nearest even),    lo' = f16((x - hi) 2^11)
-// (|x - hi - 2^-11 lo'| <= 2^-24 |x|: the residual of an RNE rounding is signed, so two 11-bit significands carry 23 bits;
+// (|x - hi - 2^-11 lo'| <= 2^-23 |x|, one fp32 ulp, in the worst case and a quarter of that on average: the residual of an RNE
+// rounding is signed, so two 11-bit significands carry 23 bits;
 // scaling the low part keeps it a NORMAL f16 number wherever x is above 2^-25 -- unscaled it would fall into the f16
 // subnormals for every |x| < 2^-3 and lose its bits), and a product sum becomes
 //     sum x w = [sum hi_x hi_w] + 2^-11 [sum hi_x lo'_w + sum lo'_x hi_w]        (dropped: 2^-22 sum lo'_x lo'_w)
@@ -171,6 +172,7 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 v[r] = (am[n][t][r] + ac[n][t][r] * (1.f / 2048.f)) + b[r];
+                if constexpr (!LAST) ovf |= !(fabsf(v[r]) < 65504.f);       // before the ReLU: fmaxf(NaN, 0) = 0 would hide an overflow upstream
                 if (relu) v[r] = fmaxf(v[r], 0.f);
             }
             if constexpr (LAST) {
@@ -187,7 +189,6 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
                     _Float16 a, l;
                     h3_split(v[r], a, l);
                     hi[r] = a; lo[r] = l;
-                    ovf |= !(fabsf(v[r]) < 65504.f);
                 }
                 if (p < H3_NPOS) {
                     const unsigned a = lds0 + (unsigned)p * H3_S + (unsigned)c * 2u;
@@ -254,6 +255,7 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         // dwords are consecutive banks)
         const int cin0 = P.cin[0], np = cin0 >> 1, cpad = (cin0 + 31) & ~31;
         const float* src = x + (size_t)patch * cin0 * H3_NPOS;
+        bool ovf = false;
         for (int i = tid; i < 35 * np; i += H3_THREADS) {
             const int q = i / np, cp = i - q * np;
             const h3f4 a = __builtin_nontemporal_load(reinterpret_cast<const h3f4*>(src + (2 * cp) * H3_NPOS + 4 * q));
@@ -264,11 +266,13 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
                 _Float16 h, l;
                 h3_split(a[j], h, l); hi[0] = h; lo[0] = l;
                 h3_split(b[j], h, l); hi[1] = h; lo[1] = l;
+                ovf = ovf || !(fabsf(a[j]) < 65504.f) || !(fabsf(b[j]) < 65504.f);
                 const unsigned ad = lds0 + (unsigned)(4 * q + j) * H3_S + 4u * cp;
                 *(__attribute__((address_space(3))) unsigned*)(size_t)ad = __builtin_bit_cast(unsigned, hi);
                 *(__attribute__((address_space(3))) unsigned*)(size_t)(ad + H3_LO) = __builtin_bit_cast(unsigned, lo);
             }
         }
+        if (P.status && __builtin_amdgcn_ballot_w64(ovf) != 0 && lane == 0) atomicOr(P.status, 1);
         const int nz = (cpad - cin0) >> 1;                       // zero channel pairs up to the k-step boundary (48 -> 64)
         for (int i = tid; i < H3_NPOS * nz; i += H3_THREADS) {
             const int p = i / nz, cp = (cin0 >> 1) + i - p * nz;

@@ -771,6 +771,10 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
         BUF_REQUIRE(P.cout[l] != 32 || (P.cin[l] % 32 == 0 && P.cin[l] <= 64), BUF_EINVAL,
                     "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (32 output channels need Cin = 32 or 64)", l, P.cin[l], P.cout[l]);
         BUF_REQUIRE(l == 0 || P.cin[l] == P.cout[l - 1], BUF_EINVAL, "buf_cylindrical_net_wg: layer %d width mismatch", l);
+        // The 32-output layers hand their K-split partial sums over through the rows of the channels 64..95, zero words included
+        // (wg_layer_mksplit / wg_layer_ksplit); those words are written once at kernel start, so no wider layer may follow.
+        BUF_REQUIRE(l == 0 || P.cout[l - 1] != 32 || P.cout[l] == 32, BUF_EINVAL,
+                    "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (only 32-output layers may follow a 32-output layer)", l, P.cin[l], P.cout[l]);
     }
     BUF_REQUIRE(P.cout[WG_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_wg: the last layer must have 32 channels");
     size_t lds = sizeof(float) * WG_BUF;

@@ -223,7 +223,9 @@ __global__ void __launch_bounds__(256) k_cell_scatter(const float* __restrict__ 
 // voxel grid, puts every run in INPUT ORDER.
 __global__ void __launch_bounds__(256) k_cell_rank(const int* __restrict__ cell_of, const int* __restrict__ table,
                                                  const float4* __restrict__ sorted_in, int n, const int* __restrict__ err,
-                                                 float4* __restrict__ sorted_out, int* __restrict__ order_out)
+                                                 float4* __restrict__ sorted_out, int* __restrict__ order_out,
+                                                 int* __restrict__ scell_out = nullptr, const int* __restrict__ dims = nullptr,
+                                                 long long cells_per_elem = 0, int dims_stride = 0)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n || (err && *err)) return;
@@ -235,6 +237,15 @@ __global__ void __launch_bounds__(256) k_cell_rank(const int* __restrict__ cell_
     for (int t = s; t < e; t++) rank += (__float_as_int(sorted_in[t].w) < i) ? 1 : 0;
     sorted_out[s + rank] = me;
     order_out[s + rank] = i;
+    if (scell_out) {
+        // the cell of every row of the cell-ordered stream, as PACKED coordinates x | y << 10 | z << 20 (one division chain per
+        // point here instead of one per cell change in k_grid_query_cell); a grid with a dimension above 1024 stores the linear
+        // cell number with the sign bit set and the query kernel divides
+        const int b = (int)(c / cells_per_elem), cl = (int)(c - (long long)b * cells_per_elem);
+        const int dx = dims[b * dims_stride], dy = dims[b * dims_stride + 1], dz = dims[b * dims_stride + 2];
+        const int x = cl % dx, t2 = cl / dx, y = t2 % dy, z = t2 / dy;
+        scell_out[s + rank] = (dx <= 1024 && dy <= 1024 && dz <= 1024) ? (x | (y << 10) | (z << 20)) : (int)(0x80000000u | (unsigned)cl);
+    }
 }
 
 // Prefix offsets of a host batch-length array -> device, validated against the expected total.  The values travel

@@ -401,6 +401,245 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     }
 }
 
+// Cell-centric self query (round 4): the queries ARE the grid's supports in cell order, so consecutive queries of the
+// stream share their cell and with it their 27-cell candidate set.  A wavefront takes 16 consecutive rows of the cell-ordered
+// stream; whenever the cell changes (scell[] holds the cell of every row) it derives the 9 run bounds ONCE -- integer cell
+// coordinates from the cell number, no fp64, no per-query search -- and stages the candidates of the 27 cells ONCE in LDS as
+// float4 (contiguous runs: coalesced 16-byte loads); every query of the cell then tests them from LDS with all 64 lanes
+// (its coordinates are wave-uniform: scalar operands), compacts the accepted (d2, index) keys into its LDS slice by ballot +
+// mbcnt and counts them into the 16 distance buckets.  After every four queries the bucket sort of k_grid_query_wave runs
+// on the four slices at once (a 16-lane group per query).  Per query: one LDS pass over ~50 candidates instead of ~50 float4
+// loads through L2 and three dependent memory round trips; rows are identical to the query-centric kernel (exact order by
+// (d2, index)).  Cells whose 27-cell set exceeds CAPC candidates, and rows longer than CAP, go to the todo list.
+#define QC_WAVES 4
+#define QC_QPW 16                   // queries per wavefront
+#ifndef QC_CAPC
+#define QC_CAPC 160                 // candidates of a 27-cell set the LDS stage holds (mean ~50; larger sets go to the lane-per-query pass)
+#endif
+
+// N queries of ONE cell against its staged candidates, 64 candidates per step: N independent chains of distance test, ballot
+// compaction and bucket count per LDS read
+template <int CAP, int N>
+__device__ __forceinline__ void qc_pass(const float4* __restrict__ cd_lds, int total, const float (&q)[N][3], unsigned long long* const (&K)[N],
+                                        int* const (&H)[N], int (&m)[N], float r2, float bin_scale, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < N; u++) m[u] = 0;
+    for (int c0 = 0; c0 < total; c0 += WAVE) {
+        const int ci = c0 + lane;
+        const float4 cd = cd_lds[ci < total ? ci : 0];
+        float d2[N];
+        unsigned long long mask[N];
+#pragma unroll
+        for (int u = 0; u < N; u++) d2[u] = sqdist3(q[u][0], q[u][1], q[u][2], cd.x, cd.y, cd.z);
+#pragma unroll
+        for (int u = 0; u < N; u++) mask[u] = __ballot(ci < total && d2[u] < r2);
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            const bool hit = ci < total && d2[u] < r2;
+            const int pos = m[u] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask[u], 0u));
+            if (hit && pos < CAP) {
+                K[u][pos] = ((unsigned long long)__float_as_uint(d2[u]) << 32) | (unsigned int)__float_as_int(cd.w);
+                atomicAdd(&H[u][min((int)(d2[u] * bin_scale), QG - 1)], 1);
+            }
+            m[u] += __popcll(mask[u]);
+        }
+    }
+}
+
+template <int CAP, int CAPC>
+__global__ void __launch_bounds__(QC_WAVES * WAVE) k_grid_query_cell(const CellGrid* __restrict__ grids, const int* __restrict__ table,
+                                                                  const float4* __restrict__ sorted, const int* __restrict__ scell,
+                                                                  const int* __restrict__ q_off, float r2, float bin_scale, int k_out, int shadow,
+                                                                  int* __restrict__ nbr_out, int* __restrict__ counts_out,
+                                                                  int* __restrict__ max_count_out, int* __restrict__ todo,
+                                                                  int* __restrict__ todo_n)
+{
+    __shared__ __attribute__((aligned(16))) float4 cand[QC_WAVES][CAPC];
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[QC_WAVES][QPW][CAP];       // arrival order, then bucket order in place
+    __shared__ __attribute__((aligned(16))) int runs[QC_WAVES][20];                                // 9 starts | 9 lengths of the staged cell
+    __shared__ int hist[QC_WAVES][QPW][QG];
+    __shared__ int pref[QC_WAVES][QPW][QG + 4];
+    __shared__ int cur[QC_WAVES][QPW][QG];
+    const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int grp = lane / QG, l16 = lane & (QG - 1);
+    const int b = blockIdx.y;
+    const int e_lo = q_off[b], e_n = q_off[b + 1] - e_lo;
+    const int base = (blockIdx.x * QC_WAVES + w) * QC_QPW;
+    if (base >= e_n) return;
+    const int nq_w = min(QC_QPW, e_n - base);
+    const CellGrid g = grids[b];
+    // lanes 0..15 (and their copies in the other rows) hold the wavefront's 16 queries
+    const bool have = l16 < nq_w;
+    const float4 me = have ? sorted[e_lo + base + l16] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int mycell = have ? scell[e_lo + base + l16] : -1;
+    int staged = -2, total = 0;
+
+    // the 27-cell candidate set of cell `c` (packed coordinates, or sign bit + linear number) -> cand[w][0 .. total)
+    auto stage = [&](int c) __attribute__((always_inline)) {
+        int cx, cy, cz;
+        if (c >= 0) { cx = c & 1023; cy = (c >> 10) & 1023; cz = c >> 20; }
+        else { const int cl = c & 0x7fffffff; cx = cl % g.dim[0]; const int t2 = cl / g.dim[0]; cy = t2 % g.dim[1]; cz = t2 / g.dim[1]; }
+        int rs = 0, len = 0;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        const int y = cy + (l16 % 3) - 1, z = cz + (l16 / 3) - 1;
+        if (l16 < 9 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+            const int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
+            rs = g0 == 0 ? 0 : table[g0 - 1];
+            len = table[g0 + (x1 - x0)] - rs;
+        }
+        wave_sync();                         // the previous cell's candidates and runs have been read
+        if (lane < 10) { runs[w][lane] = rs; runs[w][10 + lane] = len; }
+        wave_sync();
+        int st[9], pre[9];
+        int tot = 0;
+        {
+            const int4* R4 = reinterpret_cast<const int4*>(runs[w]);
+            const int4 a0 = R4[0], a1 = R4[1], a2 = R4[2], a3 = R4[3], a4 = R4[4];
+            const int sv[9] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x };
+            const int lv[9] = { a2.z, a2.w, a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z };
+#pragma unroll
+            for (int jj = 0; jj < 9; jj++) { pre[jj] = tot; st[jj] = sv[jj] - tot; tot += lv[jj]; }
+        }
+        total = __builtin_amdgcn_readfirstlane(tot);
+        if (total <= CAPC) {
+            for (int c0 = 0; c0 < total; c0 += 2 * WAVE) {
+                float4 cv[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int ci = c0 + u * WAVE + lane;
+                    int off = st[0];
+#pragma unroll
+                    for (int jj = 1; jj < 9; jj++) off = ci >= pre[jj] ? st[jj] : off;
+                    cv[u] = ci < total ? sorted[ci + off] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int ci = c0 + u * WAVE + lane;
+                    if (ci < total) cand[w][ci] = cv[u];
+                }
+            }
+        }
+        wave_sync();
+    };
+
+#pragma unroll 1
+    for (int r = 0; r < QC_QPW / QPW; r++) {
+        if (r * QPW >= nq_w) break;
+        hist[w][grp][l16] = 0;
+        wave_sync();
+        int mq[QPW];
+        unsigned stage_ovf = 0;                      // bit j: the candidate set of query j's cell does not fit the LDS stage
+#pragma unroll
+        for (int j = 0; j < QPW; j++) mq[j] = 0;
+#pragma unroll
+        for (int j = 0; j < QPW; j += 2) {           // a pair of queries per pass where they share their cell (the common case)
+            const int q0 = r * QPW + j;
+            if (q0 >= nq_w) continue;
+            const int c0 = __builtin_amdgcn_readlane(mycell, q0);
+            const int c1 = q0 + 1 < nq_w ? __builtin_amdgcn_readlane(mycell, q0 + 1) : -3;
+            float qq[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                qq[u][0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me.x), (q0 + u) & (QC_QPW - 1)));
+                qq[u][1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me.y), (q0 + u) & (QC_QPW - 1)));
+                qq[u][2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(me.z), (q0 + u) & (QC_QPW - 1)));
+            }
+            if (c0 != staged) { staged = c0; stage(c0); }
+            if (c1 == c0) {
+                if (total > CAPC) { stage_ovf |= 3u << j; continue; }
+                unsigned long long* const KK[2] = { keys[w][j], keys[w][j + 1] };
+                int* const HH[2] = { hist[w][j], hist[w][j + 1] };
+                int mm[2];
+                qc_pass<CAP, 2>(cand[w], total, qq, KK, HH, mm, r2, bin_scale, lane);
+                mq[j] = mm[0]; mq[j + 1] = mm[1];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (u == 1) {
+                        if (c1 == -3) break;
+                        staged = c1; stage(c1);
+                    }
+                    if (total > CAPC) { stage_ovf |= 1u << (j + u); continue; }
+                    const float q1[1][3] = { { qq[u][0], qq[u][1], qq[u][2] } };
+                    unsigned long long* const KK[1] = { keys[w][j + u] };
+                    int* const HH[1] = { hist[w][j + u] };
+                    int mm[1];
+                    qc_pass<CAP, 1>(cand[w], total, q1, KK, HH, mm, r2, bin_scale, lane);
+                    mq[j + u] = mm[0];
+                }
+            }
+        }
+        // ---- the four slices: counts, bucket sort, rows (a 16-lane group per query, as k_grid_query_wave) ----
+        const int qn = r * QPW + grp;
+        const bool active = qn < nq_w;
+        int m = grp == 0 ? mq[0] : (grp == 1 ? mq[1] : (grp == 2 ? mq[2] : mq[3]));
+        const int qi = __float_as_int(__shfl(me.w, qn & (QC_QPW - 1), WAVE));
+        const bool sovf = (stage_ovf >> grp) & 1u;
+        if (active && l16 == 0 && !sovf) {
+            if (counts_out) counts_out[qi] = m;
+            if (max_count_out && m > 0) atomicMax(max_count_out, m);
+        }
+        const bool redo = sovf || (m > CAP && k_out > 0);   // stage or row overflow: redone (counts included) by the lane-per-query pass
+        if (redo) {
+            if (active && l16 == 0) todo[atomicAdd(todo_n, 1)] = qi;
+            m = 0;
+        }
+        if (k_out == 0) { wave_sync(); continue; }
+        int* row = nbr_out + (size_t)qi * k_out;
+        int mmax = 0;
+#pragma unroll
+        for (int j = 0; j < QPW; j++) mmax = max(mmax, mq[j] > CAP ? 0 : mq[j]);
+        wave_sync();
+        {
+            const int cnt = hist[w][grp][l16];
+            const int ex = row16_excl_scan(cnt);
+            pref[w][grp][l16] = ex;
+            cur[w][grp][l16] = ex;
+            if (l16 == QG - 1) pref[w][grp][QG] = ex + cnt;
+        }
+        wave_sync();
+        unsigned long long* K = keys[w][grp];
+        unsigned long long* B = K;                   // bucket order IN PLACE: every lane holds its keys in registers before the first scatter store
+        const int rounds = (mmax + QG - 1) / QG;
+        unsigned long long mine[CAP / QG];
+        int blo[CAP / QG], bhi[CAP / QG], bks[CAP / QG];
+#pragma unroll
+        for (int rr = 0; rr < CAP / QG; rr++) {
+            mine[rr] = 0ull; blo[rr] = 0; bhi[rr] = 0; bks[rr] = -1;
+            if (rr < rounds) {
+                const int i = rr * QG + l16;
+                if (i < m) {
+                    const unsigned long long key = K[i];
+                    const int bk = min((int)(__uint_as_float((unsigned int)(key >> 32)) * bin_scale), QG - 1);
+                    mine[rr] = key; bks[rr] = bk; blo[rr] = pref[w][grp][bk]; bhi[rr] = pref[w][grp][bk + 1];
+                }
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int rr = 0; rr < CAP / QG; rr++)
+            if (rr < rounds && bks[rr] >= 0) B[atomicAdd(&cur[w][grp][bks[rr]], 1)] = mine[rr];
+        wave_sync();
+#pragma unroll
+        for (int rr = 0; rr < CAP / QG; rr++) {
+            if (rr < rounds) {
+                int rank = blo[rr];
+                for (int tt = 0; __any(blo[rr] + tt < bhi[rr]); tt++) {
+                    const int p = blo[rr] + tt;
+                    const unsigned long long o = B[p < bhi[rr] ? p : 0];
+                    rank += (p < bhi[rr] && o < mine[rr]) ? 1 : 0;
+                }
+                if (rr * QG + l16 < m && rank < k_out) row[rank] = (int)(unsigned int)(mine[rr] & 0xffffffffu);
+            }
+        }
+        if (active && !redo) {
+            for (int i = m + l16; i < k_out; i += QG) row[i] = shadow;
+        }
+        wave_sync();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 extern "C" int64_t buf_grid_default_cells(int ns, int nb)
 {
@@ -421,7 +660,7 @@ static void carve_grid(buf_grid_t* g, WsCarver& w, int ns, int nb, int64_t cells
     g->scan_tmp = w.take<int>(scan_tmp_ints());
 }
 
-struct GridExtra { float4* sorted_tmp; int* cell_of; int* q_off; int* todo_n; };
+struct GridExtra { float4* sorted_tmp; int* cell_of; int* q_off; int* todo_n; int* scell; };
 
 static GridExtra carve_extra(WsCarver& w, int ns, int nb)
 {
@@ -430,6 +669,7 @@ static GridExtra carve_extra(WsCarver& w, int ns, int nb)
     e.cell_of = w.take<int>((size_t)(ns > 0 ? ns : 1));
     e.q_off = w.take<int>((size_t)nb + 1);
     e.todo_n = w.take<int>(64);
+    e.scell = w.take<int>((size_t)(ns > 0 ? ns : 1));          // cell of every row of the cell-ordered stream
     return e;
 }
 
@@ -471,7 +711,8 @@ extern "C" int buf_grid_build(buf_grid_t* g, const float* supports, int ns, cons
         rc = exclusive_scan_i32(g->table, (long long)table_n, (int*)g->scan_tmp, nullptr, s);
         if (rc) return rc;
         k_cell_scatter<<<cdiv(ns, 256), 256, 0, s>>>(supports, ns, ex.cell_of, nullptr, g->table, ex.sorted_tmp);
-        k_cell_rank<<<cdiv(ns, 256), 256, 0, s>>>(ex.cell_of, g->table, ex.sorted_tmp, ns, nullptr, (float4*)g->sorted, g->order);
+        k_cell_rank<<<cdiv(ns, 256), 256, 0, s>>>(ex.cell_of, g->table, ex.sorted_tmp, ns, nullptr, (float4*)g->sorted, g->order, ex.scell,
+                                                  ((const CellGrid*)g->desc)->dim, (long long)cells_per_elem, (int)(sizeof(CellGrid) / sizeof(int)));
     }
     BUF_LAUNCH_CHECK();
     return BUF_OK;
@@ -517,7 +758,19 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
         BUF_REQUIRE(g->nb <= 65535, BUF_EINVAL, "buf_grid_query: %d batch elements (at most 65535 per call)", g->nb);
         dim3 grid2(cdiv(qmax, QW_QPB), g->nb);
         const float bin_scale = r2 > 0.f ? (float)QG / r2 : 0.f;           // distance bucket = floor(d2 * 16 / r2), monotone in d2
-        if (k_out > 32)
+        static const bool query_centric = getenv("BUF_A2_QUERY_CENTRIC") != nullptr;      // development switch: the round-1..3 kernel for self queries too
+        if (self_query && todo && !query_centric) {
+            // cell-centric: 16 rows of the cell-ordered stream per wavefront, the candidates of a cell staged once in LDS
+            dim3 gridc(cdiv(qmax, QC_WAVES * QC_QPW), g->nb);
+            if (k_out > 32)
+                k_grid_query_cell<2 * QW_CAP, 512><<<gridc, QC_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, ex.scell,
+                                                                                 g->s_off, r2, bin_scale, k_out, g->ns, nbr_out, counts_out,
+                                                                                 max_count_out, todo, ex.todo_n);
+            else
+                k_grid_query_cell<QW_CAP, QC_CAPC><<<gridc, QC_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, ex.scell,
+                                                                             g->s_off, r2, bin_scale, k_out, g->ns, nbr_out, counts_out,
+                                                                             max_count_out, todo, ex.todo_n);
+        } else if (k_out > 32)
             k_grid_query_wave<2 * QW_CAP><<<grid2, QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
                                                                              queries, ex.q_off, q_order, self_query, r2, bin_scale, k_out, g->ns,
                                                                              nbr_out, counts_out, max_count_out, todo, ex.todo_n);
@@ -527,7 +780,7 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
                                                                          counts_out, max_count_out, todo, ex.todo_n);
     }
     if (timed) timing_end(s, &span);
-    if (k_out > 0 || foreign_order) {
+    if (k_out > 0 || foreign_order || (self_query && todo)) {
         // fallback pass over the (normally empty) todo list; exits at once when the device-side count is 0.  It rewrites whole
         // rows and counts (the same values where the wave kernel already counted a long row)
         if (k_out <= 32)

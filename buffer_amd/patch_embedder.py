@@ -58,7 +58,11 @@ class PatchEmbedder:
             layers.append((w, b, True))
         layers.append((np.asarray(W[f'{p}.21.weight'], np.float32), np.asarray(W[f'{p}.21.bias'], np.float32), False))
         self.layers = layers
-        self.fused = ops.CylindricalNet(layers, device)
+        arith = getattr(cfg, 'cnn_arith', 'f32')
+        if arith not in ('f32', 'split'):
+            raise ValueError(f"cnn_arith must be 'f32' or 'split', got {arith!r}")
+        # 'split': csrc/convnet_h3.hip -- the same convolutions on the f16 matrix pipe, operands split hi + 2^-11 lo' (fp32-equivalent)
+        self.fused = ops.CylindricalNetSplit(layers, device) if arith == 'split' else ops.CylindricalNet(layers, device)
         q = 'Desc.pool_layer'
         w0, b0 = _fold_bn(W[f'{q}.0.weight'], W[f'{q}.0.bias'], W[f'{q}.1.running_mean'], W[f'{q}.1.running_var'],
                           W[f'{q}.1.weight'], W[f'{q}.1.bias'])

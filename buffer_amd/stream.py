@@ -69,7 +69,8 @@ def evaluate_stream(raws, poses, first_index=0):
             sc['pairs'].append((0, 1)); sc['gt'].append(np.eye(4)); sc['info'].append(np.eye(6)); sc['est'].append(np.eye(4))
         sc['pairs'].append((3 * q + 2, 3 * q + 4))
         sc['gt'].append(np.linalg.inv(raws[k]['relt_pose']))              # gt.log: fragment j -> fragment i
-        sc['info'].append(synth.information_matrix(raws[k]['overlap_pts'].cpu().numpy()))
+        sc['info'].append(np.asarray(raws[k]['info'], np.float64) if 'info' in raws[k]
+                          else synth.information_matrix(raws[k]['overlap_pts'].cpu().numpy()))
         sc['est'].append(np.linalg.inv(poses[k]))                          # the .log holds the inverse estimate (test.py:255)
     per_scene = []
     for sc in scenes:

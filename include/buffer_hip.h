@@ -109,8 +109,10 @@ int     buf_grid_build(buf_grid_t* g, const float* supports, int ns, const int* 
 int     buf_grid_query(const buf_grid_t* g, const float* queries, int nq, const int* q_batches_host,
                        const int* q_order, float radius, int k_out, int* nbr_out, int* counts_out,
                        int* max_count_out, void* todo_ws, void* stream);
-/* todo_ws: int32[nq] scratch (rows longer than 64 neighbours are redone by a second, unbounded pass);
- * may be null when k_out == 0 and q_order is null or the grid's own order.
+/* todo_ws: int32[nq] scratch (rows longer than 64 neighbours -- and, in the cell-centric self query, cells whose 27-cell
+ * candidate set exceeds the LDS stage -- are redone by a second, unbounded pass).  It may be null ONLY when k_out == 0 and
+ * either q_order is null or the call is a self query (queries == the grid's supports, nq == ns, q_order == g->order); a
+ * self query without it runs on the query-centric kernel.
  * Build + query in one call (what batch_query does); ws >= buf_grid_ws_bytes(ns,nb,0) + 4*nq bytes. */
 int     buf_radius_neighbors(const float* queries, int nq, const float* supports, int ns,
                              const int* q_batches_host, const int* s_batches_host, int nb, float radius,
@@ -258,7 +260,7 @@ int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* w
 
 /* A11 (dense), split-f16 form -- the same stack with fp32-EQUIVALENT arithmetic on the f16 matrix pipe (csrc/convnet_h3.hip; opt-in,
  * the all-fp32 kernel above stays the default): every fp32 operand is split once into hi = f16(x) and lo' = f16((x - hi) 2^11)
- * (x = hi + 2^-11 lo' to 2^-24 |x|), a product sum is [sum hi hi] + 2^-11 [sum hi lo' + sum lo' hi] in two fp32 accumulators:
+ * (x = hi + 2^-11 lo' to one fp32 ulp), a product sum is [sum hi hi] + 2^-11 [sum hi lo' + sum lo' hi] in two fp32 accumulators:
  * three v_mfma_f32_16x16x32_f16 per (16 outputs x 16 positions x 32 channels), direct 9-tap form.  Measured against the float64
  * stack: not worse than the fp32 kernels (tests/test_model_gpu.py, profiles/r04_f16_split.txt).  Requires every activation and
  * weight below 65504 in magnitude (f16 range): weights are checked by the tiler, an activation that leaves the range sets bit 0

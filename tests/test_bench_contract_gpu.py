@@ -18,8 +18,9 @@ def _run(args, env=None, timeout=1200):
     return json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')][-1])
 
 
-def test_bench_json_line(dev):
-    d = _run(['--steps', '2', '--warmup', '1', '--pairs-per-step', '4', '--keypts', '600'])
+def test_bench_json_line(dev, tmp_path):
+    detail = str(tmp_path / 'detail.json')
+    d = _run(['--steps', '2', '--warmup', '1', '--pairs-per-step', '4', '--keypts', '600', '--detail-json', detail])
     assert d['metric'] == 'registration pairs/sec' and d['unit'] == 'pairs/s' and d['higher_is_better'] is True
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
     assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['vs_baseline'] is None
@@ -27,28 +28,53 @@ def test_bench_json_line(dev):
     assert 'workload' in d['config'] and 'model' not in d['config'] and 'configs[1]' in d['config']['workload']
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3 and r['launches'] == 2
-    # achieved / frac = flops EXECUTED on the matrix pipe (the Winograd-domain kernel runs 0.508 of the dense count): a fraction of
-    # the peak, never above 1; the dense algorithmic count over the same time rides along as dense_equivalent_tflops
+    # achieved / frac = flops of the ISSUED matrix instructions (the Winograd-domain kernel runs 0.508 of the dense count): a fraction
+    # of the peak, never above 1; the dense algorithmic count over the same time rides along as dense_equivalent_tflops
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.1 < r['frac'] < 1.0
-    assert abs(r['executed_fraction_of_dense'] - 40 * 1024 / (9 * 140 * 64)) < 1e-12
-    assert abs(r['dense_equivalent_tflops'] * r['executed_fraction_of_dense'] - r['achieved']) < 1e-9 * r['achieved']
+    assert abs(r['useful_fraction_of_dense'] - 40 * 1024 / (9 * 140 * 64)) < 1e-12
+    assert abs(r['dense_equivalent_tflops'] * r['useful_fraction_of_dense'] - r['achieved']) < 1e-9 * r['achieved']
     assert r['traffic'] is None or (r['traffic'] > 0 and 'replayed' in r['traffic_source'])
     assert 'k_cyl_net_wg' in r['kernel']
-    # every kernel SURVEY 8(d) gives a roofline class: A1, A2, A4, A6, A8, A10, A11 head, A12, A13
+    # the opt-in split-f16 region: its own keys, the headline untouched
+    rs = d['roofline_split']
+    assert 'k_cyl_net_h3' in rs['kernel'] and 'f16x3 split' in rs['arithmetic'] and rs['peak'] == 2500.0 and rs['launches'] == 2
+    assert abs(rs['frac'] - rs['achieved'] / rs['peak']) < 1e-9 and 0.05 < rs['frac'] < 1.0
+    assert rs['error_vs_float64'] < 1e-5 and rs['error_vs_float64'] <= 1.5 * rs['error_vs_float64_fp32_kernel']
+    assert abs(d['value_split'] - 4 * 2 / (d['ms_per_step_split'] * 2e-3)) < 1e-6 * d['value_split']
+    assert d['split']['registered_ok'].startswith('8/8') and d['split']['max_abs_pose_difference_vs_f32_kernels'] < 1e-3
+    # every kernel SURVEY 8(d) gives a roofline class: A1, A2, A4, A6, A8, A10, A11 head, A12, A13 -- compact entries
     names = ' '.join(o['kernel'] for o in d['roofline_other'])
     for k in ('k_cost_net', 'k_grid_query', 'k_vox_', 'k_vn_gather', 'k_select_patches', 'k_patch_voxelize', 'k_desc_head', 'k_nn1', 'k_fps'):
         assert k in names, k
     for o in d['roofline_other']:
-        assert o['launches'] > 0 and o['avg_us'] > 0 and (o['frac'] is None or 0 < o['frac'] < 1.0), o
+        assert set(o) == {'kernel', 'bound', 'frac', 'avg_us', 'traffic_ratio'}
+        assert o['avg_us'] > 0 and (o['frac'] is None or 0 < o['frac'] < 1.0), o
+    assert d['single_pair_latency_ms'] > 0 and d['keypoint_stage_ms']['one_pair'] > 0 and d['keypoint_stage_ms']['per_step'] > 0
     c = d['cpu_baseline']
-    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['workers'] >= 1 and c['value'] > 0 and c['unit'] == 'pairs/s'
+    assert c['kind'] in ('reference cores (pyramid) + restated model', 'port') and c['cores'] >= 1 and c['workers'] >= 1 and c['value'] > 0 and c['unit'] == 'pairs/s'
     assert 'nothing scaled' in c['sample'] and c['stages_s']['descriptors'] > 0
     assert d['config']['registered_ok'].startswith('8/8') and d['config']['distinct_pairs_per_gpu'] == 4      # = pairs per step
+    # the driver keeps the last 2000 characters of the line: the four round-4 keys and every compact entry must be inside them
+    line = json.dumps(d)
+    tail = line[-2000:]
+    for k in ('"single_pair_latency_ms"', '"keypoint_stage_ms"', '"roofline_other"', 'k_grid_query', 'k_fps'):
+        assert k in tail, k
+    full = json.load(open(detail))
+    assert full['roofline_other'][0]['launches'] > 0 and 'timed_kernel_ms_per_step' in full
+
+
+def test_bench_strong_scaling_mode_two_ranks_over_gloo(dev):
+    """--total-pairs: the job's pairs of a step are fixed and dealt i -> rank i mod N (5 pairs on 2 ranks: 3 + 2)."""
+    d = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--total-pairs', '5', '--keypts', '400', '--no-cpu-baseline', '--no-split'],
+             env={'BENCH_BACKEND': 'gloo'})
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['config']['pairs_per_step_job'] == 5
+    assert abs(d['value'] - 2 * 5 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    assert d['config']['gathered_poses'] == [6, 6] and d['config']['registered_ok'].startswith('6/6')      # rank 0: 3 pairs x 2 steps
 
 
 def test_bench_two_ranks_on_one_device_over_gloo(dev):
     """`python bench.py --gpus 2` with no launcher: bench.py starts torch.distributed.run itself; both ranks share cuda:0."""
-    d = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--pairs-per-step', '3', '--keypts', '400', '--no-cpu-baseline'],
+    d = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--pairs-per-step', '3', '--keypts', '400', '--no-cpu-baseline', '--no-split'],
              env={'BENCH_BACKEND': 'gloo'})
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and 'cpu_baseline' not in d
     assert d['config']['parallelism'] == 'pair-sharded x2' and d['config']['gathered_poses'] == [6, 6]     # steps x pairs, per rank

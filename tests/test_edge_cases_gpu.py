@@ -130,6 +130,10 @@ def test_c_abi_error_codes(dev):
     bad_out = (C.c_int * 8)(64, 64, 128, 128, 64, 64, 32, 64)                   # the last layer must have 32 channels
     rc = L.buf_cylindrical_net_wg(x.data_ptr(), 2, wp, bp, (C.c_int * 8)(*good_in), bad_out, relu, y.data_ptr(), s)
     assert rc == -1
+    # a wide layer behind a 32-output layer: the K-split hand-over of the 32-output layers overwrites the padding zeros of channels 64..95
+    wide_in, wide_out = (C.c_int * 8)(48, 64, 32, 64, 128, 128, 64, 32), (C.c_int * 8)(64, 32, 64, 128, 128, 64, 32, 32)
+    rc = L.buf_cylindrical_net_wg(x.data_ptr(), 2, wp, bp, wide_in, wide_out, relu, y.data_ptr(), s)
+    assert rc == -1 and b"may follow a 32-output layer" in L.buf_last_error()
     wp_null = (C.c_void_p * 8)(*([w.data_ptr() for w in wts[:7]] + [None]))
     rc = L.buf_cylindrical_net_wg(x.data_ptr(), 2, wp_null, bp, (C.c_int * 8)(*good_in), (C.c_int * 8)(*good_out), relu, y.data_ptr(), s)
     assert rc == -1 and b"null weights" in L.buf_last_error()

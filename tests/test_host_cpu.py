@@ -145,6 +145,60 @@ def test_pair_sharding_two_gloo_ranks(tmp_path):
         assert f"ok {r}" in o
 
 
+_WORKER8 = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from buffer_amd import dist as bd
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+def pose(i):
+    T = torch.eye(4); T[0, 3] = float(i); T[1, 3] = -0.5 * i
+    return T
+# 1623 (3DMatch) and 1781 (3DLoMatch) pairs: neither divides by 8; 5 and 0 pairs: fewer pairs than ranks (empty shards)
+for n in (1623, 1781, 5, 0):
+    ids = bd.shard_indices(n, rank, world)
+    assert len(ids) in (n // world, n // world + 1) and all(i % world == rank for i in ids)
+    poses = torch.stack([pose(i) for i in ids]) if ids else torch.zeros(0, 4, 4)
+    extra = torch.tensor([[float(i), 2.0 * i, -1.0] for i in ids]).reshape(-1, 3)
+    allp, ext = bd.gather_poses(ids, poses, n, extra=extra)
+    assert allp.shape == (n, 4, 4) and ext.shape == (n, 3)
+    for i in range(n):
+        assert torch.equal(allp[i], pose(i)), (rank, n, i)
+        assert ext[i].tolist() == [float(i), 2.0 * i, -1.0]
+    assert torch.equal(bd.gather_poses(ids, poses, n), allp)                      # without the payload
+# any id assignment: the ids travel as int32 in their own exchange (rank r reports the pairs of rank 7 - r, reversed)
+n = 29
+ids = bd.shard_indices(n, world - 1 - rank, world)[::-1]
+poses = torch.stack([pose(i) for i in ids]) if ids else torch.zeros(0, 4, 4)
+allp = bd.gather_poses(ids, poses, n, explicit_ids=True)
+for i in range(n):
+    assert torch.equal(allp[i], pose(i)), (rank, i)
+try:
+    bd.gather_poses(ids, poses, n)
+    raise SystemExit('ids that break the sharding rule were accepted')
+except ValueError:
+    pass
+assert torch.isfinite(allp).all()
+dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_pair_sharding_eight_gloo_ranks_uneven_and_empty_shards(tmp_path):
+    """SURVEY 8e at the node's world size: 1623 / 1781 pairs (neither divides by 8), fewer pairs than ranks, the ground-truth
+    payload in the same exchange, explicit int32 ids; no float block ever carries an id (round 3: id -1 as float bits = NaN)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"ok {r}" in o
+
+
 def test_shard_indices_cover_everything():
     from buffer_amd import dist as bd
     for n in (0, 1, 7, 1623):
@@ -226,3 +280,51 @@ def test_winograd_filter_tiling_reproduces_the_convolution():
     got3 = np.empty(16 * 128 * 32, np.float32)
     assert _lib.lib().buf_winograd_tile_weights(w3.ctypes.data_as(C.c_void_p), 128, 32, got3.ctypes.data_as(C.c_void_p)) == 0
     assert np.array_equal(got3, t3)
+
+
+def test_split_filter_tiling_is_the_f16_pair_of_every_weight():
+    """buf_split_tile_filters (host side of csrc/convnet_h3.hip): un-tiling gives hi = f16(w) and lo' = f16((w - hi) 2^11) bit for
+    bit as numpy rounds them (round to nearest even, subnormals kept), hi + 2^-11 lo' reproduces w to 2^-23 |w| (+ the f16
+    subnormal floor 2^-36), channels beyond Cin are zero, and weights outside the f16 range are rejected."""
+    from buffer_amd import _lib, ops
+    rng = np.random.default_rng(5)
+    for cout, cin in ((64, 48), (32, 32), (128, 128)):
+        w = (rng.standard_normal((cout, cin, 3, 3)) * rng.choice([1e-7, 1e-4, 0.05, 3.0], size=(cout, cin, 3, 3))).astype(np.float32)
+        w[0, 0, 0, 0], w[1, 0, 0, 0], w[2, 0, 0, 0] = 0.0, 6.0e-8, 65503.0                         # zero, f16-subnormal hi, near the top
+        KS = (cin + 31) // 32
+        t = ops.split_tile_filters(w).reshape(cout // 32, 9, KS, 2, 2, 4, 16, 8)                 # [g, tap, ks, n2, plane, kg, row, i]
+        t = np.transpose(t, (4, 0, 3, 6, 2, 5, 7, 1)).reshape(2, cout, KS * 32, 9)              # [plane, o, c, tap]
+        hi = w.reshape(cout, cin, 9).astype(np.float16)
+        lo = ((w.reshape(cout, cin, 9) - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+        assert np.array_equal(t[0, :, :cin], hi.view(np.uint16)) and np.array_equal(t[1, :, :cin], lo.view(np.uint16))
+        assert not t[:, :, cin:].any()
+        back = hi.astype(np.float64) + lo.astype(np.float64) / 2048
+        assert np.all(np.abs(back - w.reshape(cout, cin, 9)) <= np.abs(w.reshape(cout, cin, 9)) * 2.0 ** -23 + 2.0 ** -36)
+    w[3, 1, 1, 1] = 7.0e4
+    with pytest.raises(_lib.BufferHipError):
+        ops.split_tile_filters(w)
+
+
+def test_cnn_entry_points_reject_unsupported_stacks_before_any_device_work():
+    """argument checks of the two descriptor-CNN entry points (no GPU needed: both return before the first HIP call): a wide layer
+    behind a 32-output layer (the fp32 Winograd kernel's K-split hand-over overwrites the padding zeros of channels
+    64..95), Cin 65..96 in the split kernel (three k-steps: not built), a last layer that is not 32 wide."""
+    import ctypes as C
+    from buffer_amd import _lib
+    L = _lib.lib()
+    dummy = (C.c_float * 4)()
+    ptrs = (C.c_void_p * 8)(*[C.addressof(dummy)] * 8)
+    relu = (C.c_int * 8)(1, 1, 1, 1, 1, 1, 1, 0)
+    ints = lambda *v: (C.c_int * 8)(*v)
+    x = C.addressof(dummy)
+    ok_in, ok_out = ints(48, 64, 64, 128, 128, 64, 64, 32), ints(64, 64, 128, 128, 64, 64, 32, 32)
+    assert L.buf_cylindrical_net_wg(x, 0, ptrs, ptrs, ok_in, ok_out, relu, x, None) == 0          # nothing to do
+    assert L.buf_cylindrical_net_split(x, 0, ptrs, ptrs, ok_in, ok_out, relu, x, None, None) == 0
+    rc = L.buf_cylindrical_net_wg(x, 2, ptrs, ptrs, ints(48, 64, 32, 64, 128, 128, 64, 32), ints(64, 32, 64, 128, 128, 64, 32, 32), relu, x, None)
+    assert rc == -1 and b"may follow a 32-output layer" in L.buf_last_error()
+    rc = L.buf_cylindrical_net_split(x, 2, ptrs, ptrs, ints(80, 64, 64, 128, 128, 64, 64, 32), ok_out, relu, x, None, None)
+    assert rc == -1 and b"Cin 65..96" in L.buf_last_error()
+    rc = L.buf_cylindrical_net_split(x, 2, ptrs, ptrs, ok_in, ints(64, 64, 128, 128, 64, 64, 32, 64), relu, x, None, None)
+    assert rc == -1
+    rc = L.buf_cylindrical_net_split(x, 2, ptrs, ptrs, ints(48, 64, 64, 128, 128, 64, 64, 64), ok_out, relu, x, None, None)
+    assert rc == -1 and b"width mismatch" in L.buf_last_error()

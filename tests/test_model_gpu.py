@@ -70,6 +70,56 @@ def test_patch_embedder_vs_reference(W, dev):
     np.testing.assert_allclose(out['equi'].cpu().numpy(), f['equi'], rtol=1e-4, atol=2e-5)
 
 
+def test_patch_embedder_split_arithmetic_vs_reference(W, dev):
+    """the opt-in split-f16 descriptor CNN (cnn_arith='split', csrc/convnet_h3.hip) against the same fixture F4 at the same tolerance,
+    and against the fp32 kernel: descriptors within 2e-6 of each other."""
+    from dataclasses import replace
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    f = load("desc_tiny.npz")
+    pe = PatchEmbedder(W, dev, replace(THREEDMATCH, cnn_arith='split'))
+    assert pe.fused.entry == "buf_cylindrical_net_split"
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = pe(t(f['raw']), t(f['kpts']), t(f['kaxis']), t(f['perm']))
+    np.testing.assert_allclose(out['desc'].cpu().numpy(), f['desc'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out['equi'].cpu().numpy(), f['equi'], rtol=1e-4, atol=2e-5)
+    ref = PatchEmbedder(W, dev, THREEDMATCH)(t(f['raw']), t(f['kpts']), t(f['kaxis']), t(f['perm']))
+    assert (out['desc'] - ref['desc']).abs().max().item() < 2e-6
+    pe.fused.check_range()
+    with pytest.raises(ValueError):
+        PatchEmbedder(W, dev, replace(THREEDMATCH, cnn_arith='bf16'))
+
+
+def test_split_kernel_flags_activations_outside_the_f16_range(W, dev):
+    """fail loudly: an activation >= 65504 sets the status word and check_range() raises; other widths run (64 -> 128 -> 32 ...)
+    and agree with library convolutions; unsupported widths are rejected on the host."""
+    from buffer_amd import _lib, ops
+    rng = np.random.default_rng(2)
+    widths = [(32, 64), (64, 128), (128, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 32)]
+    layers = [((rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32), (rng.standard_normal(co) * 0.1).astype(np.float32), i < 7)
+              for i, (ci, co) in enumerate(widths)]
+    net = ops.CylindricalNetSplit(layers, dev)
+    x = torch.from_numpy(rng.standard_normal((9, 32, 140)).astype(np.float32)).to(dev)
+    h = x.double().reshape(-1, 32, 7, 20)
+    for w, b, relu in layers:
+        h = torch.cat([h[..., -1:], h, h[..., :1]], -1)
+        h = torch.nn.functional.pad(h, (0, 0, 1, 1))
+        h = torch.nn.functional.conv2d(h, torch.from_numpy(w).double().to(dev), torch.from_numpy(b).double().to(dev))
+        h = torch.relu(h) if relu else h
+    y = net(x)
+    assert (y.double() - h).abs().max().item() < 1e-5 * h.abs().max().item()
+    net.check_range()
+    net(x * 1e6)
+    with pytest.raises(FloatingPointError):
+        net.check_range()
+    net.check_range()                                                          # the flag was cleared
+    bad = list(layers)
+    bad[0] = ((rng.standard_normal((64, 80, 3, 3))).astype(np.float32), layers[0][1], True)      # Cin 80: three k-steps, not built
+    bad[1] = ((rng.standard_normal((128, 64, 3, 3))).astype(np.float32), layers[1][1], True)
+    with pytest.raises(_lib.BufferHipError):
+        ops.CylindricalNetSplit(bad, dev)(torch.zeros(1, 80, 140, device=dev))
+
+
 def test_voxelize_vs_oracle_spt(W, dev):
     """fused A9+A10+point-MLP == oracle SPT [P,420,10,3] -> conv1x1+BN+ReLU -> max (incl. the zero-slot quirks)."""
     from buffer_amd.config import THREEDMATCH
@@ -160,6 +210,7 @@ def test_winograd_and_direct_forms_against_float64(W, dev):
     assert pe.fused.entry == "buf_cylindrical_net_wg"
     from util import DirectCylindricalNet
     direct = DirectCylindricalNet(pe.layers, dev)                       # tests/native: the round-1/2 kernel, test infrastructure now
+    split = ops.CylindricalNetSplit(pe.layers, dev)                     # csrc/convnet_h3.hip: fp32-equivalent on the f16 matrix pipe (opt-in)
     g = torch.Generator(device='cpu').manual_seed(5)
     for signed in (False, True):
         x = torch.rand((70, 16, 420), generator=g)
@@ -173,12 +224,17 @@ def test_winograd_and_direct_forms_against_float64(W, dev):
             h = torch.nn.functional.conv2d(h, torch.from_numpy(w).double().to(dev), torch.from_numpy(b).double().to(dev))
             h = torch.relu(h) if relu else h
         scale = h.abs().max().item()
-        yw, yd = pe.fused(x), direct(x)
-        assert (yw.double() - h).abs().max().item() < 1e-5 * scale
-        assert (yd.double() - h).abs().max().item() < 1e-5 * scale
+        yw, yd, ys = pe.fused(x), direct(x), split(x)
+        ew, ed, es = ((v.double() - h).abs().max().item() / scale for v in (yw, yd, ys))
+        print(f'signed={signed}: error vs float64 / output scale: winograd fp32 {ew:.2e}, direct fp32 {ed:.2e}, split f16 {es:.2e}')
+        assert ew < 1e-5 and ed < 1e-5
         assert (yw - yd).abs().max().item() < 1e-5 * scale
+        # the split-f16 form: the SAME bound, and not more than 1.5 x the fp32 product kernel's error (measured: 0.5-0.6 x)
+        assert es < 1e-5 and es <= 1.5 * ew
         perm = torch.randperm(70, generator=g).to(dev)
         assert torch.equal(pe.fused(x[perm]), yw[perm])
+        assert torch.equal(split(x[perm]), ys[perm])
+    split.check_range()                                                      # no activation left the f16 range
 
 
 def test_fused_descriptor_head_vs_library(W, dev):

@@ -101,9 +101,10 @@ def test_threedmatch_layout_end_to_end(tmp_path, dev):
 
 
 @pytest.mark.gpu
-def test_threedmatch_cli_two_gloo_ranks_write_the_same_logs(tmp_path, dev):
-    """python -m buffer_amd.threedmatch under 2 ranks (sharing the one device, BUFFER_DIST_BACKEND=gloo): pair i -> rank
-    i mod 2, one all_gather of poses, rank 0 writes the logs -- same files as the 1-rank run (poses to fp32 round-off: the
+@pytest.mark.parametrize("world", [2, 8])
+def test_threedmatch_cli_gloo_ranks_write_the_same_logs(tmp_path, dev, world):
+    """python -m buffer_amd.threedmatch under 2 and under 8 ranks (sharing the one device, BUFFER_DIST_BACKEND=gloo): pair i ->
+    rank i mod W, one all_gather of poses, rank 0 writes the logs -- same files as the 1-rank run (poses to fp32 round-off: the
     stacked launches of the two runs group the pairs differently)."""
     import json
     import subprocess
@@ -117,13 +118,13 @@ def test_threedmatch_cli_two_gloo_ranks_write_the_same_logs(tmp_path, dev):
     one = subprocess.run([sys.executable, '-m', 'buffer_amd.threedmatch', '--log-root', str(tmp_path / 'one')] + common,
                          capture_output=True, text=True, env=env, cwd=repo, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
-    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                          '--master-port', '29547', '-m', 'buffer_amd.threedmatch', '--log-root', str(tmp_path / 'two')] + common,
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+                          '--master-port', str(29547 + world), '-m', 'buffer_amd.threedmatch', '--log-root', str(tmp_path / 'two')] + common,
                          capture_output=True, text=True, env=env, cwd=repo, timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
     o1 = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][-1])
     o2 = json.loads([l for l in two.stdout.splitlines() if l.startswith('{')][-1])
-    assert o1['pairs'] == o2['pairs'] == 24 and o2['n_gpus'] == 2 and o1['n_gpus'] == 1
+    assert o1['pairs'] == o2['pairs'] == 24 and o2['n_gpus'] == world and o1['n_gpus'] == 1
     assert o1['registration_recall'] == o2['registration_recall'] and o1['dgr_recall'] == o2['dgr_recall']
     worst = 0.0
     for scene in tdm.SCENES:
@@ -131,5 +132,5 @@ def test_threedmatch_cli_two_gloo_ranks_write_the_same_logs(tmp_path, dev):
         k2, t2 = evaluate.read_trajectory(os.path.join(str(tmp_path / 'two'), scene, 'run.log'))
         assert [tuple(k) for k in k1] == [tuple(k) for k in k2]
         worst = max(worst, float(np.abs(np.asarray(t1, np.float64) - np.asarray(t2, np.float64)).max()))
-    print('1-rank vs 2-rank log difference:', worst)
+    print(f'1-rank vs {world}-rank log difference:', worst)
     assert worst < 1e-4

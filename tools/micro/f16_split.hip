@@ -1,5 +1,5 @@
 // Development aid (round 4): numerics of the split-f16 form of an fp32 dot product on the f16 matrix pipe.
-//   x = hi + 2^-11 lo',  hi = f16(x) (RNE),  lo' = f16((x - hi) * 2^11)   (|x - hi - 2^-11 lo'| <= 2^-24 |x|)
+//   x = hi + 2^-11 lo',  hi = f16(x) (RNE),  lo' = f16((x - hi) * 2^11)   (|x - hi - 2^-11 lo'| <= 2^-23 |x|)
 //   sum x w  ~  [hi_x hi_w]  +  2^-11 [hi_x lo'_w + lo'_x hi_w]           (two fp32 accumulators, three MFMAs per k-step)
 // Questions answered on the hardware: (1) does v_mfma_f32_16x16x32_f16 keep f16 subnormal INPUTS (it does or it does not:
 // printed), (2) how far is the three-product form from the float64 dot product over K = 1152 (a 128-channel 3x3 layer), next
