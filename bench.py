@@ -219,6 +219,10 @@ def roofline_split(timed, pmc, units, err):
          'dense_equivalent_tflops': work / n / sec / 1e12,
          'flops': 'achieved = 22842 issued MFMAs per patch x 16384 flops / HIP-event time; dense algorithmic count 0.1187 GFLOP/patch'}
     e.update(err or {})
+    nc, msc, wc = timed['cost_net_split']
+    if nc:                                           # csrc/costnet_h3.hip rides along: dense-equivalent rate only (work = SURVEY 8d's 0.160 GFLOP/match)
+        e['cost_net_split'] = {'kernel': 'k_cost_net_h3', 'avg_us': msc / nc * 1e3, 'dense_equivalent_tflops': wc / nc / (msc / nc * 1e-3) / 1e12,
+                               'matches_per_launch': wc / nc / COST_NET_DENSE_FLOPS_PER_MATCH}
     return e
 
 
@@ -457,6 +461,7 @@ def main():
         pipe_s = BufferPipeline(replace(cfg, cnn_arith='split'), dev, limits=limits)
         poses_s, mine_s, _, elapsed_s, timed_s = timed_region(pipe_s, 1)
         pipe_s.desc.fused.check_range()
+        pipe_s.inlier.fused.check_range()
         if rank == 0:
             dpose = float((mine_s - mine).abs().max().item()) if mine.numel() else 0.0
             split = dict(elapsed=elapsed_s, timed=timed_s, ok=dgr_ok(mine_s.cpu().numpy(), gts), dpose=dpose,

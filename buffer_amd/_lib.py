@@ -72,6 +72,10 @@ _SIGNATURES = {
                                 _vp, _vp, _sz, _vp]),
     "buf_cylindrical_net_wg": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_cylindrical_net_split": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_split_gemm_count": (C.c_longlong, [_i, _i, _i, _i]),
+    "buf_split_tile_gemm": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "buf_cost_volume_net_split": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "buf_cost_volume_net_split_gather": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "buf_split_filter_count": (C.c_longlong, [_i, _i]),
     "buf_split_tile_filters": (_i, [_vp, _i, _i, _vp]),
     "buf_winograd_tile_weights": (_i, [_vp, _i, _i, _vp]),

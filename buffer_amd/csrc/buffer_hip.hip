@@ -12,4 +12,5 @@
 #include "convnet_wg.hip"
 #include "convnet_h3.hip"
 #include "costnet.hip"
+#include "costnet_h3.hip"
 #include "preprocess.hip"

@@ -33,7 +33,9 @@
 // [hi | lo'][lane][8], 4 KB per (tap, k-step) and wavefront, one step ahead in registers.
 #include "common.h"
 
-#define H3_S 544u                       // bytes per position
+#ifndef H3_S
+#define H3_S 544u                       // bytes per position (136 words = 8 mod 64 banks; 528 measured the same, 560 is 20 % slower)
+#endif
 #define H3_LO 256u                      // offset of the lo' plane inside a position's row
 #define H3_NPOS 140
 #define H3_ZERO (H3_NPOS * H3_S)        // the zero row
@@ -69,6 +71,11 @@ __device__ __forceinline__ h3u4 h3_ldw(__amdgpu_buffer_rsrc_t rs, unsigned unifo
     return __builtin_amdgcn_raw_buffer_load_b128(rs, lane_byte_ofs, uniform_byte_ofs, 0);
 }
 
+// Range watch: running maximum of |v| as an unsigned bit pattern (a NaN compares above every finite value): one AND + one MAX per
+// value, no comparison kept alive (a bool OR-ed per value made the compiler park every |v| of a tile set in scratch).
+#define H3_F16_LIMIT_BITS 0x477fe000u           // 65504.f
+__device__ __forceinline__ void h3_watch(unsigned& amax, float v) { amax = max(amax, __float_as_uint(v) & 0x7fffffffu); }
+
 // x = hi + 2^-11 lo'
 __device__ __forceinline__ void h3_split(float v, _Float16& hi, _Float16& lo)
 {
@@ -96,9 +103,17 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
     auto row = [&](const unsigned (&r)[NDW], int t) __attribute__((always_inline)) {
         return (((t & 1) ? (r[t >> 1] >> 16) : (r[t >> 1] & 0xffffu)) << 4) + kgo;
     };
-    h3u4 Wc[2][2], Wn[2][2];
+    // weights: the blocks (tap, k-step) of 4 KB, WD blocks ahead in registers.  A block feeds 6 PT matrix instructions (96 PT cycles).
+    // Two blocks ahead for the 2..5-tile wavefronts measured +-0 (85.0 vs 86.0 ms per 320 000 patches): the partner workgroup of the
+    // CU covers the fetch; the kernel sits at 73 % matrix-pipe busy at the ~1.8 GHz the chip holds under f16 MFMA load.
+    constexpr int WD = 1;
+    h3u4 Wc[2][2], Wn[2][2], Wnn[2][2];
 #pragma unroll
     for (int q = 0; q < 4; q++) Wc[q >> 1][q & 1] = h3_ldw(rs, wofs + q * 1024u, lofs);
+    if constexpr (WD == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Wn[q >> 1][q & 1] = h3_ldw(rs, wofs + (9 * KS > 1 ? 4096u : 0u) + q * 1024u, lofs);
+    }
     h3u4 X[3][2];
 #pragma unroll
     for (int g = 0; g < 2; g++) {
@@ -114,11 +129,11 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const int pt = s % PT, ks = s / PT, g = s + 2;
-            if (pt == 0) {                                       // the next (tap, k-step)'s weights (past the end: the last block again)
-                const int nstep = tap * KS + ks + 1;
+            if (pt == 0) {                                       // the weights WD blocks on (past the end: the last block again)
+                const int nstep = tap * KS + ks + WD;
                 const unsigned wn = wofs + (unsigned)(nstep < 9 * KS ? nstep : 9 * KS - 1) * 4096u;
 #pragma unroll
-                for (int q = 0; q < 4; q++) Wn[q >> 1][q & 1] = h3_ldw(rs, wn + q * 1024u, lofs);
+                for (int q = 0; q < 4; q++) (WD == 2 ? Wnn : Wn)[q >> 1][q & 1] = h3_ldw(rs, wn + q * 1024u, lofs);
             }
             {
                 const unsigned a = g < S ? row(rc, g % PT) + (unsigned)(g / PT) * 64u : row(rn, (g - S) % PT) + (unsigned)(((g - S) / PT) % KS) * 64u;
@@ -139,7 +154,10 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
             __builtin_amdgcn_sched_barrier(0);
             if (pt == PT - 1) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) Wc[q >> 1][q & 1] = Wn[q >> 1][q & 1];
+                for (int q = 0; q < 4; q++) {
+                    Wc[q >> 1][q & 1] = Wn[q >> 1][q & 1];
+                    if constexpr (WD == 2) Wn[q >> 1][q & 1] = Wnn[q >> 1][q & 1];
+                }
             }
         }
         // S steps moved the ring by S mod 3: bring it back so that the next tap starts at slot 0
@@ -157,7 +175,7 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
                                          int relu, int ct, int pt0, unsigned lane, float* __restrict__ y, int* status)
 {
     const int li = lane & 15, lk = lane >> 4;
-    bool ovf = false;
+    unsigned amax = 0u;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, 0x7fffffff, 0x00027000);
     unsigned ybase = (unsigned)((32 * ct * H3_NPOS + 16 * pt0) * 4);
     asm volatile("" : "+s"(ybase));                              // (the per-store scalar offsets are formed here as well)
@@ -172,7 +190,7 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 v[r] = (am[n][t][r] + ac[n][t][r] * (1.f / 2048.f)) + b[r];
-                if constexpr (!LAST) ovf |= !(fabsf(v[r]) < 65504.f);       // before the ReLU: fmaxf(NaN, 0) = 0 would hide an overflow upstream
+                if constexpr (!LAST) h3_watch(amax, v[r]);                  // before the ReLU: fmaxf(NaN, 0) = 0 would hide an overflow upstream
                 if (relu) v[r] = fmaxf(v[r], 0.f);
             }
             if constexpr (LAST) {
@@ -198,7 +216,7 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
             }
         }
     }
-    if (!LAST && status && __builtin_amdgcn_ballot_w64(ovf) != 0 && lane == 0) atomicOr(status, 1);
+    if (!LAST && status && __builtin_amdgcn_ballot_w64(amax >= H3_F16_LIMIT_BITS) != 0 && lane == 0) atomicOr(status, 1);
 }
 
 template <int PT, int KS>
@@ -255,7 +273,7 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         // dwords are consecutive banks)
         const int cin0 = P.cin[0], np = cin0 >> 1, cpad = (cin0 + 31) & ~31;
         const float* src = x + (size_t)patch * cin0 * H3_NPOS;
-        bool ovf = false;
+        unsigned amax = 0u;
         for (int i = tid; i < 35 * np; i += H3_THREADS) {
             const int q = i / np, cp = i - q * np;
             const h3f4 a = __builtin_nontemporal_load(reinterpret_cast<const h3f4*>(src + (2 * cp) * H3_NPOS + 4 * q));
@@ -266,13 +284,13 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
                 _Float16 h, l;
                 h3_split(a[j], h, l); hi[0] = h; lo[0] = l;
                 h3_split(b[j], h, l); hi[1] = h; lo[1] = l;
-                ovf = ovf || !(fabsf(a[j]) < 65504.f) || !(fabsf(b[j]) < 65504.f);
+                h3_watch(amax, a[j]); h3_watch(amax, b[j]);
                 const unsigned ad = lds0 + (unsigned)(4 * q + j) * H3_S + 4u * cp;
                 *(__attribute__((address_space(3))) unsigned*)(size_t)ad = __builtin_bit_cast(unsigned, hi);
                 *(__attribute__((address_space(3))) unsigned*)(size_t)(ad + H3_LO) = __builtin_bit_cast(unsigned, lo);
             }
         }
-        if (P.status && __builtin_amdgcn_ballot_w64(ovf) != 0 && lane == 0) atomicOr(P.status, 1);
+        if (P.status && __builtin_amdgcn_ballot_w64(amax >= H3_F16_LIMIT_BITS) != 0 && lane == 0) atomicOr(P.status, 1);
         const int nz = (cpad - cin0) >> 1;                       // zero channel pairs up to the k-step boundary (48 -> 64)
         for (int i = tid; i < H3_NPOS * nz; i += H3_THREADS) {
             const int p = i / nz, cp = (cin0 >> 1) + i - p * nz;

@@ -621,6 +621,17 @@ class DescriptorHead:
         return desc, equi
 
 
+def split_tile_gemm(w, nt):
+    """[Cout, Cin, ntaps] fp32 -> the two f16 planes (hi, lo') in the tiling of csrc/costnet_h3.hip's ch_gemm, groups of nt
+    16-output tiles, as uint16 bit patterns (buf_split_tile_gemm; host only)."""
+    L = _lib.lib()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin, ntaps = w.shape
+    out = np.empty(L.buf_split_gemm_count(cout, cin, ntaps, nt), dtype=np.uint16)
+    check(L.buf_split_tile_gemm(w.ctypes.data, cout, cin, ntaps, nt, out.ctypes.data), "buf_split_tile_gemm")
+    return out
+
+
 def separate_cost_layer0(w):
     """Layer 0 of CostNet is linear in cost[c][n][k][l] = S[c][k][(l-n) mod 20] - T[c][k][l] (models/BUFFER.py:49-60), so its
     3x3x3 kernel w [32,32,3(dn),3(dk),3(dl)] separates exactly into a kernel on S indexed by e = dl - dn (the S-term of an
@@ -700,3 +711,65 @@ class CostVolumeNet:
         check(L.buf_cost_volume_net_gather(_ptr(equi), 7, _ptr(s_rows), _ptr(t_rows), m, self._wp, self._bp, _ptr(out), _stream()),
               "buf_cost_volume_net_gather")
         return out
+
+
+class CostVolumeNetSplit:
+    """CostNet on the f16 matrix pipe with fp32-equivalent arithmetic (csrc/costnet_h3.hip): opt-in next to CostVolumeNet, same calls.
+    Layer 0 in its separated form (separate_cost_layer0), layer 1 with its three k' planes as channels, every layer direct form."""
+
+    def __init__(self, layers, device):
+        """layers: 10 x (w [Cout,Cin,KD,KH,KW] np.float32 with BN folded, b [Cout])"""
+        assert len(layers) == 10
+        mats = []
+        w0 = layers[0][0]
+        assert tuple(w0.shape) == (32, 32, 3, 3, 3), w0.shape
+        ws, wt = separate_cost_layer0(w0)
+        mats.append((np.transpose(ws.reshape(15, 32, 32), (2, 1, 0)), 2))                      # [o][c][dk*5 + e+2]
+        mats.append((np.transpose(wt.reshape(9, 32, 32), (2, 1, 0)), 2))                       # [o][c][dk*3 + dl]
+        w1 = layers[1][0]
+        assert tuple(w1.shape) == (64, 32, 3, 3, 3), w1.shape
+        mats.append((np.transpose(w1, (0, 3, 1, 2, 4)).reshape(64, 96, 9), 2))                 # [o][dk*32 + c][dn*3 + dl]
+        for i in range(2, 9):
+            w = layers[i][0]
+            assert tuple(w.shape[2:]) == (3, 1, 3), w.shape
+            mats.append((np.ascontiguousarray(w[:, :, :, 0, :]).reshape(w.shape[0], w.shape[1], 9), 2 if i < 7 else 1))
+        w9 = layers[9][0]
+        assert tuple(w9.shape) == (20, 32, 2, 1, 2), w9.shape
+        mats.append((np.ascontiguousarray(w9[:, :, :, 0, :]).reshape(20, 32, 4), 1))
+        self.wt = [torch.from_numpy(split_tile_gemm(m, nt).view(np.int16)).to(device) for m, nt in mats]
+        self.bias = []
+        for i, (_, b) in enumerate(layers):
+            b = np.asarray(b, np.float32)
+            if i == 9:
+                b = np.concatenate([b, np.zeros(32 - b.shape[0], np.float32)])
+            self.bias.append(torch.from_numpy(np.ascontiguousarray(b)).to(device))
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self._wp = (C.c_void_p * 11)(*[t.data_ptr() for t in self.wt])
+        self._bp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.bias])
+
+    def __call__(self, s_eq, t_eq):
+        """s_eq, t_eq f32[M,32,5,20] -> f32[M]"""
+        L = _lib.lib()
+        s_eq, t_eq = s_eq.contiguous(), t_eq.contiguous()
+        m = s_eq.shape[0]
+        out = torch.empty((m,), dtype=torch.float32, device=s_eq.device)
+        check(L.buf_cost_volume_net_split(_ptr(s_eq), _ptr(t_eq), m, self._wp, self._bp, _ptr(out), _ptr(self.status), _stream()),
+              "buf_cost_volume_net_split")
+        return out
+
+    def gathered(self, equi, s_rows, t_rows):
+        L = _lib.lib()
+        equi = _dev(equi, torch.float32, "CostVolumeNetSplit.gathered")
+        if equi.dim() != 4 or tuple(equi.shape[1:]) != (32, 7, 20):
+            raise _lib.BufferHipError(f"CostVolumeNetSplit.gathered: expected [rows,32,7,20] maps, got {tuple(equi.shape)}")
+        s_rows, t_rows = _dev(s_rows, torch.int64, "s_rows"), _dev(t_rows, torch.int64, "t_rows")
+        m = int(s_rows.shape[0])
+        out = torch.empty((m,), dtype=torch.float32, device=equi.device)
+        check(L.buf_cost_volume_net_split_gather(_ptr(equi), 7, _ptr(s_rows), _ptr(t_rows), m, self._wp, self._bp, _ptr(out),
+                                                 _ptr(self.status), _stream()), "buf_cost_volume_net_split_gather")
+        return out
+
+    def check_range(self):
+        if int(self.status.item()) != 0:
+            self.status.zero_()
+            raise FloatingPointError("buf_cost_volume_net_split: a value left the f16 range (|v| >= 65504); use the fp32 kernel")

@@ -19,7 +19,7 @@ class BufferPipeline:
         self.W = W
         self.point = PointLearner(W, self.device, cfg.scale)
         self.desc = PatchEmbedder(W, self.device, cfg)
-        self.inlier = registration.CostVolume(W, self.device, cfg.azi_n)
+        self.inlier = registration.CostVolume(W, self.device, cfg.azi_n, getattr(cfg, 'cnn_arith', 'f32'))
         self.limits = None if limits is None else [int(x) for x in limits]
 
     def calibrate(self, samples):

@@ -22,7 +22,9 @@ class CostVolume:
     (csrc/costnet.hip).  The kernel is written for the released geometry (32 channels, 5 elevation rows,
     azi_n = 20); anything else raises -- there is no library-convolution path in the product."""
 
-    def __init__(self, W, device, azi_n=20):
+    def __init__(self, W, device, azi_n=20, arith='f32'):
+        if arith not in ('f32', 'split'):
+            raise ValueError(f"cnn_arith must be 'f32' or 'split', got {arith!r}")
         if azi_n != 20:
             raise NotImplementedError(f'CostVolume: the fused kernel is built for azi_n = 20 (got {azi_n})')
         self.azi_n = azi_n
@@ -31,7 +33,8 @@ class CostVolume:
         for i, bn in ((0, 1), (3, 4), (6, 7), (9, 10), (12, 13), (15, 16), (18, 19), (21, 22), (24, 25)):
             layers.append(_fold_bn(W[f'{p}.{i}.weight'], W[f'{p}.{i}.bias'], W[f'{p}.{bn}.running_mean'], W[f'{p}.{bn}.running_var']))
         layers.append((np.asarray(W[f'{p}.27.weight'], np.float32), np.asarray(W[f'{p}.27.bias'], np.float32)))
-        self.fused = ops.CostVolumeNet(layers, device)                              # csrc/costnet.hip
+        # 'split': csrc/costnet_h3.hip -- the same network on the f16 matrix pipe, operands split hi + 2^-11 lo' (fp32-equivalent)
+        self.fused = ops.CostVolumeNetSplit(layers, device) if arith == 'split' else ops.CostVolumeNet(layers, device)
 
     def __call__(self, d1, d2):
         """d1,d2 f32[M,32,5,20] -> expected azimuth shift f32[M]."""

@@ -304,6 +304,22 @@ int     buf_cost_volume_net(const float* s_eq, const float* t_eq, int m, const f
 int     buf_cost_volume_net_gather(const float* equi, int ele_n, const long long* s_rows, const long long* t_rows, int m,
                                    const float* const* wt_host, const float* const* bias_host, float* ind_out, void* stream);
 
+/* A13, split-f16 form -- the same network with fp32-EQUIVALENT arithmetic on the f16 matrix pipe (csrc/costnet_h3.hip; opt-in, see
+ * buf_cylindrical_net_split for the operand split): layer 0 separated as above, every layer a direct-form correlation.
+ * wt_host: HOST array of 11 DEVICE pointers to u16 planes laid out by buf_split_tile_gemm(w [Cout][Cin][ntaps], Cout, Cin, ntaps, nt, out):
+ *   [0] layer 0 S-term [32][32][15 taps = dk*5 + e+2] = Ws, nt 2      [1] layer 0 T-term [32][32][9 taps = dk*3 + dl] = Wt, nt 2
+ *   [2] layer 1 [64][96 = dk*32 + c][9 taps = dn*3 + dl], nt 2         [3..8] layers 2..7 [Cout][Cin][9 taps = dn*3 + dl], nt 2 (layer 7: nt 1)
+ *   [9] layer 8, nt 1          [10] layer 9 [20][32][4 taps = dn*2 + dl], nt 1 (20 outputs padded to 32)
+ * out[((((g ntaps + tap) KS + ks) nt + n2) 2 + plane) 512 + (kg 16 + row) 8 + i] = plane(w[16 nt g + 16 n2 + row][32 ks + 8 kg + i][tap]).
+ * bias_host: 10 DEVICE f32 pointers (layer 9: 32 values, 20 used).  status_dev as in buf_cylindrical_net_split. */
+long long buf_split_gemm_count(int cout, int cin, int ntaps, int nt);                               /* host only */
+int     buf_split_tile_gemm(const float* w_host, int cout, int cin, int ntaps, int nt, unsigned short* out_host);   /* host only */
+int     buf_cost_volume_net_split(const float* s_eq, const float* t_eq, int m, const void* const* wt_host,
+                                  const float* const* bias_host, float* ind_out, int* status_dev, void* stream);
+int     buf_cost_volume_net_split_gather(const float* equi, int ele_n, const long long* s_rows, const long long* t_rows, int m,
+                                         const void* const* wt_host, const float* const* bias_host, float* ind_out,
+                                         int* status_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A14  hypotheses + all-vs-all scoring (models/BUFFER.py:295-311): ind f32[m] -> R f32[m,3,3], t f32[m,3],
  * inlier_num int32[m], best_out int32[1] (first arg-max), best_mask uint8[m]. */

@@ -328,3 +328,21 @@ def test_cnn_entry_points_reject_unsupported_stacks_before_any_device_work():
     assert rc == -1
     rc = L.buf_cylindrical_net_split(x, 2, ptrs, ptrs, ints(48, 64, 64, 128, 128, 64, 64, 64), ok_out, relu, x, None, None)
     assert rc == -1 and b"width mismatch" in L.buf_last_error()
+
+
+def test_split_gemm_tiling_general_form():
+    """buf_split_tile_gemm (host side of csrc/costnet_h3.hip): groups of nt 16-output tiles, any tap count, Cout padded to whole
+    groups (layer 9 of the cost net: 20 -> 32), Cin to whole k-steps; with nt = 2 and 9 taps it is buf_split_tile_filters."""
+    from buffer_amd import ops
+    rng = np.random.default_rng(9)
+    for cout, cin, ntaps, nt in ((20, 32, 4, 1), (64, 96, 9, 2), (32, 32, 15, 2), (32, 64, 9, 1)):
+        w = (rng.standard_normal((cout, cin, ntaps)) * 0.1).astype(np.float32)
+        cpad, KS = -(-cout // (16 * nt)) * 16 * nt, (cin + 31) // 32
+        t = ops.split_tile_gemm(w, nt).reshape(cpad // (16 * nt), ntaps, KS, nt, 2, 4, 16, 8)       # [g, tap, ks, n2, plane, kg, row, i]
+        t = np.transpose(t, (4, 0, 3, 6, 2, 5, 7, 1)).reshape(2, cpad, KS * 32, ntaps)             # [plane, o, c, tap]
+        hi = w.astype(np.float16)
+        lo = ((w - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+        assert np.array_equal(t[0, :cout, :cin], hi.view(np.uint16)) and np.array_equal(t[1, :cout, :cin], lo.view(np.uint16))
+        assert not t[:, cout:].any() and not t[:, :, cin:].any()
+    w = (rng.standard_normal((64, 48, 3, 3)) * 0.1).astype(np.float32)
+    assert np.array_equal(ops.split_tile_filters(w), ops.split_tile_gemm(w.reshape(64, 48, 9), 2))

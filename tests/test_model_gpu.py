@@ -277,6 +277,40 @@ def test_fused_cost_volume_vs_library_convs(W, dev):
         registration.CostVolume(W, dev, azi_n=18)
 
 
+def test_split_cost_volume_vs_reference_and_float64(W, dev):
+    """the opt-in split-f16 cost net (cnn_arith='split', csrc/costnet_h3.hip): `ind` against fixture F5 and library convolutions at
+    the fp32 kernel's tolerance; against the network in float64 its error is below 1e-4 and not above 1.5 x the fp32 kernel's
+    (measured 0.5 x); gather form == dense form bitwise; other geometries are rejected."""
+    from buffer_amd import registration
+    cv32, cvs = registration.CostVolume(W, dev), registration.CostVolume(W, dev, arith='split')
+    f = load("match_tiny.npz")
+    se = torch.from_numpy(f['src_equi'])[f['s_mids']][:, :, 1:6].contiguous().to(dev)
+    te = torch.from_numpy(f['tgt_equi'])[f['t_mids']][:, :, 1:6].contiguous().to(dev)
+    got = cvs(se, te)
+    np.testing.assert_allclose(got.cpu().numpy(), f['ind'], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(got.cpu().numpy(), T.cost_volume(se, te, _on(W, dev)).cpu().numpy(), rtol=1e-4, atol=2e-4)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    a = torch.nn.functional.normalize(torch.rand((150, 32, 5, 20), generator=g), dim=1).to(dev)
+    b = torch.nn.functional.normalize(torch.rand((150, 32, 5, 20), generator=g), dim=1).to(dev)
+    W64 = {k: torch.from_numpy(np.asarray(v)).double().to(dev) for k, v in W.items() if k.startswith('Inlier')}
+    ref = T.cost_volume(a.double(), b.double(), W64)
+    e32 = (cv32(a, b).double() - ref).abs().max().item()
+    es = (cvs(a, b).double() - ref).abs().max().item()
+    print(f'cost net, |ind - ind(float64)| (ind in [0, 20)): fp32 kernel {e32:.2e}, split f16 {es:.2e}')
+    assert es < 1e-4 and es <= max(1.5 * e32, 1e-5)
+    equi = torch.nn.functional.normalize(torch.rand((300, 32, 7, 20), generator=g), dim=1).to(dev)
+    s_rows = torch.randint(0, 300, (157,), generator=g).to(dev)
+    t_rows = torch.randint(0, 300, (157,), generator=g).to(dev)
+    want = cvs(equi[s_rows][:, :, 1:6].contiguous(), equi[t_rows][:, :, 1:6].contiguous())
+    assert torch.equal(cvs.gathered(equi, s_rows, t_rows), want)
+    assert cvs.gathered(equi, s_rows[:0], t_rows[:0]).shape == (0,)
+    cvs.fused.check_range()
+    with pytest.raises(ValueError):
+        cvs(a[:, :, :4].contiguous(), b[:, :, :4].contiguous())
+    with pytest.raises(ValueError):
+        registration.CostVolume(W, dev, arith='bf16')
+
+
 def _truth64(pyr_npz, feats, Wnp, scale=1.0):
     """the same network evaluated in float64 on the CPU (oracle/torch_ref.py is dtype-agnostic): the reference point for
     separating fp32 conditioning from implementation error"""
