@@ -78,11 +78,14 @@ def test_kitti_branch_vs_reference_fixture(dev):
     # 80 m coordinates in fp32, features near zero behind VN-BN: the REFERENCE'S OWN run is 1.8e-4 (axis) / 4.3e-4 (eps) /
     # 3.3e-4 (score) of scale away from the float64 network (test_point_learner_error_is_the_fp32_conditioning_of_the_network),
     # the HIP path 2.0e-4 / 6.3e-4 / 3.4e-4 with its fp64 sums; element-wise against the fixture that is 1.4e-3 (eps) and
-    # 3.8e-3 (score) relative at the worst element (round 3), so the bounds below are 1.3-3x what is measured
+    # 3.8e-3 (score) relative at the worst element; the bounds below are at most 2 x what is measured (assert_close prints the share used)
+    from util import assert_close
+    used = float((np.linalg.norm(a - b, axis=1) / (1e-3 * np.linalg.norm(b, axis=1) + 1e-5)).max())
+    print(f'TOL KITTI axis: worst row uses {used:.2f} of 1e-3 |axis| + 1e-5')
     assert np.all(np.linalg.norm(a - b, axis=1) < 1e-3 * np.linalg.norm(b, axis=1) + 1e-5)
     assert np.min((a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))) > 1 - 1e-5
-    np.testing.assert_allclose(eps.cpu().numpy(), f['eps'], rtol=5e-3, atol=1e-4)             # sigmoid / softplus after two
-    np.testing.assert_allclose(score.cpu().numpy(), f['score'], rtol=5e-3, atol=1e-4)         # InstanceNorms over the pair
+    assert_close(eps.cpu().numpy(), f['eps'], 2.9e-3, 5.8e-5, 'KITTI eps')             # sigmoid / softplus after two
+    assert_close(score.cpu().numpy(), f['score'], 5e-3, 1e-4, 'KITTI score')       # InstanceNorms over the pair
     assert np.array_equal(score.cpu().numpy() > KITTI.keypts_th, f['score'] > KITTI.keypts_th)
     pe = PatchEmbedder(W, dev, KITTI)
     out = pe(t(f['raw']), t(f['kpts']), t(f['kaxis']), t(f['perm']), want_patches=True)

@@ -43,12 +43,15 @@ def test_point_learner_vs_reference(W, dev):
     pl = PointLearner(W, dev)
     axis, eps, bottle, skips, blocks = pl.efcnn(pyr, torch.from_numpy(f['features']).to(dev))
     score = pl.detnet(pyr, bottle, skips)
+    from util import assert_close
+    # tolerances = 2 x the worst element measured on this build (round 4; assert_close prints the share used): the fixture is
+    # the reference's own fp32 run, one summation order among many (test_point_learner_error_is_the_fp32_conditioning_...)
     for i in range(5):
-        np.testing.assert_allclose(blocks[i].cpu().numpy(), f[f'block{i}'], rtol=5e-4, atol=5e-5)
-    np.testing.assert_allclose(bottle.cpu().numpy(), f['bottle'], rtol=5e-4, atol=5e-5)
-    np.testing.assert_allclose(axis.cpu().numpy(), f['axis'], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(eps.cpu().numpy(), f['eps'], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(score.cpu().numpy(), f['score'], rtol=1e-3, atol=2e-4)
+        assert_close(blocks[i].cpu().numpy(), f[f'block{i}'], 2.6e-4, 2.6e-5, f'VN block {i}')
+    assert_close(bottle.cpu().numpy(), f['bottle'], 2.6e-4, 2.6e-5, 'bottleneck')
+    assert_close(axis.cpu().numpy(), f['axis'], 3.2e-5, 6.4e-6, 'axis')
+    assert_close(eps.cpu().numpy(), f['eps'], 6.4e-5, 1.3e-5, 'eps')
+    assert_close(score.cpu().numpy(), f['score'], 5.4e-4, 1.1e-4, 'score')
     # the keypoint decision (score > 0.1) must agree wherever the score is not on the threshold
     s_ref, s_got = f['score'][:, 0], score.cpu().numpy()[:, 0]
     clear = np.abs(s_ref - 0.1) > 1e-3
@@ -155,7 +158,7 @@ def test_matching_and_pose_vs_reference(W, dev):
     np.testing.assert_allclose(tr.cpu().numpy(), f['t_hyp'], rtol=0, atol=1e-5)
     dnum = np.abs(num.cpu().numpy() - f['inlier_num'])
     print('INLIER_NUM max |diff|', int(dnum.max()), 'hypotheses differing', int((dnum > 0).sum()), 'of', dnum.size)
-    assert dnum.max() <= 1 and (dnum > 0).sum() <= max(1, dnum.size // 100)      # a residual at the threshold to fp32 round-off may flip
+    assert dnum.max() == 0                         # (rounds 1-3 allowed one borderline residual: it does not fire on the committed fixture)
     assert int(best.item()) == int(f['best'])
     assert np.array_equal(np.nonzero(mask.cpu().numpy())[0], f['inlier_ind'])
     T, info = ops.post_refine(t(f['init_pose']), ss, tt, 0.10, 20)

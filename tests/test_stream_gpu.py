@@ -29,8 +29,8 @@ def test_stream_1623_pairs_from_raw_clouds(dev):
     print('STREAM ' + json.dumps(out))
     assert out['pairs'] == N_PAIRS and len(out['per_scene']) == 8
     assert np.isfinite(poses).all()
-    # quality floor on the synthetic rooms (a quarter of the pairs at 0.3 overlap): see profiles/r02_stream.json
-    assert out['dgr_recall'] > 0.85 and out['registration_recall'] > 0.85, out
+    # quality floor on the synthetic rooms (a quarter of the pairs at 0.3 overlap): measured RR 92.8 %, DGR recall 92.9 % (profiles/r03_stream.json)
+    assert out['dgr_recall'] >= 0.92 and out['registration_recall'] >= 0.92, out
     # batched launches == one pair at a time, on a sample spread over the stream (same seeds, same device-side shuffles)
     sample = list(range(0, N_PAIRS, max(1, N_PAIRS // 6)))[:6]
     worst = 0.0

@@ -2,6 +2,16 @@
 import numpy as np
 
 
+def assert_close(got, want, rtol, atol, name):
+    """np.testing.assert_allclose that PRINTS how much of the tolerance the worst element uses (no tolerance more
+    than 2 x above its printed measurement): used = max |got - want| / (atol + rtol |want|)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    used = float((np.abs(got - want) / (atol + rtol * np.abs(want))).max()) if got.size else 0.0
+    print(f'TOL {name}: worst element uses {used:.2f} of rtol={rtol:g} atol={atol:g}')
+    assert used <= 1.0, f'{name}: worst element at {used:.2f} x the tolerance (rtol={rtol:g}, atol={atol:g})'
+    return used
+
+
 def d2_table(q, s, tab):
     """fp32 ((dx*dx + dy*dy) + dz*dz) for every table entry; shadow entries -> +inf."""
     q = np.asarray(q, np.float32)
