@@ -133,6 +133,8 @@ def collect_timed(L):
 
 
 def load_traffic():
+    if os.environ.get('BUF_NO_TRAFFIC'):            # the profiled runs of tools/profile_round.sh: no stale bytes in their lines
+        return {}
     p = os.path.join(ROOT, 'profiles', 'traffic.json')
     return json.load(open(p)) if os.path.exists(p) else {}
 
@@ -178,8 +180,8 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
                    traffic_of(pmc, 'k_cost_net', matches),
                    flops='useful-tile count (0.0519 GFLOP/match: layer 0 separated, layers 1..5 Winograd); dense count of SURVEY 8d: 0.160',
                    dense_equivalent_tflops=(COST_NET_DENSE_FLOPS_PER_MATCH * matches) / (timed['cost_net'][1] / max(timed['cost_net'][0], 1) * 1e-3) / 1e12),
-        roof_entry(timed, 'grid_query', 'k_grid_query (A2 radius neighbours)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
-                   traffic_of(pmc, 'k_grid_query_wave', units.get('pairs'))),
+        roof_entry(timed, 'grid_query', 'k_grid_query_cell + k_grid_query_wave (A2 radius neighbours: cell-centric self queries, query-centric others)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
+                   traffic_of(pmc, 'k_grid_query', units.get('pairs'))),
         roof_entry(timed, 'grid_subsample', 'k_vox_* + scan + k_cell_scatter (A1 grid subsample, whole call)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9),
         roof_entry(timed, 'vn_gather', 'k_vn_gather (A4 fused VN neighbour block)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_vn_gather', units.get('pairs'))),

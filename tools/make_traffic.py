@@ -1,7 +1,7 @@
 """profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected SEPARATELY, as
 MI355X_MICROARCH.md prescribes: they do not fit one pass) of the same bench.py command.
 
-    python tools/make_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <bench json line file> <out json>
+    python tools/make_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <bench --detail-json file> <out json>
 
 Units and gfx950 correction (MI355X_MICROARCH.md, HBM): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB (1024 B);
 FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads -> doubled; WRITE_SIZE taken as is."""
@@ -11,7 +11,7 @@ import json
 import sys
 
 fetch_csv, write_csv, bench_file, out = sys.argv[1:5]
-bench = json.loads([l for l in open(bench_file).read().splitlines() if l.startswith('{')][-1])
+bench = json.load(open(bench_file))            # the uncompacted record (bench.py --detail-json)
 
 
 def per_launch(path, counter):
@@ -27,6 +27,13 @@ def per_launch(path, counter):
 
 fetch, n_f = per_launch(fetch_csv, 'FETCH_SIZE')
 write, n_w = per_launch(write_csv, 'WRITE_SIZE')
+# A2 as ONE operator: the cell-centric kernel (self queries) and the query-centric one (pool / upsample queries) of a pyramid
+for d, n in ((fetch, n_f), (write, n_w)):
+    ks = [k for k in ('k_grid_query_cell', 'k_grid_query_wave') if k in d]
+    if ks:
+        tot = sum(n[k] for k in ks)
+        d['k_grid_query'] = sum(d[k] * n[k] for k in ks) / tot
+        n['k_grid_query'] = tot
 cfg = bench['config']
 pairs = cfg['pairs_per_step_per_gpu']
 patches = 2 * cfg['keypoints_per_fragment'] * pairs
@@ -39,7 +46,11 @@ units = {
     'k_patch_voxelize': (patches, 'patch', 12 * 512 + 4 * 16 * 420),
     'k_select_patches_grid': (patches, 'patch', 12 * 512 + 12),
     'k_cost_net': (matches, 'match', 2 * 3200 * 4 + 4),
-    'k_grid_query_wave': (pairs, 'pair (mean over the 7 query shapes)', None),
+    'k_cyl_net_h3': (patches, 'patch', 48 * 140 * 4 + 32 * 140 * 4),
+    'k_cost_net_h3': (matches, 'match', 2 * 3200 * 4 + 4),
+    'k_grid_query': (pairs, 'pair (mean over the 7 query shapes: 3 cell-centric self queries, 4 query-centric)', None),
+    'k_grid_query_cell': (pairs, 'pair (mean over the 3 self queries)', None),
+    'k_grid_query_wave': (pairs, 'pair (mean over the 4 pool / upsample queries)', None),
     'k_vn_gather': (pairs, 'pair (mean over the 5 blocks)', None),
     'k_nn1': (pairs, 'pair', None),
     'k_fps': (pairs, 'pair', None),
