@@ -179,7 +179,8 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
         roof_entry(timed, 'cost_net', 'k_cost_net (A13 CostVolume + CostNet, fused fp32 MFMA)', 'mfma', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12,
                    traffic_of(pmc, 'k_cost_net', matches),
                    flops='useful-tile count (0.0519 GFLOP/match: layer 0 separated, layers 1..5 Winograd); dense count of SURVEY 8d: 0.160',
-                   dense_equivalent_tflops=(COST_NET_DENSE_FLOPS_PER_MATCH * matches) / (timed['cost_net'][1] / max(timed['cost_net'][0], 1) * 1e-3) / 1e12),
+                   dense_equivalent_tflops=((COST_NET_DENSE_FLOPS_PER_MATCH * matches) / (timed['cost_net'][1] / timed['cost_net'][0] * 1e-3) / 1e12
+                                            if timed['cost_net'][0] else None)),
         roof_entry(timed, 'grid_query', 'k_grid_query_cell + k_grid_query_wave (A2 radius neighbours: cell-centric self queries, query-centric others)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_grid_query', units.get('pairs'))),
         roof_entry(timed, 'grid_subsample', 'k_vox_* + scan + k_cell_scatter (A1 grid subsample, whole call)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9),
@@ -438,7 +439,7 @@ def main():
         torch.cuda.synchronize()
         L.buf_timing_enable(0)
         timed_alone = collect_timed(L)
-    if rank == 0 and pps:
+    if rank == 0 and pps and not os.environ.get('BUF_NO_TRAFFIC'):      # (not in the PMC-profiled runs: full-step launches only there)
         # what ONE caller of models/BUFFER.py:231-333 sees: one pair, un-batched, un-pipelined, host clock around a synchronised
         # call (median of 10); and the keypoint stage alone (pyramid, point learner, FPS), for one pair and for a whole step
         def med(fn, n=10):
@@ -479,6 +480,8 @@ def main():
         # A6 bytes: 12 N' + 4 P per cloud; N' (points above the score threshold) <= the sds cloud sizes
         fps_bytes = (sum(12.0 * int(x) for inp in inputs for x in inp['lengths']) / len(inputs) + 8.0 * keypts) * per_launch
         main_roof, _ = rooflines(timed, pmc, fps_bytes, units)                 # dominant kernel: events of the timed region
+        if a.arith == 'split':
+            main_roof = roofline_split(timed, pmc, units, None)
         units['patches_per_select'] = 2 * keypts * per_launch
         _, other = rooflines(timed_alone, pmc, fps_bytes, units)              # the others: each kernel alone on the chip
         alone_steps = 2 if timed_alone is not timed else a.steps
@@ -581,10 +584,12 @@ def run_stream(a, rank, world, dev, cdev, dist, L):
         quality = stream.evaluate_stream(meta, all_poses.cpu().numpy())
         quality['scored'] = f'{n} pairs (all ranks, gathered poses)'
         main_roof, other = rooflines(timed, load_traffic(), None, {})
+        if a.arith == 'split':
+            main_roof = roofline_split(timed, load_traffic(), {}, None)
         print(json.dumps({
             'metric': 'registration pairs/sec', 'value': n / elapsed, 'unit': 'pairs/s', 'n_gpus': world, 'steps': 1, 'warmup': 0,
-            'ms_per_step': elapsed * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic',
+            'ms_per_step': elapsed * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32' if a.arith == 'f32' else 'f32 (split-f16 matrix products, fp32 accumulate)', 'data': 'synthetic',
             'config': {'workload': f'{n} synthetic 3DMatch-shape pairs streamed from raw clouds, pre-processing included '
                                    f'(BASELINE configs[2]); overlaps {list(overlaps)} in equal shares',
                        'keypoints_per_fragment': cfg.num_keypts, 'pairs_per_launch': batch, 'neighbor_limits': limits,

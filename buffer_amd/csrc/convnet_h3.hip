@@ -63,6 +63,13 @@ struct CylH3Params {
 #endif
 };
 
+#ifdef H3_STAMP
+__device__ long long* h3_stamp_ptr;      // development build (-DH3_STAMP): s_memtime per wavefront at the layer boundaries
+#define H3_STAMP_AT(SLOT) if ((threadIdx.x & 63) == 0) h3_stamp_ptr[((size_t)blockIdx.x * 4 + threadIdx.x / 64) * 32 + (SLOT)] = __builtin_amdgcn_s_memtime();
+#else
+#define H3_STAMP_AT(SLOT)
+#endif
+
 __device__ __forceinline__ h3u4 h3_lds128(unsigned a) { return *(const __attribute__((address_space(3))) h3u4*)(size_t)a; }
 __device__ __forceinline__ unsigned h3_lds32(unsigned a) { return *(const __attribute__((address_space(3))) unsigned*)(size_t)a; }
 
@@ -82,6 +89,26 @@ __device__ __forceinline__ void h3_split(float v, _Float16& hi, _Float16& lo)
     hi = (_Float16)v;
     lo = (_Float16)((v - (float)hi) * 2048.f);
 }
+
+// The same for two values at once, packed: 5 instructions instead of 8 (the epilogues are vector-ALU work beside the partner
+// workgroup's matrix instructions: 14 % of a workgroup's time).  v_cvt_pk_f16_f32 rounds both to hi; v_fma_mix_f32 forms the exact
+// residual v - hi straight from the packed half (no conversion back); v_fma_mixlo / mixhi_f16 scale it by 2^11 and round it into
+// the two halves of lo'.  Bit-identical to h3_split (every step is the same exactly rounded operation).
+__device__ __forceinline__ void h3_split2(float v0, float v1, float k2048, unsigned& hi, unsigned& lo)
+{
+    h3h2 h;
+    h[0] = (_Float16)v0; h[1] = (_Float16)v1;
+    hi = __builtin_bit_cast(unsigned, h);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lo) : "v"(r0), "v"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lo) : "v"(r1), "v"(k2048));
+}
+// range watch of the epilogues: running maximum of |v| as a float (one v_max3_f32 with |.| modifiers per value pair).  A NaN
+// would slip through a float maximum, but inside the stack a NaN can only follow an infinity of the layer before, which this
+// catches; the kernels' INPUTS go through the integer form h3_watch.
+__device__ __forceinline__ void h3_watch2(float& amax, float v0, float v1) { amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1))); }
 
 // The product sums of the wavefront's tile: outputs [32 of group ct], positions of the tiles pt0 .. pt0 + PT - 1 (pt0 even), K = 9 taps x
 // KS k-steps of 32 channels.  am: sum hi hi, ac: sum hi lo' + lo' hi.  Steps (k-step, tile) of a tap run as a software pipeline
@@ -171,52 +198,51 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
 // Epilogue of a wavefront's tile: v = hi-sum + 2^-11 cross-sum + bias, ReLU, then either the split back into the LDS image (the
 // C/D layout gives a lane 4 consecutive output channels of one position: one ds_write_b64 per plane) or y[32][140] in fp32.
 template <int PT, bool LAST>
-__device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT], const h3f4 (&ac)[2][PT], const float* __restrict__ bias,
-                                         int relu, int ct, int pt0, unsigned lane, float* __restrict__ y, int* status)
+__device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT], const h3f4 (&ac)[2][PT], int relu, int ct, int pt0, unsigned lane,
+                                         float* __restrict__ y, int* status)
 {
     const int li = lane & 15, lk = lane >> 4;
-    unsigned amax = 0u;
+    float amax = 0.f;
+    float k2048 = 2048.f;
+    asm volatile("" : "+v"(k2048));                              // one register for the multiplier of v_fma_mixlo / mixhi_f16
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, 0x7fffffff, 0x00027000);
     unsigned ybase = (unsigned)((32 * ct * H3_NPOS + 16 * pt0) * 4);
     asm volatile("" : "+s"(ybase));                              // (the per-store scalar offsets are formed here as well)
 #pragma unroll
     for (int n = 0; n < 2; n++) {
         const int c = 32 * ct + 16 * n + 4 * lk;
-        const h3f4 b = *reinterpret_cast<const h3f4*>(bias + c);
 #pragma unroll
         for (int t = 0; t < PT; t++) {
             const int p = 16 * (pt0 + t) + li;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                v[r] = (am[n][t][r] + ac[n][t][r] * (1.f / 2048.f)) + b[r];
-                if constexpr (!LAST) h3_watch(amax, v[r]);                  // before the ReLU: fmaxf(NaN, 0) = 0 would hide an overflow upstream
-                if (relu) v[r] = fmaxf(v[r], 0.f);
-            }
+            for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(ac[n][t][r], 1.f / 2048.f, am[n][t][r]);     // the bias started the hi-sum
             if constexpr (LAST) {
                 if (p < H3_NPOS) {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), yrs, (unsigned)(4 * lk * H3_NPOS + li) * 4u,
-                                                              ybase + (unsigned)(((16 * n + r) * H3_NPOS + 16 * t) * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu ? fmaxf(v[r], 0.f) : v[r]), yrs,
+                                                              (unsigned)(4 * lk * H3_NPOS + li) * 4u, ybase + (unsigned)(((16 * n + r) * H3_NPOS + 16 * t) * 4), 0);
                 }
             } else {
-                h3h4 hi, lo;
+                h3_watch2(amax, v[0], v[1]); h3_watch2(amax, v[2], v[3]);       // before the ReLU
+                if (relu) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    _Float16 a, l;
-                    h3_split(v[r], a, l);
-                    hi[r] = a; lo[r] = l;
+                    for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
                 }
+                unsigned h0, h1, l0, l1;
+                h3_split2(v[0], v[1], k2048, h0, l0);
+                h3_split2(v[2], v[3], k2048, h1, l1);
+                const h3u2 hi = { h0, h1 }, lo = { l0, l1 };
                 if (p < H3_NPOS) {
                     const unsigned a = lds0 + (unsigned)p * H3_S + (unsigned)c * 2u;
-                    *(__attribute__((address_space(3))) h3u2*)(size_t)a = __builtin_bit_cast(h3u2, hi);
-                    *(__attribute__((address_space(3))) h3u2*)(size_t)(a + H3_LO) = __builtin_bit_cast(h3u2, lo);
+                    *(__attribute__((address_space(3))) h3u2*)(size_t)a = hi;
+                    *(__attribute__((address_space(3))) h3u2*)(size_t)(a + H3_LO) = lo;
                 }
             }
         }
     }
-    if (!LAST && status && __builtin_amdgcn_ballot_w64(amax >= H3_F16_LIMIT_BITS) != 0 && lane == 0) atomicOr(status, 1);
+    if (!LAST && status && __builtin_amdgcn_ballot_w64(!(amax < 65504.f)) != 0 && lane == 0) atomicOr(status, 1);
 }
 
 template <int PT, int KS>
@@ -225,16 +251,21 @@ __device__ __forceinline__ void h3_layer(unsigned lds0, const void* wt, const fl
 {
     h3f4 am[2][PT], ac[2][PT];
 #pragma unroll
-    for (int n = 0; n < 2; n++)
+    for (int n = 0; n < 2; n++) {
+        // the hi-sum starts at the bias (C/D layout: a lane holds outputs 32 ct + 16 n + 4 (lane >> 4) + r of its position)
+        const h3f4 b = *reinterpret_cast<const h3f4*>(bias + 32 * ct + 16 * n + 4 * (lane >> 4));
 #pragma unroll
-        for (int t = 0; t < PT; t++) { am[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; ac[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; }
+        for (int t = 0; t < PT; t++) { am[n][t] = b; ac[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; }
+    }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, 0x7fffffff, 0x00027000);
     h3_gemm<PT, KS>(lds0, rs, (unsigned)ct * (9u * KS * 4096u), pt0, lane, am, ac);
+    H3_STAMP_AT(30)
     __syncthreads();                                             // every wavefront has read its input: the image may be rewritten
+    H3_STAMP_AT(31)
     unsigned lane_s = lane;
     asm volatile("" : "+v"(lane_s));                             // the store addresses are formed here, not hoisted out of the layer loop (and spilled)
-    if (last) h3_store<PT, true>(lds0, am, ac, bias, relu, ct, pt0, lane_s, y, status);
-    else h3_store<PT, false>(lds0, am, ac, bias, relu, ct, pt0, lane_s, y, status);
+    if (last) h3_store<PT, true>(lds0, am, ac, relu, ct, pt0, lane_s, y, status);
+    else h3_store<PT, false>(lds0, am, ac, relu, ct, pt0, lane_s, y, status);
 }
 
 template <int KS>
@@ -300,6 +331,7 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         }
     }
     __syncthreads();
+    H3_STAMP_AT(0)
 #pragma unroll 1
     for (int l = 0; l < H3_LAYERS; l++) {
         const int ks = (P.cin[l] + 31) >> 5, cout = P.cout[l];
@@ -308,6 +340,13 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         if (ks == 4) h3_dispatch<4>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status);
         else if (ks == 2) h3_dispatch<2>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status);
         else h3_dispatch<1>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status);
+#ifdef H3_STAMP
+        if ((threadIdx.x & 63) == 0) {      // gemm end / barrier end of this layer (slots 30, 31) -> per-layer slots
+            long long* q = h3_stamp_ptr + ((size_t)blockIdx.x * 4 + threadIdx.x / 64) * 32;
+            q[1 + 3 * l] = q[30]; q[2 + 3 * l] = q[31];
+        }
+#endif
+        H3_STAMP_AT(3 + 3 * l)
         __syncthreads();
     }
 }
@@ -398,8 +437,41 @@ extern "C" int buf_cylindrical_net_split(const float* x, int npatch, const void*
     for (int l = 0; l < H3_LAYERS; l++) macs += 9.0 * P.cin[l] * P.cout[l];
     TimedSpan span;
     bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * 140 * macs * npatch, BUF_TIMED_CYL_NET_SPLIT);
+#ifdef H3_STAMP
+    long long* stamps = nullptr;
+    BUF_CHECK_HIP(hipMalloc(&stamps, (size_t)npatch * 4 * 32 * sizeof(long long)));
+    BUF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h3_stamp_ptr), &stamps, sizeof(stamps)));
+#endif
     k_cyl_net_h3<<<npatch, H3_THREADS, H3_LDS, (hipStream_t)stream>>>(x, P, y);
     if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
+#ifdef H3_STAMP
+    if (npatch >= 4096) {   // per layer and wavefront: K loops | wait at the barrier | epilogue (split + store); second half of the workgroups
+        BUF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        long long* h = (long long*)malloc((size_t)npatch * 4 * 32 * sizeof(long long));
+        BUF_CHECK_HIP(hipMemcpy(h, stamps, (size_t)npatch * 4 * 32 * sizeof(long long), hipMemcpyDeviceToHost));
+        double g[H3_LAYERS][4] = {}, bw[H3_LAYERS][4] = {}, ep[H3_LAYERS][4] = {}, tot = 0;
+        long n = 0;
+        for (int b = npatch / 2; b < npatch; b++, n++)
+            for (int w = 0; w < 4; w++) {
+                const long long* q = h + ((size_t)b * 4 + w) * 32;
+                for (int l = 0; l < H3_LAYERS; l++) {
+                    const long long start = l == 0 ? q[0] : q[3 + 3 * (l - 1)];
+                    g[l][w] += (double)(q[1 + 3 * l] - start); bw[l][w] += (double)(q[2 + 3 * l] - q[1 + 3 * l]); ep[l][w] += (double)(q[3 + 3 * l] - q[2 + 3 * l]);
+                }
+                if (w == 0) tot += (double)(q[3 + 3 * (H3_LAYERS - 1)] - q[0]);
+            }
+        fprintf(stderr, "H3_STAMP: %ld workgroups, layers total %.0f cycles per patch\n", n, tot / n);
+        for (int l = 0; l < H3_LAYERS; l++) {
+            const int ks = (P.cin[l] + 31) / 32;
+            const double mf = 9.0 * ks * 27 * (P.cout[l] / 16) / 4;        // MFMAs per wave (mean)
+            fprintf(stderr, "  layer %d %3d->%3d: MFMAs/wave %5.0f | K loops %6.0f %6.0f %6.0f %6.0f | barrier wait %5.0f %5.0f %5.0f %5.0f | epilogue %5.0f %5.0f %5.0f %5.0f | cycles per MFMA (wave 0, whole layer) %.1f\n",
+                    l, P.cin[l], P.cout[l], mf, g[l][0] / n, g[l][1] / n, g[l][2] / n, g[l][3] / n, bw[l][0] / n, bw[l][1] / n, bw[l][2] / n, bw[l][3] / n,
+                    ep[l][0] / n, ep[l][1] / n, ep[l][2] / n, ep[l][3] / n, (g[l][0] + bw[l][0] + ep[l][0]) / n / mf);
+        }
+        free(h);
+    }
+    (void)hipFree(stamps);
+#endif
     return BUF_OK;
 }

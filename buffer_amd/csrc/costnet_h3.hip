@@ -130,31 +130,27 @@ __device__ __forceinline__ void ch_gemm(const unsigned (&adr)[PT], unsigned row_
     }
 }
 
-// v = relu(hi-sum + 2^-11 cross-sum + bias) of a tile set, split and packed: the C/D layout gives a lane 4 consecutive output
-// channels of one position = 8 bytes per plane.  -> true if a value left the f16 range
+// v = relu(hi-sum + 2^-11 cross-sum) of a tile set (the bias started the hi-sum), split and packed: the C/D layout gives a lane 4
+// consecutive output channels of one position = 8 bytes per plane.  amax: running maximum of |v| before the ReLU (range watch)
 template <int PT, int NT>
-__device__ __forceinline__ void ch_pack(const h3f4 (&am)[NT][PT], const h3f4 (&ac)[NT][PT], const float* __restrict__ bias, int c0, unsigned lane,
-                                        h3u2 (&ph)[NT][PT], h3u2 (&pl)[NT][PT], unsigned& amax)
+__device__ __forceinline__ void ch_pack(const h3f4 (&am)[NT][PT], const h3f4 (&ac)[NT][PT], float k2048,
+                                        h3u2 (&ph)[NT][PT], h3u2 (&pl)[NT][PT], float& amax)
 {
-    const int lk = lane >> 4;
 #pragma unroll
-    for (int n = 0; n < NT; n++) {
-        const h3f4 b = *reinterpret_cast<const h3f4*>(bias + c0 + 16 * n + 4 * lk);
+    for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int t = 0; t < PT; t++) {
-            h3h4 hi, lo4;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = (am[n][t][r] + ac[n][t][r] * (1.f / 2048.f)) + b[r];
-                h3_watch(amax, v);
-                v = fmaxf(v, 0.f);
-                _Float16 a, l;
-                h3_split(v, a, l);
-                hi[r] = a; lo4[r] = l;
-            }
-            ph[n][t] = __builtin_bit_cast(h3u2, hi); pl[n][t] = __builtin_bit_cast(h3u2, lo4);
+            for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(ac[n][t][r], 1.f / 2048.f, am[n][t][r]);
+            h3_watch2(amax, v[0], v[1]); h3_watch2(amax, v[2], v[3]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            unsigned h0, h1, l0, l1;
+            h3_split2(v[0], v[1], k2048, h0, l0);
+            h3_split2(v[2], v[3], k2048, h1, l1);
+            ph[n][t] = (h3u2){ h0, h1 }; pl[n][t] = (h3u2){ l0, l1 };
         }
-    }
 }
 
 // packed tiles -> the split image `out` ([position][C hi | C lo' | pad], position stride so, lo' plane at lo)
@@ -179,30 +175,30 @@ __device__ __forceinline__ void ch_put(unsigned out, unsigned so, unsigned lo, c
 // pack + put tile by tile (the packed form of a whole 9 x 2 tile set beside its 144 accumulators would spill)
 template <int PT, int NT>
 __device__ __forceinline__ void ch_store(unsigned out, unsigned so, unsigned lo, const h3f4 (&am)[NT][PT], const h3f4 (&ac)[NT][PT],
-                                         const float* __restrict__ bias, int c0, int p0, int npos, unsigned lane, unsigned& amax)
+                                         int c0, int p0, int npos, unsigned lane, float& amax)
 {
     const int li = lane & 15, lk = lane >> 4;
+    float k2048 = 2048.f;
+    asm volatile("" : "+v"(k2048));
 #pragma unroll
     for (int n = 0; n < NT; n++) {
         const int c = c0 + 16 * n + 4 * lk;
-        const h3f4 b = *reinterpret_cast<const h3f4*>(bias + c);
 #pragma unroll
         for (int t = 0; t < PT; t++) {
             const int p = p0 + 16 * t + li;
-            h3h4 hi, lo4;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = (am[n][t][r] + ac[n][t][r] * (1.f / 2048.f)) + b[r];
-                h3_watch(amax, v);
-                v = fmaxf(v, 0.f);
-                _Float16 a, l;
-                h3_split(v, a, l);
-                hi[r] = a; lo4[r] = l;
-            }
+            for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(ac[n][t][r], 1.f / 2048.f, am[n][t][r]);
+            h3_watch2(amax, v[0], v[1]); h3_watch2(amax, v[2], v[3]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            unsigned h0, h1, l0, l1;
+            h3_split2(v[0], v[1], k2048, h0, l0);
+            h3_split2(v[2], v[3], k2048, h1, l1);
             if (p < npos) {
                 const unsigned a = out + (unsigned)p * so + (unsigned)c * 2u;
-                *(__attribute__((address_space(3))) h3u2*)(size_t)a = __builtin_bit_cast(h3u2, hi);
-                *(__attribute__((address_space(3))) h3u2*)(size_t)(a + lo) = __builtin_bit_cast(h3u2, lo4);
+                *(__attribute__((address_space(3))) h3u2*)(size_t)a = (h3u2){ h0, h1 };
+                *(__attribute__((address_space(3))) h3u2*)(size_t)(a + lo) = (h3u2){ l0, l1 };
             }
             __builtin_amdgcn_sched_barrier(0);       // tile by tile: interleaved, the temporaries of several tiles beside 144 accumulators spill
         }
@@ -212,7 +208,7 @@ __device__ __forceinline__ void ch_store(unsigned out, unsigned so, unsigned lo,
 // One unpadded 3 x 3 layer HIN x HIN (CIN channels) -> HOUT x HOUT (COUT), in place at the start of the buffer: the wavefront's
 // tiles [pt0, pt0 + PT) x outputs [c0, c0 + 16 NT).
 template <int PT, int NT, int CIN, int COUT, int HIN, int D>
-__device__ __forceinline__ void ch_layer(unsigned lds0, const void* wt, const float* bias, int group, int pt0, unsigned lane, unsigned& amax)
+__device__ __forceinline__ void ch_layer(unsigned lds0, const void* wt, const float* bias, int group, int pt0, unsigned lane, float& amax)
 {
     constexpr int TAPS_H = 3, TAPS_W = 3;
     constexpr int HOUT = HIN - TAPS_H + 1, NPOS = HOUT * HOUT, KS = CIN / 32;
@@ -227,15 +223,17 @@ __device__ __forceinline__ void ch_layer(unsigned lds0, const void* wt, const fl
     }
     h3f4 am[NT][PT], ac[NT][PT];
 #pragma unroll
-    for (int n = 0; n < NT; n++)
+    for (int n = 0; n < NT; n++) {
+        const h3f4 b = *reinterpret_cast<const h3f4*>(bias + group * 16 * NT + 16 * n + 4 * (lane >> 4));      // the hi-sum starts at the bias
 #pragma unroll
-        for (int t = 0; t < PT; t++) { am[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; ac[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; }
+        for (int t = 0; t < PT; t++) { am[n][t] = b; ac[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; }
+    }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, 0x7fffffff, 0x00027000);
     ch_gemm<PT, NT, KS, TAPS_H, TAPS_W, D>(adr, HIN * SI, SI, 2u * CIN, rs, (unsigned)group * (TAPS_H * TAPS_W * KS * NT * 2048u), lane, am, ac);
     __syncthreads();                                             // every wavefront has read the input map
     unsigned lane_s = lane;
     asm volatile("" : "+v"(lane_s));
-    ch_store<PT, NT>(lds0, SO, 2u * COUT, am, ac, bias, group * 16 * NT, 16 * pt0, NPOS, lane_s, amax);
+    ch_store<PT, NT>(lds0, SO, 2u * COUT, am, ac, group * 16 * NT, 16 * pt0, NPOS, lane_s, amax);
 }
 
 // Wavefront tiles (w = wavefront, 16-position tiles x 16-output tiles):
@@ -256,7 +254,10 @@ __global__ void __launch_bounds__(CH_THREADS, 2) k_cost_net_h3(const float* __re
     const int w = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const unsigned lane = tid & (WAVE - 1);
     const int li = lane & 15, lk = lane >> 4;
-    unsigned amax = 0u;
+    unsigned amax_in = 0u;                       // inputs: integer watch (catches NaN); inside the stack: float maximum
+    float amax = 0.f;
+    float k2048 = 2048.f;
+    asm volatile("" : "+v"(k2048));
     CH_STAMP_AT(0)
     {   // both maps -> split images, transposed on the way in: global [c][k][l] -> LDS [k][l][c]; S with two wrap-around columns per side
         const float* a = s_eq + (P.s_rows ? (size_t)P.s_rows[match] * P.row_floats + P.skip_floats : (size_t)match * 3200);
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(CH_THREADS, 2) k_cost_net_h3(const float* __re
                 h3_split(sv[1][j], h, lo); sh[1] = h; sl[1] = lo;
                 h3_split(tv[0][j], h, lo); th[0] = h; tl[0] = lo;
                 h3_split(tv[1][j], h, lo); th[1] = h; tl[1] = lo;
-                h3_watch(amax, sv[0][j]); h3_watch(amax, sv[1][j]); h3_watch(amax, tv[0][j]); h3_watch(amax, tv[1][j]);
+                h3_watch(amax_in, sv[0][j]); h3_watch(amax_in, sv[1][j]); h3_watch(amax_in, tv[0][j]); h3_watch(amax_in, tv[1][j]);
                 auto put = [&](unsigned pos_adr, h3h2 vh, h3h2 vl) __attribute__((always_inline)) {
                     *(__attribute__((address_space(3))) unsigned*)(size_t)(pos_adr + 4u * cp) = __builtin_bit_cast(unsigned, vh);
                     *(__attribute__((address_space(3))) unsigned*)(size_t)(pos_adr + 64u + 4u * cp) = __builtin_bit_cast(unsigned, vl);
@@ -350,18 +351,19 @@ __global__ void __launch_bounds__(CH_THREADS, 2) k_cost_net_h3(const float* __re
                 const h3f4* s4 = reinterpret_cast<const h3f4*>(SM + (kq * 20 + jj) * CH_MAPS + 8 * c8);
                 const h3f4* t4 = reinterpret_cast<const h3f4*>(TB + (kq * 18 + l) * CH_MAPS + 8 * c8);
                 const h3f4 s0 = s4[0], s1 = s4[1], t0 = t4[0], t1 = t4[1];
-                h3h8 hi, lo;
+                h3u4 hi, lo;
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const float v = fmaxf((q < 4 ? s0[q & 3] : s1[q & 3]) + (q < 4 ? t0[q & 3] : t1[q & 3]), 0.f);
-                    _Float16 a, l2;
-                    h3_split(v, a, l2);
-                    hi[q] = a; lo[q] = l2;
-                    h3_watch(amax, v);
+                for (int q = 0; q < 8; q += 2) {
+                    const float v0 = fmaxf((q < 4 ? s0[q & 3] : s1[q & 3]) + (q < 4 ? t0[q & 3] : t1[q & 3]), 0.f);
+                    const float v1 = fmaxf((q < 4 ? s0[(q + 1) & 3] : s1[(q + 1) & 3]) + (q < 4 ? t0[(q + 1) & 3] : t1[(q + 1) & 3]), 0.f);
+                    h3_watch2(amax, v0, v1);
+                    unsigned hh, ll;
+                    h3_split2(v0, v1, k2048, hh, ll);
+                    hi[q >> 1] = hh; lo[q >> 1] = ll;
                 }
                 const unsigned ad = lds0 + CH_XC + (unsigned)pos * CH_SXC + (unsigned)(kq * 64 + c8 * 16);
-                *(__attribute__((address_space(3))) h3u4*)(size_t)ad = __builtin_bit_cast(h3u4, hi);
-                *(__attribute__((address_space(3))) h3u4*)(size_t)(ad + 192u) = __builtin_bit_cast(h3u4, lo);
+                *(__attribute__((address_space(3))) h3u4*)(size_t)ad = hi;
+                *(__attribute__((address_space(3))) h3u4*)(size_t)(ad + 192u) = lo;
             }
             __syncthreads();
             CH_STAMP_ADD(12, tf0)
@@ -373,11 +375,13 @@ __global__ void __launch_bounds__(CH_THREADS, 2) k_cost_net_h3(const float* __re
             for (int t = 0; t < 2; t++) adr[t] = lds0 + CH_XC + (unsigned)((2 * half + t) * 18 + li) * CH_SXC + lk * 16u;
             h3f4 am[2][2], ac[2][2];
 #pragma unroll
-            for (int n = 0; n < 2; n++)
+            for (int n = 0; n < 2; n++) {
+                const h3f4 b1 = *reinterpret_cast<const h3f4*>(P.bias[1] + 32 * pair + 16 * n + 4 * lk);
 #pragma unroll
-                for (int t = 0; t < 2; t++) { am[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; ac[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; }
+                for (int t = 0; t < 2; t++) { am[n][t] = b1; ac[n][t] = (h3f4){ 0.f, 0.f, 0.f, 0.f }; }
+            }
             ch_gemm<2, 2, 3, 3, 3, 6>(adr, 18 * CH_SXC, CH_SXC, 192u, rs1, (unsigned)pair * (9 * 3 * 2 * 2048u), lane, am, ac);
-            ch_pack<2, 2>(am, ac, P.bias[1], 32 * pair, lane, ph[j], pl[j], amax);
+            ch_pack<2, 2>(am, ac, k2048, ph[j], pl[j], amax);
             __syncthreads();                                     // the chunk has been read: the next one (or the layer-1 map) may be written
             CH_STAMP_ADD(13, tg0)
         }
@@ -439,7 +443,7 @@ __global__ void __launch_bounds__(CH_THREADS, 2) k_cost_net_h3(const float* __re
         if (lane == 0) ind_out[match] = sw / se;
     }
     CH_STAMP_AT(9)
-    if (P.status && __builtin_amdgcn_ballot_w64(amax >= H3_F16_LIMIT_BITS) != 0 && lane == 0) atomicOr(P.status, 1);
+    if (P.status && __builtin_amdgcn_ballot_w64(amax_in >= H3_F16_LIMIT_BITS || !(amax < 65504.f)) != 0 && lane == 0) atomicOr(P.status, 1);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------

@@ -15,6 +15,8 @@ bench = json.load(open(bench_file))            # the uncompacted record (bench.p
 
 
 def per_launch(path, counter):
+    """mean counter value per dispatch and kernel (the profiled bench runs issue full-step launches only: BUF_NO_TRAFFIC=1 turns
+    the single-pair latency measurements of bench.py off)"""
     agg, disp = collections.defaultdict(float), collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
