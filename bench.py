@@ -465,9 +465,19 @@ def main():
         poses_s, mine_s, _, elapsed_s, timed_s = timed_region(pipe_s, 1)
         pipe_s.desc.fused.check_range()
         pipe_s.inlier.fused.check_range()
+        lat_s = None
+        if rank == 0 and pps and not os.environ.get('BUF_NO_TRAFFIC'):
+            ts = []
+            for _ in range(11):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pipe_s.register_batch([inputs[0]], seeds=[0])
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            lat_s = float(np.median(ts[1:]))
         if rank == 0:
             dpose = float((mine_s - mine).abs().max().item()) if mine.numel() else 0.0
-            split = dict(elapsed=elapsed_s, timed=timed_s, ok=dgr_ok(mine_s.cpu().numpy(), gts), dpose=dpose,
+            split = dict(elapsed=elapsed_s, timed=timed_s, ok=dgr_ok(mine_s.cpu().numpy(), gts), dpose=dpose, latency=lat_s,
                          err=cnn_error_vs_float64(pipe, pipe_s, dev))
 
     if rank == 0:
@@ -511,6 +521,7 @@ def main():
             out['value_split'] = pairs / split['elapsed']
             out['ms_per_step_split'] = split['elapsed'] / a.steps * 1e3
             out['split'] = {'registered_ok': f"{split['ok']}/{len(all_poses)}", 'max_abs_pose_difference_vs_f32_kernels': split['dpose'],
+                            'single_pair_latency_ms': split['latency'],
                             'headline': "value / dtype stay on the fp32-MFMA kernels; *_split = the same steps with cnn_arith='split'"}
             detail.update({k: out[k] for k in ('roofline_split', 'value_split', 'ms_per_step_split', 'split')})
         # compact tail (the driver keeps the last 2000 characters of the line): every other kernel as {kernel, bound, frac, avg_us,
