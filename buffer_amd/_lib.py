@@ -64,6 +64,8 @@ _SIGNATURES = {
     "buf_fps_ragged": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "buf_svd3x3_batched": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "buf_vn_gather_block": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "buf_vn_gather_pre_ws_bytes": (_sz, [_i, _i]),
+    "buf_vn_gather_block_pre": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "buf_vn_pointwise": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "buf_gather_max": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "buf_vn_std": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

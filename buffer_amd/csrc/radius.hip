@@ -779,7 +779,6 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
                                                                          ex.q_off, q_order, self_query, r2, bin_scale, k_out, g->ns, nbr_out,
                                                                          counts_out, max_count_out, todo, ex.todo_n);
     }
-    if (timed) timing_end(s, &span);
     if (k_out > 0 || foreign_order || (self_query && todo)) {
         // fallback pass over the (normally empty) todo list; exits at once when the device-side count is 0.  It rewrites whole
         // rows and counts (the same values where the wave kernel already counted a long row)
@@ -790,6 +789,7 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
             k_grid_query<64><<<blocks, WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, queries, nq,
                                                     ex.q_off, g->nb, todo, r2, k_out, g->ns, nbr_out, counts_out, max_count_out, ex.todo_n);
     }
+    if (timed) timing_end(s, &span);          // the span covers the fallback pass too (stage / row overflows of the fast kernels are part of the operator's cost)
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }

@@ -125,6 +125,156 @@ __global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_p
     dst[0] = (float)(ax / (double)K); dst[1] = (float)(ay / (double)K); dst[2] = (float)(az / (double)K);      // mean_pool, vn_layers.py:165-166
 }
 
+// ---- mode '6' (block 0: one input vector channel) with the gathered rows staged in LDS (round 4) -------------------------------
+// k_vn_gather walks a neighbour row as a chain of dependent loads (index -> support point + feature row, ~1000 cycles per slot and
+// K slots per lane, every output lane of a point repeating the chain).  Here a workgroup owns VG6_PTS points: their index rows
+// are read once (coalesced), every (point, slot)'s support coordinates and feature vector -- 24 bytes -- are fetched with all loads
+// in flight at once into LDS as delta = (s - q) / scale and f, the mean of the deltas is formed once per point, and the lanes
+// (point, output channel) then run the slots from LDS.  Same arithmetic, same order of the fp64 sums: bit-identical to k_vn_gather.
+#define VG6_PTS 32
+__global__ void __launch_bounds__(256) k_vn_gather6_lds(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                      const float* __restrict__ feats, const int* __restrict__ idx,
+                                                      int nq, int ns, int K, int cout, float scale, VnParams P, float* __restrict__ out)
+{
+    extern __shared__ float lds[];
+    float* wf = lds;                                   // [cout][4]
+    float* wd = wf + cout * 4;
+    float* ef = wd + cout * 4;                         // [VG6_PTS][K][8]: ex, ey, ez, real, fx, fy, fz, -
+    float* mean = ef + (size_t)VG6_PTS * K * 8;        // [VG6_PTS][4]
+    for (int t = threadIdx.x; t < cout * 4; t += 256) { wf[t] = P.wf[t]; wd[t] = P.wd[t]; }
+    const int p0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * VG6_PTS;
+    const int np = min(VG6_PTS, nq - p0);
+    for (int t = threadIdx.x; t < np * K; t += 256) {
+        const int pl = t / K, i = p0 + pl;
+        const int j = idx[(size_t)p0 * K + t];
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < ns) {
+            const float qx = q_pts[3 * (size_t)i], qy = q_pts[3 * (size_t)i + 1], qz = q_pts[3 * (size_t)i + 2];
+            a = make_float4((s_pts[3 * (size_t)j] - qx) / scale, (s_pts[3 * (size_t)j + 1] - qy) / scale, (s_pts[3 * (size_t)j + 2] - qz) / scale, 1.f);
+            b = make_float4(feats[3 * (size_t)j], feats[3 * (size_t)j + 1], feats[3 * (size_t)j + 2], 0.f);
+        }
+        reinterpret_cast<float4*>(ef)[2 * t] = a;
+        reinterpret_cast<float4*>(ef)[2 * t + 1] = b;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < np) {                       // mean over K of delta (point_learner.py:392), sequential fp64 sum as k_vn_gather
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        const float4* e4 = reinterpret_cast<const float4*>(ef) + (size_t)threadIdx.x * K * 2;
+        for (int k = 0; k < K; k++) {
+            const float4 a = e4[2 * k];
+            if (a.w != 0.f) { sx += (double)a.x; sy += (double)a.y; sz += (double)a.z; }
+        }
+        mean[4 * threadIdx.x] = (float)(sx / (double)K); mean[4 * threadIdx.x + 1] = (float)(sy / (double)K); mean[4 * threadIdx.x + 2] = (float)(sz / (double)K);
+    }
+    __syncthreads();
+    const bool has_bn = P.bn_scale != nullptr;
+    for (int t = threadIdx.x; t < np * cout; t += 256) {
+        const int pl = t / cout, o = t - pl * cout;
+        const float* wfo = wf + o * 4;
+        const float* wdo = wd + o * 4;
+        const float bsc = has_bn ? P.bn_scale[o] : 0.f, bsh = has_bn ? P.bn_shift[o] : 0.f;
+        const float mx = mean[4 * pl], my = mean[4 * pl + 1], mz = mean[4 * pl + 2];
+        const float4* e4 = reinterpret_cast<const float4*>(ef) + (size_t)pl * K * 2;
+        double ax = 0.0, ay = 0.0, az = 0.0;
+        for (int k = 0; k < K; k++) {
+            const float4 a = e4[2 * k], b = e4[2 * k + 1];
+            const float ex = a.x, ey = a.y, ez = a.z, fx = b.x, fy = b.y, fz = b.z;
+            const float cx = fy * ez - fz * ey, cy = fz * ex - fx * ez, cz = fx * ey - fy * ex;
+            float px = wfo[0] * fx + wfo[1] * ex + wfo[2] * cx + wfo[3] * mx;
+            float py = wfo[0] * fy + wfo[1] * ey + wfo[2] * cy + wfo[3] * my;
+            float pz = wfo[0] * fz + wfo[1] * ez + wfo[2] * cz + wfo[3] * mz;
+            float dx = wdo[0] * fx + wdo[1] * ex + wdo[2] * cx + wdo[3] * mx;
+            float dy = wdo[0] * fy + wdo[1] * ey + wdo[2] * cy + wdo[3] * my;
+            float dz = wdo[0] * fz + wdo[1] * ez + wdo[2] * cz + wdo[3] * mz;
+            vn_epilogue(px, py, pz, dx, dy, dz, has_bn, bsc, bsh, P.slope);
+            ax += (double)px; ay += (double)py; az += (double)pz;
+        }
+        float* dst = out + (size_t)(p0 + pl) * 3 * cout + 3 * o;
+        dst[0] = (float)(ax / (double)K); dst[1] = (float)(ay / (double)K); dst[2] = (float)(az / (double)K);
+    }
+}
+
+// ---- mode '1' with the channel contraction hoisted out of the neighbour loop (round 4) ----------------------------------------
+// VN-linear is linear and its input is [f_j (Cin channels), delta_ij]: the feature part of both maps depends on the SUPPORT point
+// only, PF[j] = [Wf[:, :Cin] f_j | Wd[:, :Cin] f_j] (k_vn_linear_pre: N_s x 2 Cout dot products over Cin, fp64, rounded once),
+// and a neighbour slot costs 6 multiply-adds for the delta column instead of 6 (Cin + 1): the K-fold repetition of the
+// contraction -- 12 Cin of the ~12 Cin + 40 operations per slot -- is gone (Cin = 10 .. 40 in the four resnet blocks).
+// The sum [PF + w_delta * delta] is formed in fp64 from the fp32 PF: one rounding more than the all-fp64 dot product of
+// k_vn_gather, of half an ulp of the partial sum (tests/test_model_gpu.py bounds the result against the float64 network as before).
+__global__ void __launch_bounds__(256) k_vn_linear_pre(const float* __restrict__ feats, int ns, int cin, int cout, VnParams P,
+                                                     float* __restrict__ pf)
+{
+    extern __shared__ float lds[];
+    const int cinp = cin + 1;
+    float* wf = lds;
+    float* wd = lds + cout * cinp;
+    for (int t = threadIdx.x; t < cout * cinp; t += 256) { wf[t] = P.wf[t]; wd[t] = P.wd[t]; }
+    __syncthreads();
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)ns * 2 * cout) return;
+    const int j = (int)(t / (2 * cout)), o2 = (int)(t % (2 * cout));
+    const float* w = (o2 < cout ? wf + o2 * cinp : wd + (o2 - cout) * cinp);
+    const float* f = feats + (size_t)j * 3 * cin;
+    double x = 0.0, y = 0.0, z = 0.0;
+    for (int c = 0; c < cin; c++) {
+        const double a = w[c];
+        x += a * (double)f[3 * c]; y += a * (double)f[3 * c + 1]; z += a * (double)f[3 * c + 2];
+    }
+    float* d = pf + (size_t)t * 3;
+    d[0] = (float)x; d[1] = (float)y; d[2] = (float)z;
+}
+
+// A workgroup owns VG6_PTS points: their index rows and deltas are staged once in LDS (16 bytes per (point, slot): ex, ey, ez,
+// support index), so the slot loop of a lane (point, output channel) has no dependent index -> row chain left: the PF reads of
+// several slots are in flight together (unrolled by four).
+__global__ void __launch_bounds__(256) k_vn_gather_pre(const float* __restrict__ q_pts, const float* __restrict__ s_pts,
+                                                     const float* __restrict__ pf, const int* __restrict__ idx,
+                                                     int nq, int ns, int K, int cin, int cout, float scale,
+                                                     VnParams P, float* __restrict__ out)
+{
+    extern __shared__ float lds[];
+    float4* ej = reinterpret_cast<float4*>(lds);        // [VG6_PTS][K]: ex, ey, ez, bitcast support index (-1: shadow)
+    const int p0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * VG6_PTS;
+    const int np = min(VG6_PTS, nq - p0);
+    for (int t = threadIdx.x; t < np * K; t += 256) {
+        const int pl = t / K, i = p0 + pl;
+        const int j = idx[(size_t)p0 * K + t];
+        float4 a = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (j < ns) {
+            const float qx = q_pts[3 * (size_t)i], qy = q_pts[3 * (size_t)i + 1], qz = q_pts[3 * (size_t)i + 2];
+            a = make_float4((s_pts[3 * (size_t)j] - qx) / scale, (s_pts[3 * (size_t)j + 1] - qy) / scale, (s_pts[3 * (size_t)j + 2] - qz) / scale,
+                            __int_as_float(j));
+        }
+        ej[t] = a;
+    }
+    __syncthreads();
+    const int cinp = cin + 1;
+    const bool has_bn = P.bn_scale != nullptr;
+    for (int t = threadIdx.x; t < np * cout; t += 256) {
+        const int pl = t / cout, o = t - pl * cout;
+        const double wfe = P.wf[o * cinp + cin], wde = P.wd[o * cinp + cin];
+        const float bsc = has_bn ? P.bn_scale[o] : 0.f, bsh = has_bn ? P.bn_shift[o] : 0.f;
+        const float4* e4 = ej + (size_t)pl * K;
+        double ax = 0.0, ay = 0.0, az = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < K; k++) {
+            const float4 e = e4[k];
+            const int j = __float_as_int(e.w);
+            float px = 0.f, py = 0.f, pz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+            if (j >= 0) {                                    // shadow: delta = 0, features = 0 (:329-349)
+                const float* a = pf + ((size_t)j * 2 * cout + o) * 3;
+                const float* b = a + (size_t)cout * 3;
+                px = (float)((double)a[0] + wfe * (double)e.x); py = (float)((double)a[1] + wfe * (double)e.y); pz = (float)((double)a[2] + wfe * (double)e.z);
+                dx = (float)((double)b[0] + wde * (double)e.x); dy = (float)((double)b[1] + wde * (double)e.y); dz = (float)((double)b[2] + wde * (double)e.z);
+            }
+            vn_epilogue(px, py, pz, dx, dy, dz, has_bn, bsc, bsh, P.slope);
+            ax += (double)px; ay += (double)py; az += (double)pz;
+        }
+        float* dst = out + (size_t)(p0 + pl) * 3 * cout + 3 * o;
+        dst[0] = (float)(ax / (double)K); dst[1] = (float)(ay / (double)K); dst[2] = (float)(az / (double)K);      // mean_pool, vn_layers.py:165-166
+    }
+}
+
 // Point-wise VN layer (VNLinearLeakyReLU with dim=4; VNBlock, unary, shortcut, fc_layer, VNStdFeature):
 //   in_i = concat( A[ia(i)] (ca channels; row through ind_a[i*ind_stride], >= na -> zeros) , B[i] (cb channels) )
 //   out_i = VN(in_i) (+ residual_i)
@@ -228,9 +378,44 @@ extern "C" int buf_vn_gather_block(const float* q_pts, const float* s_pts, const
     long long total = (long long)nq * cout;
     TimedSpan span;
     bool timed = timing_begin((hipStream_t)stream, &span, 4.0 * nq * k + 12.0 * nq + 12.0 * nq * cin + 12.0 * nq * cout, BUF_TIMED_VN_GATHER);
-    k_vn_gather<<<cdiv(total, 256), 256, lds, (hipStream_t)stream>>>(q_pts, s_pts, feats, idx, nq, ns, k, cin, cout,
-                                                                   mode == 6 ? 1 : 0, scale,
-                                                                   make_params(wf, wd, bn_scale, bn_shift, slope), out);
+    static const bool direct6 = getenv("BUF_VN_GATHER_DIRECT") != nullptr;        // development switch: the round-1..3 kernel for mode '6' too
+    const size_t lds6 = sizeof(float) * (8 * (size_t)cout + (size_t)VG6_PTS * k * 8 + VG6_PTS * 4);
+    if (mode == 6 && !direct6 && lds6 <= 48 * 1024)
+        k_vn_gather6_lds<<<cdiv(nq, VG6_PTS), 256, lds6, (hipStream_t)stream>>>(q_pts, s_pts, feats, idx, nq, ns, k, cout, scale,
+                                                                              make_params(wf, wd, bn_scale, bn_shift, slope), out);
+    else
+        k_vn_gather<<<cdiv(total, 256), 256, lds, (hipStream_t)stream>>>(q_pts, s_pts, feats, idx, nq, ns, k, cin, cout,
+                                                                       mode == 6 ? 1 : 0, scale,
+                                                                       make_params(wf, wd, bn_scale, bn_shift, slope), out);
+    if (timed) timing_end((hipStream_t)stream, &span);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}
+
+// mode '1' through the hoisted contraction; ws: f32[ns * 6 * cout] (buf_vn_gather_pre_ws_bytes)
+extern "C" size_t buf_vn_gather_pre_ws_bytes(int ns, int cout) { return sizeof(float) * 6 * (size_t)(ns > 0 ? ns : 1) * (size_t)(cout > 0 ? cout : 1); }
+
+extern "C" int buf_vn_gather_block_pre(const float* q_pts, const float* s_pts, const float* feats, const int* idx,
+                                       int nq, int ns, int k, int cin, int cout, float scale,
+                                       const float* wf, const float* wd, const float* bn_scale, const float* bn_shift,
+                                       float slope, float* out, void* ws, size_t ws_bytes, void* stream)
+{
+    BUF_REQUIRE(nq >= 0 && ns >= 0 && k > 0 && cin > 0 && cout > 0, BUF_EINVAL, "buf_vn_gather_block_pre: bad sizes");
+    BUF_REQUIRE(scale != 0.f, BUF_EINVAL, "buf_vn_gather_block_pre: scale == 0");
+    if (nq == 0) return BUF_OK;
+    BUF_REQUIRE(q_pts && s_pts && feats && idx && wf && wd && out, BUF_EINVAL, "buf_vn_gather_block_pre: null argument");
+    BUF_REQUIRE(ws && ws_bytes >= buf_vn_gather_pre_ws_bytes(ns, cout), BUF_EWORKSPACE, "buf_vn_gather_block_pre: workspace of %zu bytes, need %zu",
+                ws_bytes, buf_vn_gather_pre_ws_bytes(ns, cout));
+    const size_t lds = sizeof(float) * 2 * (size_t)cout * (cin + 1);
+    BUF_REQUIRE(lds <= 64 * 1024, BUF_EINVAL, "buf_vn_gather_block_pre: weights exceed 64 KiB of LDS");
+    const VnParams P = make_params(wf, wd, bn_scale, bn_shift, slope);
+    TimedSpan span;
+    bool timed = timing_begin((hipStream_t)stream, &span, 4.0 * nq * k + 12.0 * nq + 12.0 * nq * cin + 12.0 * nq * cout, BUF_TIMED_VN_GATHER);
+    if (ns > 0)
+        k_vn_linear_pre<<<cdiv((long long)ns * 2 * cout, 256), 256, lds, (hipStream_t)stream>>>(feats, ns, cin, cout, P, (float*)ws);
+    const size_t lds_g = sizeof(float4) * (size_t)VG6_PTS * k;
+    BUF_REQUIRE(lds_g <= 48 * 1024, BUF_EINVAL, "buf_vn_gather_block_pre: k=%d too large for the LDS stage", k);
+    k_vn_gather_pre<<<cdiv(nq, VG6_PTS), 256, lds_g, (hipStream_t)stream>>>(q_pts, s_pts, (const float*)ws, idx, nq, ns, k, cin, cout, scale, P, out);
     if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
     return BUF_OK;

@@ -4,6 +4,7 @@ PyTorch is used for device memory and stream handles only; every operator below 
 gfx950 kernel behind the C ABI of include/buffer_hip.h.  Nothing here falls back to the CPU.
 """
 import ctypes as C
+import os
 import numpy as np
 import torch
 
@@ -327,6 +328,14 @@ def vn_gather_block(layer, q_pts, s_pts, feats, idx, mode, scale=1.0):
     ns = s_pts.shape[0]
     cin = feats.shape[1] // 3
     out = torch.empty((nq, 3 * layer.cout), dtype=torch.float32, device=feats.device)
+    if int(mode) == 1 and not os.environ.get('BUF_VN_GATHER_DIRECT'):
+        # the channel contraction once per support point instead of once per neighbour slot (csrc/vn.hip, round 4)
+        wsb = L.buf_vn_gather_pre_ws_bytes(ns, layer.cout)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=feats.device)
+        check(L.buf_vn_gather_block_pre(_ptr(q_pts), _ptr(s_pts), _ptr(feats), _ptr(idx), nq, ns, k, cin, layer.cout, float(scale),
+                                        _ptr(layer.wf), _ptr(layer.wd), _ptr(layer.bsc), _ptr(layer.bsh), layer.slope, _ptr(out),
+                                        _ptr(ws), wsb, _stream()), "buf_vn_gather_block_pre")
+        return out
     check(L.buf_vn_gather_block(_ptr(q_pts), _ptr(s_pts), _ptr(feats), _ptr(idx), nq, ns, k, cin, layer.cout, int(mode),
                                 float(scale), _ptr(layer.wf), _ptr(layer.wd), _ptr(layer.bsc), _ptr(layer.bsh),
                                 layer.slope, _ptr(out), _stream()), "buf_vn_gather_block")

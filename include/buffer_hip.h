@@ -203,6 +203,14 @@ int     buf_vn_gather_block(const float* q_pts, const float* s_pts, const float*
                             int nq, int ns, int k, int cin, int cout, int mode, float scale,
                             const float* wf, const float* wd, const float* bn_scale, const float* bn_shift,
                             float slope, float* out, void* stream);
+/* The same for mode '1' with the channel contraction hoisted out of the neighbour loop (csrc/vn.hip: the feature part of both
+ * VN-linear maps is formed once per SUPPORT point, a neighbour slot adds the delta column): 4-5 x fewer operations in the resnet
+ * blocks, results within half an ulp of a partial sum of buf_vn_gather_block.  ws: buf_vn_gather_pre_ws_bytes(ns, cout) bytes. */
+size_t  buf_vn_gather_pre_ws_bytes(int ns, int cout);
+int     buf_vn_gather_block_pre(const float* q_pts, const float* s_pts, const float* feats, const int* idx,
+                                int nq, int ns, int k, int cin, int cout, float scale,
+                                const float* wf, const float* wd, const float* bn_scale, const float* bn_shift,
+                                float slope, float* out, void* ws, size_t ws_bytes, void* stream);
 /* point-wise VN layer on concat(a[ind_a[i*ind_stride]] , b[i]) (+ residual); ind_a null = identity;
  * rows with index >= na read as zeros (closest_pool shadow); wd null = plain VN linear. */
 int     buf_vn_pointwise(const float* a, const int* ind_a, int ind_stride, int na, int ca, const float* b, int cb,

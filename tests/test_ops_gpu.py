@@ -231,3 +231,41 @@ def test_permute_clouds_is_a_keyed_permutation(dev):
             pos = np.array([src[tuple(r)] for r in a])
             assert abs(np.corrcoef(pos, np.arange(n))[0, 1]) < 4.0 / np.sqrt(n)        # a random permutation: sigma = 1/sqrt(n-1)
         lo += n
+
+
+def test_vn_gather_staged_and_hoisted_forms_against_the_direct_kernel(dev, tmp_path):
+    """Round 4: block 0 (mode '6') runs on k_vn_gather6_lds (gathered rows staged in LDS) and must be BIT-IDENTICAL to the direct
+    kernel; the resnet blocks (mode '1') run with the channel contraction hoisted to the support points (k_vn_linear_pre +
+    k_vn_gather_pre) and must agree with the direct kernel to 2e-6 of the tensor scale.  The direct kernels are selected with
+    BUF_VN_GATHER_DIRECT=1 in a child process (the C side reads the switch once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from buffer_amd import ops, synth, pyramid
+from buffer_amd.config import THREEDMATCH
+from buffer_amd.pipeline import BufferPipeline
+dev = torch.device('cuda:0')
+pipe = BufferPipeline(THREEDMATCH, dev, limits=[17, 20, 24])
+inp = pipe.upload(synth.make_pair(3000, n_raw=60_000))
+pyr = pyramid.build_pyramid(inp['points'], inp['lengths'], pipe.limits, THREEDMATCH)
+x0 = ops.vn_gather_block(pipe.point.b0, pyr['points'][0], pyr['points'][0], inp['features'].contiguous(), pyr['neighbors'][0], 6, 1.0)
+x1 = ops.vn_gather_block(pipe.point.res[0]['conv'], pyr['points'][1], pyr['points'][0], x0, pyr['pools'][0], 1, 1.0)
+np.savez(sys.argv[1], x0=x0.cpu().numpy(), x1=x1.cpu().numpy())
+""" % root
+    outs = []
+    for direct in (False, True):
+        path = str(tmp_path / f'vn_{int(direct)}.npz')
+        env = dict(os.environ, **({'BUF_VN_GATHER_DIRECT': '1'} if direct else {}))
+        env.pop('BUF_VN_GATHER_DIRECT', None) if not direct else None
+        r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    a, b = outs
+    assert np.array_equal(a['x0'], b['x0'])                                   # mode '6': same arithmetic, same order
+    d = np.abs(a['x1'] - b['x1']).max() / np.abs(b['x1']).max()
+    print('hoisted vs direct VN gather (block 1): max difference / scale =', d)
+    assert d < 2e-6
