@@ -262,10 +262,22 @@ def make_samples(kind, seeds):
     import multiprocessing as mp
     jobs = [(kind, s) for s in seeds]
     workers = max(1, min(len(jobs), (os.cpu_count() or 1) // max(int(os.environ.get('LOCAL_WORLD_SIZE', 1)), 1), 32))
-    if workers == 1:
+    # Under a profiler (rocprofv3 preloads its tool library, which initialises the GPU runtime before main) a forked child inherits a
+    # half-initialised runtime and its signal handlers: a worker can hang in the tool's finaliser when the pool is torn down (one
+    # profiled run of round 4 sat there for an hour).  No forks then: the samples are made one after the other.
+    profiled = any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '') \
+        or bool(os.environ.get('BUF_NO_TRAFFIC')) or bool(os.environ.get('BUF_BENCH_NO_FORK'))
+    if workers == 1 or profiled:
         return [_make_sample(j) for j in jobs]
-    with mp.get_context('fork').Pool(workers) as pool:
-        return pool.map(_make_sample, jobs)
+    pool = mp.get_context('fork').Pool(workers)
+    try:
+        out = pool.map(_make_sample, jobs)
+        pool.close()                                   # workers leave through their normal exit, not through SIGTERM
+        pool.join()
+        return out
+    except BaseException:
+        pool.terminate()
+        raise
 
 
 def cnn_error_vs_float64(pipe_f32, pipe_split, dev):

@@ -9,6 +9,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 out=$R/gpurun_out/$name
 mkdir -p "$out"
 export TMPDIR=/tmp
+export BUF_BENCH_NO_FORK=1          # bench.py: no forked sample generation under the profiler (a forked child can hang in the tool's finaliser)
 args=()
 for a in "$@"; do                      # the profiler runs from /tmp: make repo-relative paths absolute
     if [ -e "$R/$a" ] && [ "${a#-}" = "$a" ]; then args+=("$R/$a"); else args+=("$a"); fi
@@ -17,10 +18,10 @@ set -- "${args[@]}"
 cd /tmp
 if [ "$mode" = stats ]; then
     shift   # --
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o "$name" -- "$@" > "$out/run.log" 2>&1
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o "$name" -- "$@" > "$out/run.log" 2>&1
 else
     counters=$1; shift 2
-    rocprofv3 --kernel-trace --pmc $counters --output-format csv -d "$out" -o "$name" -- "$@" > "$out/run.log" 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d "$out" -o "$name" -- "$@" > "$out/run.log" 2>&1
 fi
 cd "$R"
 find "$out" -name "*.csv" | head
