@@ -414,7 +414,9 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
 #define QC_WAVES 4
 #define QC_QPW 16                   // queries per wavefront
 #ifndef QC_CAPC
-#define QC_CAPC 160                 // candidates of a 27-cell set the LDS stage holds (mean ~50; larger sets go to the lane-per-query pass)
+// candidates of a 27-cell set the LDS stage holds (mean ~50; larger sets go to the lane-per-query pass): 160 and 192 measure the
+// same at 64 pairs per launch (28 vs 24 wavefronts per CU); 192 leaves fewer rows to that pass
+#define QC_CAPC 192
 #endif
 
 // N queries of ONE cell against its staged candidates, 64 candidates per step: N independent chains of distance test, ballot
