@@ -29,6 +29,14 @@ def per_launch(path, counter):
 
 fetch, n_f = per_launch(fetch_csv, 'FETCH_SIZE')
 write, n_w = per_launch(write_csv, 'WRITE_SIZE')
+# the VN gather blocks as ONE operator (round 4): block 0 on k_vn_gather6_lds, the four resnet blocks on k_vn_linear_pre + k_vn_gather_pre;
+# per launch of the OPERATOR = bytes of all three kernels / number of block calls (gather6 + gather_pre dispatches)
+for d, n in ((fetch, n_f), (write, n_w)):
+    ks = [k for k in ('k_vn_gather6_lds', 'k_vn_gather_pre', 'k_vn_linear_pre') if k in d]
+    if ks and 'k_vn_gather' not in d:
+        calls = n.get('k_vn_gather6_lds', 0) + n.get('k_vn_gather_pre', 0)
+        d['k_vn_gather'] = sum(d[k] * n[k] for k in ks) / max(calls, 1)
+        n['k_vn_gather'] = calls
 # A2 as ONE operator: the cell-centric kernel (self queries) and the query-centric one (pool / upsample queries) of a pyramid
 for d, n in ((fetch, n_f), (write, n_w)):
     ks = [k for k in ('k_grid_query_cell', 'k_grid_query_wave') if k in d]
