@@ -4,13 +4,22 @@
 // Reference: axis_align -> normalize -> sphere_query (420 ball queries of 10 samples per patch,
 // materialising [P,420,10,3]) -> var_to_invar -> Conv2d1x1(3->16)+BN+ReLU -> max over the 10 samples.
 // Here: one workgroup per patch; the aligned, normalised 512-point patch sits in LDS (8 KB).
-//   1. point-parallel: every point looks up the voxel balls that can contain it (a 16^3 lookup grid over the
-//      unit ball, cell -> candidate centres, built once per call) and sets its bit in the hit mask of each
-//      ball that does (exact d^2 test, LDS atomicOr) -- ~30 candidates (14 hits) per point instead of 420 tests.  The table is
-//      compact (round 3): a 64-byte row per cell (24 candidates + the descriptor of its overflow run) = 256 KB and one packed
-//      overflow array (~40 KB for the 3DMatch grid; round 2: rows of 896 bytes, 3.7 MB).  The phase was 61 k of the kernel's
-//      78 k cycles per patch (-DVOX_STAMP) and is bound by the number of wavefront-level tests: it now runs in two passes
-//      (rows for every point, overflow runs for the queued 30 % only; see phase 1 below), 42 k of 59 k;
+//   1. hit masks (bit k of centre c <=> |centre_c - point_k|^2 < r^2) for ALL centre x point pairs on the f16 matrix pipe
+//      (round 4; rounds 1-3 tested ~30 candidate centres per point found through a 16^3 lookup grid and set the bits with LDS
+//      atomics: 42 k of the kernel's 59 k cycles per patch, bound by the number of wavefront-level tests).  One
+//      v_mfma_f32_32x32x16_f16 gives D = d^2 - r^2 of 32 points x 32 centres to ~1e-6: both operands are split x = hi + 2^-11 lo'
+//      (22 significant bits) and the K = 16 slots hold the terms of |c|^2 - r^2 + |q|^2 - 2 c.q:
+//          slot   point side (A)        centre side (B)
+//          0-2    q_hi (x,y,z)          X_hi             X = -2c
+//          3-5    q_lo'                 2^-11 X_hi
+//          6-8    q_hi                  2^-11 X_lo'
+//          9,10   |q|^2: hi, lo'        1, 2^-11
+//          11-13  1, 2^-11, 2^-22       |c|^2 - r^2 in three pieces
+//      The sign bit of D is the hit bit, shifted into the lane's mask piece by one v_alignbit per pair.  The answer has to be
+//      the reference's fp32 test `sqdist3(c, q) < r2` bit for bit, and it is: a lane whose |D| comes within eps (hdr[1], > 6x the
+//      error bound of the split form, see k_vox_ctab) of zero for any of its 16 pairs redoes those 16 tests with sqdist3 --
+//      about one pair in 10^5, a few lanes per patch.  Points that no ball can reach (|q| beyond max|c| + r, NaN) get a vector
+//      that makes D = +30000.
 //   2. centre-parallel: one lane per voxel centre walks its mask in index order (= pointnet2 ball_query's "first nsample
 //      in index order") and runs each hit through the azimuth de-rotation, the 3->16 MLP, BN, ReLU and the running max,
 //      all lanes slot by slot.
@@ -18,25 +27,16 @@
 #include "common.h"
 #include <type_traits>
 
-#define VOX_THREADS 448     // 7 wavefronts >= 420 centres
+#define VOX_THREADS 448     // 7 wavefronts >= 420 centres = 14 centre tiles of 32
 #define VOX_MAXPTS 1024
 static_assert(VOX_MAXPTS <= 32 * 32, "the non-empty-word summary of a hit mask is one 32-bit register (voxelize phase 2+3)");
 #define VOX_CH 16
 #define VOX_MAXS 16           // max samples per voxel kept in the hit list
-#define VOX_GRID 16           // lookup grid cells per axis
-#ifndef VOX_PP
-#define VOX_PP 3              // points per step of a lane group in phase 1a (2..5 measured within 4 %)
-#endif
-#define VOX_SENT 0xFFFFu      // end-of-list filler of a lookup row
+#define VOX_K 16              // K slots of the distance MFMA = f16 values per point / centre vector
+#define VOX_BIG 30000.f       // D of a pair that cannot hit (unreachable point, lane past the last centre)
 
-// Lookup table: rows[VOX_CELLS + 1][32] unsigned short -- entries 0..23 the cell's first candidate centres (VOX_SENT beyond the
-// list), entries 24, 25 one unsigned = start | count << 21 of the cell's run in the overflow array (candidates 24, 25, ...);
-// row VOX_CELLS is empty (points outside the grid).  Overflow runs are claimed with an atomic counter (their order in the array
-// is arbitrary, their content is not).
-#define VOX_CELLS (VOX_GRID * VOX_GRID * VOX_GRID)
-#define VOX_ROW 32
-#define VOX_ROW_N 24
-__host__ __device__ static inline size_t vox_overflow_capacity(int ncentres) { return (size_t)VOX_CELLS * (size_t)(ncentres > VOX_ROW_N ? ncentres - VOX_ROW_N : 0) + 64; }
+typedef _Float16 voxh8 __attribute__((ext_vector_type(8)));
+typedef float voxf16 __attribute__((ext_vector_type(16)));
 
 struct VoxMlp {             // Conv2d1x1(3->16) with the eval-mode BatchNorm folded in: 64 scalars, SGPR-resident
     float w[VOX_CH][3];     // s * Desc.pnt_layer.0.weight,  s = gamma / sqrt(var + 1e-5)
@@ -58,15 +58,12 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
                                                              float* __restrict__ out_x, float* __restrict__ out_R,
                                                              float* __restrict__ out_rand, float* __restrict__ out_patches)
 {
-    // dynamic LDS, sized by the launch (36.9 KB + the 7 KB centre copy at 512 points -> three workgroups per CU; the hit lists
-    // never leave the registers.  Reading the centres from L1/L2 instead would admit a fourth workgroup but measured slower):
+    // dynamic LDS, sized by the launch (52 KB at 512 points -> three workgroups per CU; the hit lists never leave the registers):
     extern __shared__ float4 pts[];                              // [npts] aligned, normalised patch
-    const int W = (npts + 31) >> 5;                              // mask words per centre
+    const int W = (npts + 31) >> 5;                              // mask words per centre = point tiles of 32
     unsigned* mask = reinterpret_cast<unsigned*>(pts + npts);    // [W][VOX_THREADS] hit bits
-    __shared__ float4 cen[VOX_THREADS];
+    voxh8* pvec = reinterpret_cast<voxh8*>(mask + (size_t)W * VOX_THREADS);   // [W][32 rows][2 halves]: point vectors, MFMA row order
     __shared__ float Rs[9];
-    __shared__ uint2 longq[VOX_MAXPTS];                          // phase 1b: (point, overflow run) of the points with long candidate lists
-    __shared__ unsigned nlong;
     const int p = blockIdx.x, tid = threadIdx.x;
     const float* src = patches + (size_t)p * npts * 3;
     VOX_STAMP_AT(0)
@@ -118,114 +115,69 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
     const int c = tid;
     const bool active = c < ncentres;
     float ca = 1.f, sa = 0.f;
-    {
-        float4 cc = make_float4(1e30f, 1e30f, 1e30f, 0.f);
-        if (active) {
-            cc = make_float4(centres[3 * c], centres[3 * c + 1], centres[3 * c + 2], 0.f);
-            int az = c % azi_n;                                  // ordering rad -> ele -> azi (utils/common.py:422-428)
-            ca = azi_cs[2 * az]; sa = azi_cs[2 * az + 1];        // cos/sin of -az * 2pi/azi_n (:485-491)
-        }
-        cen[tid] = cc;
+    if (active) {
+        int az = c % azi_n;                                      // ordering rad -> ele -> azi (utils/common.py:422-428)
+        ca = azi_cs[2 * az]; sa = azi_cs[2 * az + 1];            // cos/sin of -az * 2pi/azi_n (:485-491)
     }
-    for (int i = tid; i < W * VOX_THREADS; i += VOX_THREADS) mask[i] = 0u;
-    if (tid == 0) nlong = 0u;
-    __syncthreads();
-    // Phase 1: 8 lanes share a point and split its candidate list.  The phase is bound by the NUMBER of wavefront-level tests
-    // (~16 instructions each: -DVOX_STAMP experiments -- neither the table's latency nor the LDS atomics moved it), and lists are
-    // uneven (mean 30 candidates, 30 % of the points over 24, up to 140 next to the keypoint), so it runs in two passes:
-    //   1a. every point: the 24 candidates of its row, 3 per lane (VOX_PP points per step: 4 x VOX_PP row loads in flight per
-    //       lane); a point whose cell has an overflow run is queued in LDS;
-    //   1b. queued points only: 64 overflow candidates per round, 8 per lane, two points per step.
-    // Round 2 walked the long lists inside 1a, 32 candidates per round, whenever ANY of a wavefront's 8 points had one (94 % of
-    // the steps): 1 260 wavefront-tests per patch against 380 now.  The d^2 test is the one a full scan would do (same operand
-    // order), the lookup grid only removes centres that cannot pass it.
+    // Phase 1a: the 16 f16 of every point (slots above), stored at the MFMA row that hands lane half h of the result the points
+    // 16h .. 16h+15 of the tile in register order: point 16h + 4a + b -> row 8a + 4h + b.
     {
-        const float lo = tab_hdr[0], inv_h = tab_hdr[1];
-        const int sub = tid & 7;
-        const unsigned short* __restrict__ ovf = tab + (size_t)(VOX_CELLS + 1) * VOX_ROW;
-        // N candidates of one point: all centre reads first (entries past the list read centre 0 and are masked), then the tests
-        auto batch = [&](auto nc, const unsigned short* cj, const float4& q, unsigned* mrow, unsigned bit) __attribute__((always_inline)) {
-            constexpr int N = decltype(nc)::value;
-            float4 cc[N];
-#pragma unroll
-            for (int i = 0; i < N; i++) cc[i] = cen[cj[i] == VOX_SENT ? 0 : cj[i]];
-#pragma unroll
-            for (int i = 0; i < N; i++)
-                // (a branch per test: unconditional atomics with a zero operand -- straight-line code -- measured 55 % SLOWER: the
-                // LDS atomic of a full wavefront is what costs, not the branch around it)
-                if (cj[i] != VOX_SENT && sqdist3(cc[i].x, cc[i].y, cc[i].z, q.x, q.y, q.z) < voxel_r2) atomicOr(&mrow[cj[i]], bit);
-        };
-        for (int k0 = tid >> 3; k0 < npts; k0 += VOX_PP * (VOX_THREADS / 8)) {
-            float4 q[VOX_PP];
-            const unsigned short* row[VOX_PP];
-            unsigned short e[VOX_PP][3];
-            unsigned desc[VOX_PP];
-#pragma unroll
-            for (int u = 0; u < VOX_PP; u++) {
-                const int k = k0 + u * (VOX_THREADS / 8);
-                q[u] = pts[k < npts ? k : npts - 1];
-                const int ix = (int)floorf((q[u].x - lo) * inv_h), iy = (int)floorf((q[u].y - lo) * inv_h),
-                          iz = (int)floorf((q[u].z - lo) * inv_h);
-                const bool ok = k < npts && ix >= 0 && iy >= 0 && iz >= 0 && ix < VOX_GRID && iy < VOX_GRID && iz < VOX_GRID;
-                row[u] = tab + (size_t)(ok ? (ix * VOX_GRID + iy) * VOX_GRID + iz : VOX_CELLS) * VOX_ROW;   // else: the empty row
+        const float lim2 = tab_hdr[0];
+        for (int k = tid; k < W * 32; k += VOX_THREADS) {
+            const float4 q = pts[k < npts ? k : npts - 1];
+            const float qq = fmaf(q.z, q.z, fmaf(q.y, q.y, q.x * q.x));
+            const bool reach = k < npts && qq <= lim2;           // (NaN: unreachable, as in the reference's `d2 < r2`)
+            voxh8 v0 = { 0, 0, 0, 0, 0, 0, 0, 0 }, v1 = { 0, (_Float16)VOX_BIG, 0, (_Float16)1.f, (_Float16)0x1p-11f, (_Float16)0x1p-22f, 0, 0 };
+            if (reach) {
+                const _Float16 hx = (_Float16)q.x, hy = (_Float16)q.y, hz = (_Float16)q.z;
+                const _Float16 lx = (_Float16)((q.x - (float)hx) * 2048.f), ly = (_Float16)((q.y - (float)hy) * 2048.f),
+                               lz = (_Float16)((q.z - (float)hz) * 2048.f);
+                const _Float16 q0 = (_Float16)qq, q1 = (_Float16)((qq - (float)q0) * 2048.f);
+                v0 = voxh8{ hx, hy, hz, lx, ly, lz, hx, hy };
+                v1[0] = hz; v1[1] = q0; v1[2] = q1;
             }
-#pragma unroll
-            for (int u = 0; u < VOX_PP; u++) {
-#pragma unroll
-                for (int v = 0; v < 3; v++) e[u][v] = row[u][sub + 8 * v];
-                desc[u] = *reinterpret_cast<const unsigned*>(row[u] + VOX_ROW_N);
-            }
-#pragma unroll
-            for (int u = 0; u < VOX_PP; u++) {
-                const int k = k0 + u * (VOX_THREADS / 8);
-                batch(std::integral_constant<int, 3>{}, e[u], q[u], mask + (k >> 5) * VOX_THREADS, 1u << (k & 31));
-                if (sub == 0 && (desc[u] >> 21) != 0u) {
-                    const unsigned slot = atomicAdd(&nlong, 1u);
-                    longq[slot] = make_uint2((unsigned)k, desc[u]);
-                }
-            }
+            const int p = k & 31, row = ((p >> 2) & 3) * 8 + (p >> 4) * 4 + (p & 3);
+            pvec[((k >> 5) * 32 + row) * 2] = v0;
+            pvec[((k >> 5) * 32 + row) * 2 + 1] = v1;
         }
-        __syncthreads();
-        const int nq = (int)nlong;
-        for (int i0 = tid >> 3; i0 < nq; i0 += 2 * (VOX_THREADS / 8)) {
-            uint2 it[2];
-            float4 q[2];
-            unsigned short f[2][8];
+    }
+    __syncthreads();
+    // Phase 1b: wavefront w owns centre tiles w and w + 7 (B operands in registers), walks the point tiles and writes, per tile,
+    // the 16-bit mask piece of (centre = lane & 31, points 16 (lane >> 5) ..) -- every piece of every active centre is written,
+    // so the masks need no clearing.
+    {
+        const int wv = tid >> 6, lane = tid & 63, col = lane & 31, half = lane >> 5;
+        const float eps = tab_hdr[1];
+        const voxh8* __restrict__ ctab = reinterpret_cast<const voxh8*>(tab);
+        unsigned short* mask16 = reinterpret_cast<unsigned short*>(mask);
+        const voxf16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int j = 0; j < 2; j++) {
+            const int cen = (wv + 7 * j) * 32 + col;
+            if ((wv + 7 * j) * 32 >= ncentres) break;
+            const voxh8 B = ctab[cen * 2 + half];
+            for (int t = 0; t < W; t++) {
+                const voxh8 A = pvec[(t * 32 + col) * 2 + half];
+                const voxf16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, zero, 0, 0, 0);
+                unsigned piece = 0u;
+                float amin = 3.4e38f;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int i = i0 + u * (VOX_THREADS / 8);
-                it[u] = i < nq ? longq[i] : make_uint2(0u, 0u);           // (run of length 0: nothing to test)
-                q[u] = pts[it[u].x];
-            }
+                for (int i = 15; i >= 0; i--) piece = __builtin_amdgcn_alignbit(piece, __float_as_uint(D[i]), 31);   // (piece << 1) | sign
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int nov = (int)(it[u].y >> 21);
-                const unsigned short* run = ovf + (it[u].y & 0x1FFFFFu);
-#pragma unroll
-                for (int v = 0; v < 8; v++) {
-                    const int j = sub + 8 * v;
-                    const unsigned short x = *(j < nov ? run + j : tab);
-                    f[u][v] = j < nov ? x : (unsigned short)VOX_SENT;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int k = (int)it[u].x;
-                const unsigned bit = 1u << (k & 31);
-                unsigned* mrow = mask + (k >> 5) * VOX_THREADS;
-                batch(std::integral_constant<int, 8>{}, f[u], q[u], mrow, bit);
-                const int nov = (int)(it[u].y >> 21);
-                const unsigned short* run = ovf + (it[u].y & 0x1FFFFFu);
-                for (int j0 = 64; j0 < nov; j0 += 32) {                    // beyond 24 + 64 candidates: 3 % of the points
-                    unsigned short g[4];
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const int j = j0 + sub + 8 * v;
-                        const unsigned short x = run[min(j, nov - 1)];
-                        g[v] = j < nov ? x : (unsigned short)VOX_SENT;
+                for (int i = 0; i < 16; i += 2) amin = fminf(fminf(amin, fabsf(D[i])), fabsf(D[i + 1]));
+                if (amin < eps) {                                // too close to call from the split form: the reference's own test
+                    piece = 0u;
+                    if (cen < ncentres) {
+                        const float cx = centres[3 * cen], cy = centres[3 * cen + 1], cz = centres[3 * cen + 2];
+                        for (int i = 0; i < 16; i++) {
+                            const int k = t * 32 + half * 16 + i;
+                            if (k < npts) {
+                                const float4 q = pts[k];
+                                if (sqdist3(cx, cy, cz, q.x, q.y, q.z) < voxel_r2) piece |= 1u << i;
+                            }
+                        }
                     }
-                    batch(std::integral_constant<int, 4>{}, g, q[u], mrow, bit);
                 }
+                mask16[((t * VOX_THREADS + cen) << 1) + half] = (unsigned short)piece;
             }
         }
     }
@@ -277,64 +229,59 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
     VOX_STAMP_AT(4)
 }
 
-// Lookup grid over [-L, L]^3, L = max |centre coordinate| + r: cell -> the centres whose ball can reach the cell
-// (box-to-centre distance <= r plus a rounding margin), in centre order: the first 24 in the cell's row, the rest in a run of
-// the overflow array claimed from *counter (zeroed by the caller).  One wavefront per cell; block VOX_CELLS writes the empty row.
-__global__ void __launch_bounds__(WAVE) k_vox_table(const float* __restrict__ centres, int ncentres, float r,
-                                                    float* __restrict__ hdr, unsigned* __restrict__ counter,
-                                                    unsigned short* __restrict__ rows, unsigned short* __restrict__ ovf)
+// Centre side of the distance MFMA: ctab[VOX_THREADS][16] f16 (slots in the file header), hdr[0] = the squared reach
+// (max|c| + r)^2 with a margin -- a point beyond it hits no ball --, hdr[1] = eps, the |D| under which a lane falls back on the
+// reference's fp32 test.  Error of D against the exact d^2 - r^2, S = (max|c| + reach)^2 bounding every partial sum:
+// fp32 accumulation of 14 exact f16 products <= 14 * 2^-24 * S; the 22-bit forms of X and q 2 * 2^-23 * S/2; the dropped
+// lo * lo terms 2^-22 * S/2; |q|^2 in fp32 and as two pieces 4 * 2^-24 * S; the fp32 roundings of the reference's own sqdist3 at
+// d^2 ~ r^2 4 * 2^-24 * S at most: < 1.5e-6 * S in all.  eps = 1e-5 * max(S, 1).
+__global__ void __launch_bounds__(VOX_THREADS) k_vox_ctab(const float* __restrict__ centres, int ncentres, float r, float r2,
+                                                          float* __restrict__ hdr, unsigned short* __restrict__ ctab)
 {
-    const int cell = blockIdx.x, lane = threadIdx.x;
-    unsigned short* row = rows + (size_t)cell * VOX_ROW;
-    if (cell == VOX_CELLS) {
-        if (lane < VOX_ROW) row[lane] = lane < VOX_ROW_N ? (unsigned short)VOX_SENT : (unsigned short)0;
-        return;
+    __shared__ float smax[VOX_THREADS / WAVE];
+    const int c = threadIdx.x;
+    double x[3] = { 0.0, 0.0, 0.0 };
+    if (c < ncentres)
+        for (int a = 0; a < 3; a++) x[a] = (double)centres[3 * c + a];
+    const double cc = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    float m = (float)sqrt(cc) * 1.000001f;
+    for (int d = WAVE / 2; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+    if ((c & (WAVE - 1)) == 0) smax[c / WAVE] = m;
+    __syncthreads();
+    if (c == 0) {
+        float cmax = 0.f;
+        for (int i = 0; i < VOX_THREADS / WAVE; i++) cmax = fmaxf(cmax, smax[i]);
+        const float reach = (cmax + r) * 1.001f + 1e-3f;
+        const float S = (cmax + reach) * (cmax + reach);
+        hdr[0] = reach * reach; hdr[1] = 1e-5f * fmaxf(S, 1.f); hdr[2] = cmax; hdr[3] = 0.f;
     }
-    float L = 0.f;
-    for (int i = lane; i < 3 * ncentres; i += WAVE) L = fmaxf(L, fabsf(centres[i]));
-    for (int d = WAVE / 2; d > 0; d >>= 1) L = fmaxf(L, __shfl_xor(L, d, WAVE));
-    L += r;
-    const float h = 2.f * L / (float)VOX_GRID;
-    if (cell == 0 && lane == 0) { hdr[0] = -L; hdr[1] = 1.f / h; hdr[2] = h; hdr[3] = 0.f; }
-    const int ix = cell / (VOX_GRID * VOX_GRID), iy = (cell / VOX_GRID) % VOX_GRID, iz = cell % VOX_GRID;
-    const float bx = -L + ix * h, by = -L + iy * h, bz = -L + iz * h;
-    const float rr = r * 1.001f + 1e-3f * h;
-    auto reaches = [&](int c) {
-        if (c >= ncentres) return false;
-        const float cx = centres[3 * c], cy = centres[3 * c + 1], cz = centres[3 * c + 2];
-        const float dx = fmaxf(fmaxf(bx - cx, cx - (bx + h)), 0.f);
-        const float dy = fmaxf(fmaxf(by - cy, cy - (by + h)), 0.f);
-        const float dz = fmaxf(fmaxf(bz - cz, cz - (bz + h)), 0.f);
-        return dx * dx + dy * dy + dz * dz <= rr * rr;
-    };
-    int total = 0;
-    for (int c0 = 0; c0 < ncentres; c0 += WAVE) total += __popcll(__ballot(reaches(c0 + lane)));
-    const int nov = total > VOX_ROW_N ? total - VOX_ROW_N : 0;
-    unsigned start = 0;
-    if (nov > 0) {
-        if (lane == 0) start = atomicAdd(counter, (unsigned)nov);
-        start = __shfl(start, 0, WAVE);
-    }
-    int n = 0;
-    for (int c0 = 0; c0 < ncentres; c0 += WAVE) {
-        const int c = c0 + lane;
-        const bool in = reaches(c);
-        const unsigned long long m = __ballot(in);
-        if (in) {
-            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < VOX_ROW_N) row[pos] = (unsigned short)c;
-            else ovf[start + (unsigned)(pos - VOX_ROW_N)] = (unsigned short)c;
+    _Float16 v[VOX_K];
+    for (int i = 0; i < VOX_K; i++) v[i] = (_Float16)0.f;
+    v[9] = (_Float16)1.f; v[10] = (_Float16)0x1p-11f;
+    if (c < ncentres) {
+        for (int a = 0; a < 3; a++) {
+            const float X = (float)(-2.0 * x[a]);                               // exact
+            const _Float16 Xh = (_Float16)X;
+            const _Float16 Xl = (_Float16)((X - (float)Xh) * 2048.f);
+            v[a] = Xh;
+            v[3 + a] = (_Float16)((float)Xh * 0x1p-11f);
+            v[6 + a] = (_Float16)((float)Xl * 0x1p-11f);
         }
-        n += __popcll(m);
-    }
-    for (int i = n + lane; i < VOX_ROW_N; i += WAVE) row[i] = (unsigned short)VOX_SENT;
-    if (lane == 0) *reinterpret_cast<unsigned*>(row + VOX_ROW_N) = start | ((unsigned)nov << 21);
+        const double e = cc - (double)r2;
+        const _Float16 e0 = (_Float16)(float)e;
+        const double r1 = e - (double)(float)e0;
+        const _Float16 e1 = (_Float16)(float)(r1 * 2048.0);
+        const double r2_ = r1 - (double)(float)e1 * (1.0 / 2048.0);
+        const _Float16 e2 = (_Float16)(float)(r2_ * 4194304.0);
+        v[11] = e0; v[12] = e1; v[13] = e2;
+    } else v[11] = (_Float16)VOX_BIG;
+    for (int i = 0; i < VOX_K; i++) ctab[c * VOX_K + i] = __builtin_bit_cast(unsigned short, v[i]);
 }
 
 extern "C" size_t buf_patch_voxelize_ws_bytes(int ncentres)
 {
     if (ncentres <= 0) return 0;
-    return 256 + sizeof(unsigned short) * ((size_t)(VOX_CELLS + 1) * VOX_ROW + vox_overflow_capacity(ncentres));
+    return 256 + sizeof(unsigned short) * (size_t)VOX_THREADS * VOX_K;
 }
 
 extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int npatch, int npts, float des_r,
@@ -352,19 +299,17 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
                 BUF_EINVAL, "buf_patch_voxelize: null argument");
     BUF_REQUIRE(ws && ws_bytes >= buf_patch_voxelize_ws_bytes(ncentres), BUF_EWORKSPACE,
                 "buf_patch_voxelize: workspace of %zu bytes, need %zu", ws_bytes, buf_patch_voxelize_ws_bytes(ncentres));
-    BUF_REQUIRE(vox_overflow_capacity(ncentres) < (1u << 21), BUF_EINVAL, "buf_patch_voxelize: ncentres=%d (overflow runs are addressed with 21 bits)", ncentres);
     float* hdr = (float*)ws;
-    unsigned* counter = (unsigned*)((char*)ws + 64);
     unsigned short* tab = (unsigned short*)((char*)ws + 256);
-    BUF_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), (hipStream_t)stream));
-    k_vox_table<<<VOX_CELLS + 1, WAVE, 0, (hipStream_t)stream>>>(centres, ncentres, voxel_r, hdr, counter, tab, tab + (size_t)(VOX_CELLS + 1) * VOX_ROW);
+    k_vox_ctab<<<1, VOX_THREADS, 0, (hipStream_t)stream>>>(centres, ncentres, voxel_r, voxel_r * voxel_r, hdr, tab);
     BUF_LAUNCH_CHECK();
     VoxMlp M;   // host copies of the 16x3 MLP (HOST pointers: tiny, passed by value to the kernel)
     for (int ch = 0; ch < VOX_CH; ch++) {
         for (int j = 0; j < 3; j++) M.w[ch][j] = bn_scale[ch] * mlp_w[3 * ch + j];
         M.b[ch] = bn_scale[ch] * mlp_b[ch] + bn_shift[ch];
     }
-    const size_t lds = sizeof(float4) * (size_t)npts + sizeof(unsigned) * (size_t)((npts + 31) / 32) * VOX_THREADS;
+    const size_t W = (size_t)((npts + 31) / 32);
+    const size_t lds = sizeof(float4) * (size_t)npts + sizeof(unsigned) * W * VOX_THREADS + sizeof(_Float16) * VOX_K * 32 * W;
     static LdsGrant grant;
     if (lds > 48 * 1024)
         if (int rc = grant_dynamic_lds((const void*)k_patch_voxelize, lds, grant)) return rc;

@@ -183,6 +183,42 @@ def test_voxelize_other_shapes_vs_oracle(dev, npts, rad_n, azi_n, ele_n, nsample
         np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_voxelize_points_on_the_ball_surfaces(dev):
+    """k_patch_voxelize finds the hit masks with a split-f16 distance form on the matrix pipe and hands every pair it cannot call
+    (|d^2 - r^2| < eps) to the reference's own fp32 test.  Here EVERY point sits on the surface of some voxel ball, centre + r u
+    (1 + delta) with delta from 0 to +-1e-5, plus points beyond every ball's reach and non-finite ones: the sample lists (first
+    nsample hits in index order) must be the oracle's -- one flipped pair changes a sample, i.e. the output, far beyond 1e-4."""
+    import torch
+    from buffer_amd import ops
+    from buffer_amd.weights import load_weights
+    from oracle import torch_ref as T
+    W = load_weights("3dmatch")
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    rad_n, azi_n, ele_n, nsample, npts, P = 3, 20, 7, 10, 512, 48
+    g = torch.Generator(device='cpu').manual_seed(77)
+    centres = T.voxel_centres(rad_n, azi_n, ele_n)
+    r = 0.8 / rad_n
+    ci = torch.randint(0, centres.shape[0], (P, npts), generator=g)
+    u = torch.nn.functional.normalize(torch.randn((P, npts, 3), generator=g), dim=-1)
+    deltas = torch.tensor([0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 1e-5, -1e-5], dtype=torch.float64)
+    dl = deltas[torch.randint(0, len(deltas), (P, npts), generator=g)]
+    patches = (centres[ci].double() + r * u.double() * (1 + dl[..., None])).float()
+    patches[:, 7] = torch.tensor([3.0, -2.0, 1.5])                         # beyond the reach of every ball
+    patches[:, 9] = torch.tensor([1e30, 0.0, 0.0])
+    patches[:, -1] = 0                                                     # keypoint (origin) in the last slot
+    ang = -torch.arange(azi_n, dtype=torch.float64) * 2 * np.pi / azi_n
+    azi_cs = torch.stack([torch.cos(ang), torch.sin(ang)], 1).float()
+    s = Wt['Desc.pnt_layer.1.weight'] / torch.sqrt(Wt['Desc.pnt_layer.1.running_var'] + 1e-5)
+    t = Wt['Desc.pnt_layer.1.bias'] - Wt['Desc.pnt_layer.1.running_mean'] * s
+    x, R, ra, pn = ops.patch_voxelize(patches.to(dev), None, 1.0, centres.to(dev), azi_cs.to(dev), r, nsample,
+                                      W['Desc.pnt_layer.0.weight'].reshape(16, 3), W['Desc.pnt_layer.0.bias'], s.numpy(), t.numpy(),
+                                      azi_n, True)
+    assert torch.equal(pn.cpu(), patches)                                  # R = I, des_r = 1, keypoint at the origin
+    with torch.no_grad():
+        want = T.point_mlp_max(T.spt(patches, rad_n, azi_n, ele_n, 0.8, nsample), Wt).reshape(P, 16, -1)
+    np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("n", [0, 1, 3, 600])
 def test_fused_cnns_small_and_odd_batches(dev, n):
     """k_cyl_net / k_desc_head / k_cost_net with 0, 1, 3 and a non-round number of workgroups == library convolutions."""
