@@ -36,7 +36,24 @@ static_assert(VOX_MAXPTS <= 32 * 32, "the non-empty-word summary of a hit mask i
 #define VOX_BIG 30000.f       // D of a pair that cannot hit (unreachable point, lane past the last centre)
 
 typedef _Float16 voxh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 voxh4 __attribute__((ext_vector_type(4)));
+typedef _Float16 voxh2 __attribute__((ext_vector_type(2)));
 typedef float voxf16 __attribute__((ext_vector_type(16)));
+typedef float voxf4 __attribute__((ext_vector_type(4)));
+#define VOX_ATAB (VOX_THREADS * VOX_K)          // offset (f16 units) of the MLP operand table behind the centre table
+
+// (v0, v1) -> packed f16 pairs hi = f16(v), lo' = f16((v - hi) * 2048): v = hi + 2^-11 lo' to 22 bits (5 instructions)
+__device__ __forceinline__ void vox_split2(float v0, float v1, float k2048, unsigned& hi, unsigned& lo)
+{
+    voxh2 h;
+    h[0] = (_Float16)v0; h[1] = (_Float16)v1;
+    hi = __builtin_bit_cast(unsigned, h);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lo) : "v"(r0), "v"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lo) : "v"(r1), "v"(k2048));
+}
 
 struct VoxMlp {             // Conv2d1x1(3->16) with the eval-mode BatchNorm folded in: 64 scalars, SGPR-resident
     float w[VOX_CH][3];     // s * Desc.pnt_layer.0.weight,  s = gamma / sqrt(var + 1e-5)
@@ -50,51 +67,59 @@ __device__ long long* vox_stamp_ptr;      // development build (-DVOX_STAMP): s_
 #define VOX_STAMP_AT(SLOT)
 #endif
 
+// A9 (models/patch_embedder.py:131-147): per patch the rotation that takes the keypoint's axis onto e_z and rand_axis; one thread
+// per patch, ahead of k_patch_voxelize (inside it this was ~400 serial instructions on one lane in front of a barrier).
+__global__ void __launch_bounds__(256) k_patch_rotation(const float* __restrict__ axis, int npatch, float* __restrict__ out_R,
+                                                        float* __restrict__ out_rand)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npatch) return;
+    float R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    float rx = 1.f, ry = 0.f, rz = 0.f;                          // KITTI/ETH: rand_axis = e_x, R = I (:143-147)
+    if (axis) {
+        // RodsRotatFormula(z_axis, e_z) (utils/common.py:501-525), returned transposed
+        float ax = axis[3 * (size_t)p], ay = axis[3 * (size_t)p + 1], az = axis[3 * (size_t)p + 2];
+        float cx = ay, cy = -ax, cz = 0.f;                       // a x e_z
+        float na = sqrtf(ax * ax + ay * ay + az * az);
+        float cs = az / (fmaxf(na, 1e-8f) * 1.0f);               // cosine_similarity
+        cs = fminf(fmaxf(cs, -1.f), 1.f);
+        float th = acosf(cs);
+        float nc = fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-12f);   // F.normalize
+        cx /= nc; cy /= nc; cz /= nc;
+        rx = cx; ry = cy; rz = cz;                               // rand_axis = normalize(z_axis x e_z) (:138-141)
+        float K[9] = { 0, -cz, cy, cz, 0, -cx, -cy, cx, 0 };
+        float K2[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+        float sn = sinf(th), oc = 1.f - cosf(th);
+        float Rm[9];
+        for (int i = 0; i < 9; i++) Rm[i] = (i % 4 == 0 ? 1.f : 0.f) + sn * K[i] + oc * K2[i];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) R[3 * i + j] = Rm[3 * j + i];
+    }
+    for (int i = 0; i < 9; i++) out_R[9 * (size_t)p + i] = R[i];
+    out_rand[3 * (size_t)p] = rx; out_rand[3 * (size_t)p + 1] = ry; out_rand[3 * (size_t)p + 2] = rz;
+}
+
 __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __restrict__ patches, const float* __restrict__ axis,
                                                              int npts, float des_r, const float* __restrict__ centres,
                                                              int ncentres, int azi_n, const float* __restrict__ azi_cs,
                                                              float voxel_r2, int nsample, VoxMlp M,
                                                              const float* __restrict__ tab_hdr, const unsigned short* __restrict__ tab,
-                                                             float* __restrict__ out_x, float* __restrict__ out_R,
-                                                             float* __restrict__ out_rand, float* __restrict__ out_patches)
+                                                             float* __restrict__ out_x, const float* __restrict__ out_R,
+                                                             float* __restrict__ out_patches)
 {
     // dynamic LDS, sized by the launch (52 KB at 512 points -> three workgroups per CU; the hit lists never leave the registers):
     extern __shared__ float4 pts[];                              // [npts] aligned, normalised patch
     const int W = (npts + 31) >> 5;                              // mask words per centre = point tiles of 32
     unsigned* mask = reinterpret_cast<unsigned*>(pts + npts);    // [W][VOX_THREADS] hit bits
     voxh8* pvec = reinterpret_cast<voxh8*>(mask + (size_t)W * VOX_THREADS);   // [W][32 rows][2 halves]: point vectors, MFMA row order
-    __shared__ float Rs[9];
     const int p = blockIdx.x, tid = threadIdx.x;
     const float* src = patches + (size_t)p * npts * 3;
     VOX_STAMP_AT(0)
-    if (tid == 0) {
-        float R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
-        float rx = 1.f, ry = 0.f, rz = 0.f;                      // KITTI/ETH: rand_axis = e_x, R = I (:143-147)
-        if (axis) {
-            // RodsRotatFormula(z_axis, e_z) (utils/common.py:501-525), returned transposed
-            float ax = axis[3 * (size_t)p], ay = axis[3 * (size_t)p + 1], az = axis[3 * (size_t)p + 2];
-            float cx = ay, cy = -ax, cz = 0.f;                   // a x e_z
-            float na = sqrtf(ax * ax + ay * ay + az * az);
-            float cs = az / (fmaxf(na, 1e-8f) * 1.0f);           // cosine_similarity
-            cs = fminf(fmaxf(cs, -1.f), 1.f);
-            float th = acosf(cs);
-            float nc = fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-12f);   // F.normalize
-            cx /= nc; cy /= nc; cz /= nc;
-            rx = cx; ry = cy; rz = cz;                           // rand_axis = normalize(z_axis x e_z) (:138-141)
-            float K[9] = { 0, -cz, cy, cz, 0, -cx, -cy, cx, 0 };
-            float K2[9];
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
-            float sn = sinf(th), oc = 1.f - cosf(th);
-            float Rm[9];
-            for (int i = 0; i < 9; i++) Rm[i] = (i % 4 == 0 ? 1.f : 0.f) + sn * K[i] + oc * K2[i];
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) R[3 * i + j] = Rm[3 * j + i];
-        }
-        for (int i = 0; i < 9; i++) { Rs[i] = R[i]; out_R[9 * (size_t)p + i] = R[i]; }
-        out_rand[3 * (size_t)p] = rx; out_rand[3 * (size_t)p + 1] = ry; out_rand[3 * (size_t)p + 2] = rz;
-    }
-    __syncthreads();
+    float Rs[9];                                                 // k_patch_rotation's matrix: uniform loads
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rs[i] = out_R[9 * (size_t)p + i];
     // centre on the keypoint (= last slot, :124-125), rotate (delta @ R), divide by des_r (:168-171)
     float kx = src[3 * (size_t)(npts - 1)], ky = src[3 * (size_t)(npts - 1) + 1], kz = src[3 * (size_t)(npts - 1) + 2];
     for (int k = tid; k < npts; k += VOX_THREADS) {
@@ -155,36 +180,45 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
             const int cen = (wv + 7 * j) * 32 + col;
             if ((wv + 7 * j) * 32 >= ncentres) break;
             const voxh8 B = ctab[cen * 2 + half];
-            for (int t = 0; t < W; t++) {
-                const voxh8 A = pvec[(t * 32 + col) * 2 + half];
-                const voxf16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, zero, 0, 0, 0);
-                unsigned piece = 0u;
-                float amin = 3.4e38f;
+            const voxh8* arow = pvec + col * 2 + half;
+            unsigned short* mrow = mask16 + (cen << 1) + half;
+            for (int t0 = 0; t0 < W; t0 += 4) {
 #pragma unroll
-                for (int i = 15; i >= 0; i--) piece = __builtin_amdgcn_alignbit(piece, __float_as_uint(D[i]), 31);   // (piece << 1) | sign
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + u;
+                    if (t >= W) break;                           // (uniform)
+                    const voxh8 A = arow[t * 64];
+                    const voxf16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, zero, 0, 0, 0);
+                    unsigned piece = 0u;
+                    float amin = 3.4e38f;
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) amin = fminf(fminf(amin, fabsf(D[i])), fabsf(D[i + 1]));
-                if (amin < eps) {                                // too close to call from the split form: the reference's own test
-                    piece = 0u;
-                    if (cen < ncentres) {
-                        const float cx = centres[3 * cen], cy = centres[3 * cen + 1], cz = centres[3 * cen + 2];
-                        for (int i = 0; i < 16; i++) {
-                            const int k = t * 32 + half * 16 + i;
-                            if (k < npts) {
-                                const float4 q = pts[k];
-                                if (sqdist3(cx, cy, cz, q.x, q.y, q.z) < voxel_r2) piece |= 1u << i;
+                    for (int i = 15; i >= 0; i--) piece = __builtin_amdgcn_alignbit(piece, __float_as_uint(D[i]), 31);   // (piece << 1) | sign
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) amin = fminf(fminf(amin, fabsf(D[i])), fabsf(D[i + 1]));
+                    if (amin < eps) {                            // too close to call from the split form: the reference's own test
+                        piece = 0u;
+                        if (cen < ncentres) {
+                            const float cx = centres[3 * cen], cy = centres[3 * cen + 1], cz = centres[3 * cen + 2];
+                            for (int i = 0; i < 16; i++) {
+                                const int k = t * 32 + half * 16 + i;
+                                if (k < npts) {
+                                    const float4 q = pts[k];
+                                    if (sqdist3(cx, cy, cz, q.x, q.y, q.z) < voxel_r2) piece |= 1u << i;
+                                }
                             }
                         }
                     }
+                    mrow[t * (2 * VOX_THREADS)] = (unsigned short)piece;
                 }
-                mask16[((t * VOX_THREADS + cen) << 1) + half] = (unsigned short)piece;
             }
         }
     }
     __syncthreads();
     VOX_STAMP_AT(2)
     // Phases 2 + 3: every centre lane walks its hit mask in index order (= ball_query's "first nsample in index order") and
-    // feeds each hit straight through de-rotation -> 3->16 MLP -> BN -> ReLU -> running max; all lanes advance slot by slot.
+    // feeds each hit through de-rotation -> 3->16 MLP -> running max; all lanes advance two slots per step (one v_max3 takes
+    // both).  max_s relu(w.n_s + b) = relu(max_s(w.n_s) + b) (rounding is monotone), so the bias, BN shift and ReLU are applied
+    // once, after the walk: 3 multiply-adds and half a max per channel and sample.
     // `nz` = the mask words that hold a hit; a word is fetched from LDS only when the previous one is used up.
     int cnt = 0;                                                 // accepted samples (incl. a zeroed hit on point 0)
     bool zero_slot = false;
@@ -195,35 +229,64 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
     float acc[VOX_CH];
 #pragma unroll
     for (int ch = 0; ch < VOX_CH; ch++) acc[ch] = -3.4e38f;
-    for (int sidx = 0; sidx < nsample && __any(bits != 0u || nz != 0u); sidx++) {
+    auto next_hit = [&]() __attribute__((always_inline)) {        // index of the lane's next hit, -1: none left
         if (bits == 0u && nz != 0u) {
             wcur = __ffs(nz) - 1;
             nz &= nz - 1u;
             bits = mask[wcur * VOX_THREADS + tid];
         }
-        if (bits != 0u) {
-            const int k = wcur * 32 + __ffs(bits) - 1;
-            bits &= bits - 1u;
-            cnt++;
-            if (k != 0) {                                        // utils/common.py:447-449: a hit on point 0 is zeroed
-                const float4 q = pts[k];
-                const float nx = q.x * ca - q.y * sa, ny = q.x * sa + q.y * ca, nz_ = q.z;
+        if (bits == 0u) return -1;
+        const int k = wcur * 32 + __ffs(bits) - 1;
+        bits &= bits - 1u;
+        cnt++;
+        zero_slot = zero_slot || k == 0;                         // utils/common.py:447-449: a hit on point 0 is zeroed
+        return k;
+    };
+    // The 3->16 MLP of both samples on the matrix pipe: v_mfma_f32_4x4x4_16B_f16 is 16 independent 4x4x4 products, lane l =
+    // column l % 4 of block l / 4 -- its OWN sample as B, 4 channels of that sample as D, and row l % 4 of the weights as A.
+    // Split-f16 again (fp32-equivalent): w.n = Wh.nh + (2^-11 Wh).nl' + (2^-11 Wl').nh, three chained products per 4 channels.
+    voxh4 Aw[4][3];                                              // [channel group][Wh | 2^-11 Wh | 2^-11 Wl'], row = lane % 4
+    {
+        const voxh4* __restrict__ atab = reinterpret_cast<const voxh4*>(tab + VOX_ATAB);
 #pragma unroll
-                for (int ch = 0; ch < VOX_CH; ch++) {
-                    const float h = fmaf(M.w[ch][2], nz_, fmaf(M.w[ch][1], ny, fmaf(M.w[ch][0], nx, M.b[ch])));
-                    acc[ch] = fmaxf(fmaxf(acc[ch], h), 0.f);     // v_max3: ReLU and the running max
-                }
-            } else zero_slot = true;
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int v = 0; v < 3; v++) Aw[j][v] = atab[(j * 3 + v) * 4 + (tid & 3)];
+    }
+    const voxf4 zero4 = { 0.f, 0.f, 0.f, 0.f };
+    for (int sidx = 0; sidx < nsample && __any(bits != 0u || nz != 0u); sidx += 2) {
+        const int ka = next_hit();
+        const int kb = sidx + 1 < nsample ? next_hit() : -1;
+        // a lone hit stands in for its missing partner; a lane with neither (out of hits, or a hit on point 0) takes the keypoint
+        // in the last slot, which is the origin: w.0 = 0 is the value its zero-padded slots contribute anyway
+        const bool va = ka > 0, vb = kb > 0;
+        const float4 qa = pts[va ? ka : (vb ? kb : npts - 1)], qb = pts[vb ? kb : (va ? ka : npts - 1)];
+        unsigned ah[2], al[2], bh[2], bl[2];
+        vox_split2(qa.x * ca - qa.y * sa, qa.x * sa + qa.y * ca, 2048.f, ah[0], al[0]);
+        vox_split2(qa.z, 0.f, 2048.f, ah[1], al[1]);
+        vox_split2(qb.x * ca - qb.y * sa, qb.x * sa + qb.y * ca, 2048.f, bh[0], bl[0]);
+        vox_split2(qb.z, 0.f, 2048.f, bh[1], bl[1]);
+        const voxh4 Ah = __builtin_bit_cast(voxh4, make_uint2(ah[0], ah[1])), Al = __builtin_bit_cast(voxh4, make_uint2(al[0], al[1]));
+        const voxh4 Bh = __builtin_bit_cast(voxh4, make_uint2(bh[0], bh[1])), Bl = __builtin_bit_cast(voxh4, make_uint2(bl[0], bl[1]));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            voxf4 da = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][2], Ah, zero4, 0, 0, 0);
+            voxf4 db = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][2], Bh, zero4, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][1], Al, da, 0, 0, 0);
+            db = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][1], Bl, db, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][0], Ah, da, 0, 0, 0);
+            db = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][0], Bh, db, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[4 * j + r] = fmaxf(fmaxf(acc[4 * j + r], da[r]), db[r]);
         }
     }
     VOX_STAMP_AT(3)
     if (active) {
-        bool padded = cnt < nsample || zero_slot;                // zeroed slots go through the MLP as the origin
+        const bool padded = cnt < nsample || zero_slot;          // zeroed slots go through the MLP as the origin: w.0 = 0
 #pragma unroll
         for (int ch = 0; ch < VOX_CH; ch++) {
-            float v = acc[ch];
-            if (padded) v = fmaxf(v, fmaxf(M.b[ch], 0.f));
-            out_x[((size_t)p * VOX_CH + ch) * ncentres + c] = v;
+            const float v = padded ? fmaxf(acc[ch], 0.f) : acc[ch];
+            out_x[((size_t)p * VOX_CH + ch) * ncentres + c] = fmaxf(v + M.b[ch], 0.f);
         }
     }
     VOX_STAMP_AT(4)
@@ -235,8 +298,9 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
 // fp32 accumulation of 14 exact f16 products <= 14 * 2^-24 * S; the 22-bit forms of X and q 2 * 2^-23 * S/2; the dropped
 // lo * lo terms 2^-22 * S/2; |q|^2 in fp32 and as two pieces 4 * 2^-24 * S; the fp32 roundings of the reference's own sqdist3 at
 // d^2 ~ r^2 4 * 2^-24 * S at most: < 1.5e-6 * S in all.  eps = 1e-5 * max(S, 1).
+// Behind it the MLP operand table of phases 2+3: atab[channel group 4][Wh | 2^-11 Wh | 2^-11 Wl'][row 4][x, y, z, 0] f16.
 __global__ void __launch_bounds__(VOX_THREADS) k_vox_ctab(const float* __restrict__ centres, int ncentres, float r, float r2,
-                                                          float* __restrict__ hdr, unsigned short* __restrict__ ctab)
+                                                          VoxMlp M, float* __restrict__ hdr, unsigned short* __restrict__ ctab)
 {
     __shared__ float smax[VOX_THREADS / WAVE];
     const int c = threadIdx.x;
@@ -276,12 +340,24 @@ __global__ void __launch_bounds__(VOX_THREADS) k_vox_ctab(const float* __restric
         v[11] = e0; v[12] = e1; v[13] = e2;
     } else v[11] = (_Float16)VOX_BIG;
     for (int i = 0; i < VOX_K; i++) ctab[c * VOX_K + i] = __builtin_bit_cast(unsigned short, v[i]);
+    if (c < VOX_CH * 3) {
+        const int ch = c / 3, a = c % 3;
+        const float w = M.w[ch][a];
+        const _Float16 wh = (_Float16)w;
+        const _Float16 wl = (_Float16)((w - (float)wh) * 2048.f);
+        const _Float16 o[3] = { wh, (_Float16)((float)wh * 0x1p-11f), (_Float16)((float)wl * 0x1p-11f) };
+        for (int t = 0; t < 3; t++) {
+            unsigned short* row = ctab + VOX_ATAB + (((ch >> 2) * 3 + t) * 4 + (ch & 3)) * 4;
+            row[a] = __builtin_bit_cast(unsigned short, o[t]);
+            if (a == 0) row[3] = 0;
+        }
+    }
 }
 
 extern "C" size_t buf_patch_voxelize_ws_bytes(int ncentres)
 {
     if (ncentres <= 0) return 0;
-    return 256 + sizeof(unsigned short) * (size_t)VOX_THREADS * VOX_K;
+    return 256 + sizeof(unsigned short) * ((size_t)VOX_THREADS * VOX_K + 4 * 3 * 4 * 4);
 }
 
 extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int npatch, int npts, float des_r,
@@ -301,13 +377,14 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
                 "buf_patch_voxelize: workspace of %zu bytes, need %zu", ws_bytes, buf_patch_voxelize_ws_bytes(ncentres));
     float* hdr = (float*)ws;
     unsigned short* tab = (unsigned short*)((char*)ws + 256);
-    k_vox_ctab<<<1, VOX_THREADS, 0, (hipStream_t)stream>>>(centres, ncentres, voxel_r, voxel_r * voxel_r, hdr, tab);
-    BUF_LAUNCH_CHECK();
-    VoxMlp M;   // host copies of the 16x3 MLP (HOST pointers: tiny, passed by value to the kernel)
+    VoxMlp M;   // host copies of the 16x3 MLP (HOST pointers: tiny, passed by value to the kernels)
     for (int ch = 0; ch < VOX_CH; ch++) {
         for (int j = 0; j < 3; j++) M.w[ch][j] = bn_scale[ch] * mlp_w[3 * ch + j];
         M.b[ch] = bn_scale[ch] * mlp_b[ch] + bn_shift[ch];
     }
+    k_vox_ctab<<<1, VOX_THREADS, 0, (hipStream_t)stream>>>(centres, ncentres, voxel_r, voxel_r * voxel_r, M, hdr, tab);
+    k_patch_rotation<<<(npatch + 255) / 256, 256, 0, (hipStream_t)stream>>>(axis, npatch, out_R, out_rand);
+    BUF_LAUNCH_CHECK();
     const size_t W = (size_t)((npts + 31) / 32);
     const size_t lds = sizeof(float4) * (size_t)npts + sizeof(unsigned) * W * VOX_THREADS + sizeof(_Float16) * VOX_K * 32 * W;
     static LdsGrant grant;
@@ -322,7 +399,7 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
 #endif
     k_patch_voxelize<<<npatch, VOX_THREADS, lds, (hipStream_t)stream>>>(patches, axis, npts, des_r, centres, ncentres, azi_n,
                                                                       azi_cs, voxel_r * voxel_r, nsample, M, hdr, tab, out_x,
-                                                                      out_R, out_rand, out_patches);
+                                                                      out_R, out_patches);
     if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
 #ifdef VOX_STAMP

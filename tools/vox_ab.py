@@ -72,7 +72,7 @@ def cmp(a, b):
     for k in A.files:
         same = np.array_equal(A[k].view(np.uint32), B[k].view(np.uint32))
         nd = int((A[k].view(np.uint32) != B[k].view(np.uint32)).sum())
-        print(f'{k}: {A[k].shape} bitwise equal: {same} ({nd} differing values)')
+        print(f'{k}: {A[k].shape} bitwise equal: {same} ({nd} differing values, max |diff| {np.abs(A[k] - B[k]).max():.3g})')
         bad += nd
     sys.exit(1 if bad else 0)
 
