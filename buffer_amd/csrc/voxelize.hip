@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
                     for (int i = 15; i >= 0; i--) piece = __builtin_amdgcn_alignbit(piece, __float_as_uint(D[i]), 31);   // (piece << 1) | sign
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) amin = fminf(fminf(amin, fabsf(D[i])), fabsf(D[i + 1]));
-                    if (amin < eps) {                            // too close to call from the split form: the reference's own test
+                    if (!(amin >= eps)) {                        // too close to call from the split form: the reference's own test
                         piece = 0u;
                         if (cen < ncentres) {
                             const float cx = centres[3 * cen], cy = centres[3 * cen + 1], cz = centres[3 * cen + 2];
@@ -317,7 +317,8 @@ __global__ void __launch_bounds__(VOX_THREADS) k_vox_ctab(const float* __restric
         for (int i = 0; i < VOX_THREADS / WAVE; i++) cmax = fmaxf(cmax, smax[i]);
         const float reach = (cmax + r) * 1.001f + 1e-3f;
         const float S = (cmax + reach) * (cmax + reach);
-        hdr[0] = reach * reach; hdr[1] = 1e-5f * fmaxf(S, 1.f); hdr[2] = cmax; hdr[3] = 0.f;
+        // centre sets too large for the f16 pieces (|c|^2 - r^2 must stay far below 65504): eps = +inf sends EVERY lane to the fp32 test
+        hdr[0] = reach * reach; hdr[1] = cmax <= 64.f ? 1e-5f * fmaxf(S, 1.f) : __builtin_inff(); hdr[2] = cmax; hdr[3] = 0.f;
     }
     _Float16 v[VOX_K];
     for (int i = 0; i < VOX_K; i++) v[i] = (_Float16)0.f;

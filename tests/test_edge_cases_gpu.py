@@ -219,6 +219,37 @@ def test_voxelize_points_on_the_ball_surfaces(dev):
     np.testing.assert_allclose(x.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_voxelize_scaled_geometry(dev):
+    """The same patches at 128 x the scale (centres, voxel radius and patch radius scaled by the power of two, MLP weights by its
+    inverse: every fp32 distance and product scales exactly) give the same output.  At that scale the voxel grid is past what the
+    split-f16 distance form of k_patch_voxelize may represent (max |c| > 64), so every pair takes the fp32 test."""
+    import torch
+    from buffer_amd import ops
+    from buffer_amd.weights import load_weights
+    from oracle import torch_ref as T
+    W = load_weights("3dmatch")
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    g = torch.Generator(device='cpu').manual_seed(5)
+    P, npts = 40, 512
+    u = torch.nn.functional.normalize(torch.randn((P, npts, 3), generator=g), dim=-1) * torch.rand((P, npts, 1), generator=g).sqrt() * 0.3
+    u[:, -1] = 0
+    patches = u + torch.tensor([0.5, -1.0, 2.0])
+    axis = torch.nn.functional.normalize(torch.randn((P, 3), generator=g), dim=1)
+    centres = T.voxel_centres(3, 20, 7)
+    ang = -torch.arange(20, dtype=torch.float64) * 2 * np.pi / 20
+    azi_cs = torch.stack([torch.cos(ang), torch.sin(ang)], 1).float()
+    s = Wt['Desc.pnt_layer.1.weight'] / torch.sqrt(Wt['Desc.pnt_layer.1.running_var'] + 1e-5)
+    t = Wt['Desc.pnt_layer.1.bias'] - Wt['Desc.pnt_layer.1.running_mean'] * s
+    w0 = W['Desc.pnt_layer.0.weight'].reshape(16, 3)
+    out = []
+    for k in (1.0, 128.0):
+        x, R, ra, pn = ops.patch_voxelize(patches.to(dev), axis.to(dev), 0.3 / k, (centres * k).to(dev), azi_cs.to(dev), k * 0.8 / 3, 10,
+                                          w0 / k, W['Desc.pnt_layer.0.bias'], s.numpy(), t.numpy(), 20, True)
+        out.append((x.cpu().numpy(), pn.cpu().numpy() / k))
+    assert np.array_equal(out[0][1], out[1][1])
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-5, atol=1e-5)     # (the f16 pieces of w / 128 round differently; a flipped hit shows at 1e-3 and up)
+
+
 @pytest.mark.parametrize("n", [0, 1, 3, 600])
 def test_fused_cnns_small_and_odd_batches(dev, n):
     """k_cyl_net / k_desc_head / k_cost_net with 0, 1, 3 and a non-round number of workgroups == library convolutions."""
