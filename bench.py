@@ -43,6 +43,8 @@ CYL_NET_EXECUTED_FRACTION = 40 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs
 #                                          9 x 140 x 4 x 16 MACs of the direct form = 0.508 of the dense count
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_16x16x32_f16), ~2.5 PFLOP/s
+VALU_ISSUE_PEAK_GINSTR = 256 * 4 * 2.4 / 4          # G wave-instructions/s: 1024 SIMDs, one 64-lane VALU instruction per 4 cycles, 2.4 GHz
+VOX_VALU_INSTR_PER_PATCH = 15320                     # SQ_INSTS_VALU per patch of k_patch_voxelize (512 points, 420 voxels, 10 samples)
 CYL_NET_DENSE_FLOPS_PER_PATCH = 118702080.0       # 2 x 140 x sum 9 Cin Cout
 # csrc/convnet_h3.hip issues 3 v_mfma_f32_16x16x32_f16 (16384 flops each) per (16 outputs, 16 positions, 32 channels): 9 position
 # tiles for the 140 positions, layer 0's 48 channels as two k-steps: 22842 matrix instructions per patch
@@ -150,6 +152,22 @@ def roof_entry(timed, name, label, bound, peak, unit, scale, traffic=None, **ext
     return e
 
 
+def voxelize_entry(timed, traffic, patches):
+    """k_patch_voxelize is vector-ALU issue bound (SQ counters, profiles/r04_voxelize_sq.txt: the vector ALUs are busy 88 % of the
+    kernel's cycles): achieved = wave-level VALU instructions per second (the measured count per patch x this launch's patches /
+    HIP-event time), peak = 1024 SIMDs x one wave instruction per 4 cycles at 2.4 GHz.  The byte rate rides along."""
+    e = roof_entry(timed, 'patch_voxelize', 'k_patch_voxelize (A9 + A10 + point MLP)', 'valu', HBM_PEAK_GBS, 'GB/s', 1e9, traffic)
+    if not e or not patches:
+        return e
+    e['hbm_gbps'], e['hbm_frac'] = e['achieved'], e['frac']
+    e['valu_wave_instructions_per_patch'] = VOX_VALU_INSTR_PER_PATCH
+    e['achieved'] = VOX_VALU_INSTR_PER_PATCH * patches / (e['avg_us'] * 1e-6) / 1e9
+    e['peak'], e['unit'] = VALU_ISSUE_PEAK_GINSTR, 'G wave-instructions/s'
+    e['frac'] = e['achieved'] / e['peak']
+    e['source'] = 'SQ_INSTS_VALU / patches of tools/vox_pmc.sh (profiles/r04_voxelize_sq.txt)'
+    return e
+
+
 def traffic_of(pmc, kernel, units):
     """HBM bytes per launch from the committed PMC summary (profiles/traffic.json: bytes per unit of work, measured with
     separate --pmc FETCH_SIZE / WRITE_SIZE passes and the gfx950 FETCH correction) x the units of this run's launch."""
@@ -188,9 +206,7 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
                    traffic_of(pmc, 'k_vn_gather', units.get('pairs'))),
         roof_entry(timed, 'select_patches', 'k_select_patches_grid (A8 ball query + grouping)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_select_patches_grid', units.get('patches_per_select'))),
-        # VALU / LDS-atomic bound, not HBM bound: the byte rate is reported for reference only
-        roof_entry(timed, 'patch_voxelize', 'k_patch_voxelize (A9 + A10 + point MLP)', 'valu', HBM_PEAK_GBS, 'GB/s', 1e9,
-                   traffic_of(pmc, 'k_patch_voxelize', units.get('patches'))),
+        voxelize_entry(timed, traffic_of(pmc, 'k_patch_voxelize', units.get('patches')), units.get('patches')),
         roof_entry(timed, 'desc_head', 'k_desc_head (A11 attention pooling + normalisation)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_desc_head', units.get('patches'))),
         roof_entry(timed, 'nn1', 'k_nn1 (A12 mutual 1-NN, exact fp32 VALU)', 'valu', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12),
