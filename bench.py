@@ -44,7 +44,7 @@ CYL_NET_EXECUTED_FRACTION = 40 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_16x16x32_f16), ~2.5 PFLOP/s
 VALU_ISSUE_PEAK_GINSTR = 256 * 4 * 2.4 / 4          # G wave-instructions/s: 1024 SIMDs, one 64-lane VALU instruction per 4 cycles, 2.4 GHz
-VOX_VALU_INSTR_PER_PATCH = 15320                     # SQ_INSTS_VALU per patch of k_patch_voxelize (512 points, 420 voxels, 10 samples)
+VOX_VALU_INSTR_PER_PATCH = 17250                     # SQ_INSTS_VALU per patch of k_patch_voxelize (512 points, 420 voxels, 10 samples)
 CYL_NET_DENSE_FLOPS_PER_PATCH = 118702080.0       # 2 x 140 x sum 9 Cin Cout
 # csrc/convnet_h3.hip issues 3 v_mfma_f32_16x16x32_f16 (16384 flops each) per (16 outputs, 16 positions, 32 channels): 9 position
 # tiles for the 140 positions, layer 0's 48 channels as two k-steps: 22842 matrix instructions per patch
@@ -153,7 +153,7 @@ def roof_entry(timed, name, label, bound, peak, unit, scale, traffic=None, **ext
 
 
 def voxelize_entry(timed, traffic, patches):
-    """k_patch_voxelize is vector-ALU issue bound (SQ counters, profiles/r04_voxelize_sq.txt: the vector ALUs are busy 88 % of the
+    """k_patch_voxelize is vector-ALU issue bound (SQ counters, profiles/r04_voxelize_sq.txt: the vector ALUs are busy 94 % of the
     kernel's cycles): achieved = wave-level VALU instructions per second (the measured count per patch x this launch's patches /
     HIP-event time), peak = 1024 SIMDs x one wave instruction per 4 cycles at 2.4 GHz.  The byte rate rides along."""
     e = roof_entry(timed, 'patch_voxelize', 'k_patch_voxelize (A9 + A10 + point MLP)', 'valu', HBM_PEAK_GBS, 'GB/s', 1e9, traffic)

@@ -36,24 +36,7 @@ static_assert(VOX_MAXPTS <= 32 * 32, "the non-empty-word summary of a hit mask i
 #define VOX_BIG 30000.f       // D of a pair that cannot hit (unreachable point, lane past the last centre)
 
 typedef _Float16 voxh8 __attribute__((ext_vector_type(8)));
-typedef _Float16 voxh4 __attribute__((ext_vector_type(4)));
-typedef _Float16 voxh2 __attribute__((ext_vector_type(2)));
 typedef float voxf16 __attribute__((ext_vector_type(16)));
-typedef float voxf4 __attribute__((ext_vector_type(4)));
-#define VOX_ATAB (VOX_THREADS * VOX_K)          // offset (f16 units) of the MLP operand table behind the centre table
-
-// (v0, v1) -> packed f16 pairs hi = f16(v), lo' = f16((v - hi) * 2048): v = hi + 2^-11 lo' to 22 bits (5 instructions)
-__device__ __forceinline__ void vox_split2(float v0, float v1, float k2048, unsigned& hi, unsigned& lo)
-{
-    voxh2 h;
-    h[0] = (_Float16)v0; h[1] = (_Float16)v1;
-    hi = __builtin_bit_cast(unsigned, h);
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(v0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(v1));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lo) : "v"(r0), "v"(k2048));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lo) : "v"(r1), "v"(k2048));
-}
 
 struct VoxMlp {             // Conv2d1x1(3->16) with the eval-mode BatchNorm folded in: 64 scalars, SGPR-resident
     float w[VOX_CH][3];     // s * Desc.pnt_layer.0.weight,  s = gamma / sqrt(var + 1e-5)
@@ -182,35 +165,40 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
             const voxh8 B = ctab[cen * 2 + half];
             const voxh8* arow = pvec + col * 2 + half;
             unsigned short* mrow = mask16 + (cen << 1) + half;
-            for (int t0 = 0; t0 < W; t0 += 4) {
+            const float cx = cen < ncentres ? centres[3 * cen] : 0.f, cy = cen < ncentres ? centres[3 * cen + 1] : 0.f,
+                        cz = cen < ncentres ? centres[3 * cen + 2] : 0.f;
+            auto tile = [&](const voxh8* a, unsigned short* m, int t) __attribute__((always_inline)) {
+                const voxf16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(*a, B, zero, 0, 0, 0);
+                unsigned piece = 0u;
+                float amin = 3.4e38f;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int t = t0 + u;
-                    if (t >= W) break;                           // (uniform)
-                    const voxh8 A = arow[t * 64];
-                    const voxf16 D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, zero, 0, 0, 0);
-                    unsigned piece = 0u;
-                    float amin = 3.4e38f;
+                for (int i = 15; i >= 0; i--) piece = __builtin_amdgcn_alignbit(piece, __float_as_uint(D[i]), 31);   // (piece << 1) | sign
 #pragma unroll
-                    for (int i = 15; i >= 0; i--) piece = __builtin_amdgcn_alignbit(piece, __float_as_uint(D[i]), 31);   // (piece << 1) | sign
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) amin = fminf(fminf(amin, fabsf(D[i])), fabsf(D[i + 1]));
-                    if (!(amin >= eps)) {                        // too close to call from the split form: the reference's own test
-                        piece = 0u;
-                        if (cen < ncentres) {
-                            const float cx = centres[3 * cen], cy = centres[3 * cen + 1], cz = centres[3 * cen + 2];
-                            for (int i = 0; i < 16; i++) {
-                                const int k = t * 32 + half * 16 + i;
-                                if (k < npts) {
-                                    const float4 q = pts[k];
-                                    if (sqdist3(cx, cy, cz, q.x, q.y, q.z) < voxel_r2) piece |= 1u << i;
-                                }
+                for (int i = 0; i < 16; i += 2) amin = fminf(fminf(amin, fabsf(D[i])), fabsf(D[i + 1]));
+                if (!(amin >= eps)) {                            // too close to call from the split form: the reference's own test
+                    unsigned fix = 0u;
+                    if (cen < ncentres) {
+#pragma unroll 1
+                        for (int i = 0; i < 16; i++) {
+                            const int k = t * 32 + half * 16 + i;
+                            if (k < npts) {
+                                const float4 q = pts[k];
+                                if (sqdist3(cx, cy, cz, q.x, q.y, q.z) < voxel_r2) fix |= 1u << i;
                             }
                         }
                     }
-                    mrow[t * (2 * VOX_THREADS)] = (unsigned short)piece;
+                    piece = fix;
                 }
+                *m = (unsigned short)piece;
+            };
+            int t0 = 0;
+            for (; t0 + 4 <= W; t0 += 4) {                       // groups of four tiles: constant offsets from one address pair
+                const voxh8* a4 = arow + t0 * 64;
+                unsigned short* m4 = mrow + t0 * (2 * VOX_THREADS);
+#pragma unroll
+                for (int u = 0; u < 4; u++) tile(a4 + u * 64, m4 + u * (2 * VOX_THREADS), t0 + u);
             }
+            for (; t0 < W; t0++) tile(arow + t0 * 64, mrow + t0 * (2 * VOX_THREADS), t0);
         }
     }
     __syncthreads();
@@ -242,18 +230,6 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
         zero_slot = zero_slot || k == 0;                         // utils/common.py:447-449: a hit on point 0 is zeroed
         return k;
     };
-    // The 3->16 MLP of both samples on the matrix pipe: v_mfma_f32_4x4x4_16B_f16 is 16 independent 4x4x4 products, lane l =
-    // column l % 4 of block l / 4 -- its OWN sample as B, 4 channels of that sample as D, and row l % 4 of the weights as A.
-    // Split-f16 again (fp32-equivalent): w.n = Wh.nh + (2^-11 Wh).nl' + (2^-11 Wl').nh, three chained products per 4 channels.
-    voxh4 Aw[4][3];                                              // [channel group][Wh | 2^-11 Wh | 2^-11 Wl'], row = lane % 4
-    {
-        const voxh4* __restrict__ atab = reinterpret_cast<const voxh4*>(tab + VOX_ATAB);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int v = 0; v < 3; v++) Aw[j][v] = atab[(j * 3 + v) * 4 + (tid & 3)];
-    }
-    const voxf4 zero4 = { 0.f, 0.f, 0.f, 0.f };
     for (int sidx = 0; sidx < nsample && __any(bits != 0u || nz != 0u); sidx += 2) {
         const int ka = next_hit();
         const int kb = sidx + 1 < nsample ? next_hit() : -1;
@@ -261,23 +237,13 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
         // in the last slot, which is the origin: w.0 = 0 is the value its zero-padded slots contribute anyway
         const bool va = ka > 0, vb = kb > 0;
         const float4 qa = pts[va ? ka : (vb ? kb : npts - 1)], qb = pts[vb ? kb : (va ? ka : npts - 1)];
-        unsigned ah[2], al[2], bh[2], bl[2];
-        vox_split2(qa.x * ca - qa.y * sa, qa.x * sa + qa.y * ca, 2048.f, ah[0], al[0]);
-        vox_split2(qa.z, 0.f, 2048.f, ah[1], al[1]);
-        vox_split2(qb.x * ca - qb.y * sa, qb.x * sa + qb.y * ca, 2048.f, bh[0], bl[0]);
-        vox_split2(qb.z, 0.f, 2048.f, bh[1], bl[1]);
-        const voxh4 Ah = __builtin_bit_cast(voxh4, make_uint2(ah[0], ah[1])), Al = __builtin_bit_cast(voxh4, make_uint2(al[0], al[1]));
-        const voxh4 Bh = __builtin_bit_cast(voxh4, make_uint2(bh[0], bh[1])), Bl = __builtin_bit_cast(voxh4, make_uint2(bl[0], bl[1]));
+        const float ax = qa.x * ca - qa.y * sa, ay = qa.x * sa + qa.y * ca, az = qa.z;
+        const float bx = qb.x * ca - qb.y * sa, by = qb.x * sa + qb.y * ca, bz = qb.z;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            voxf4 da = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][2], Ah, zero4, 0, 0, 0);
-            voxf4 db = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][2], Bh, zero4, 0, 0, 0);
-            da = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][1], Al, da, 0, 0, 0);
-            db = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][1], Bl, db, 0, 0, 0);
-            da = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][0], Ah, da, 0, 0, 0);
-            db = __builtin_amdgcn_mfma_f32_4x4x4f16(Aw[j][0], Bh, db, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[4 * j + r] = fmaxf(fmaxf(acc[4 * j + r], da[r]), db[r]);
+        for (int ch = 0; ch < VOX_CH; ch++) {
+            const float ha = fmaf(M.w[ch][2], az, fmaf(M.w[ch][1], ay, M.w[ch][0] * ax));
+            const float hb = fmaf(M.w[ch][2], bz, fmaf(M.w[ch][1], by, M.w[ch][0] * bx));
+            acc[ch] = fmaxf(fmaxf(acc[ch], ha), hb);
         }
     }
     VOX_STAMP_AT(3)
@@ -298,9 +264,8 @@ __global__ void __launch_bounds__(VOX_THREADS) k_patch_voxelize(const float* __r
 // fp32 accumulation of 14 exact f16 products <= 14 * 2^-24 * S; the 22-bit forms of X and q 2 * 2^-23 * S/2; the dropped
 // lo * lo terms 2^-22 * S/2; |q|^2 in fp32 and as two pieces 4 * 2^-24 * S; the fp32 roundings of the reference's own sqdist3 at
 // d^2 ~ r^2 4 * 2^-24 * S at most: < 1.5e-6 * S in all.  eps = 1e-5 * max(S, 1).
-// Behind it the MLP operand table of phases 2+3: atab[channel group 4][Wh | 2^-11 Wh | 2^-11 Wl'][row 4][x, y, z, 0] f16.
 __global__ void __launch_bounds__(VOX_THREADS) k_vox_ctab(const float* __restrict__ centres, int ncentres, float r, float r2,
-                                                          VoxMlp M, float* __restrict__ hdr, unsigned short* __restrict__ ctab)
+                                                          float* __restrict__ hdr, unsigned short* __restrict__ ctab)
 {
     __shared__ float smax[VOX_THREADS / WAVE];
     const int c = threadIdx.x;
@@ -341,24 +306,12 @@ __global__ void __launch_bounds__(VOX_THREADS) k_vox_ctab(const float* __restric
         v[11] = e0; v[12] = e1; v[13] = e2;
     } else v[11] = (_Float16)VOX_BIG;
     for (int i = 0; i < VOX_K; i++) ctab[c * VOX_K + i] = __builtin_bit_cast(unsigned short, v[i]);
-    if (c < VOX_CH * 3) {
-        const int ch = c / 3, a = c % 3;
-        const float w = M.w[ch][a];
-        const _Float16 wh = (_Float16)w;
-        const _Float16 wl = (_Float16)((w - (float)wh) * 2048.f);
-        const _Float16 o[3] = { wh, (_Float16)((float)wh * 0x1p-11f), (_Float16)((float)wl * 0x1p-11f) };
-        for (int t = 0; t < 3; t++) {
-            unsigned short* row = ctab + VOX_ATAB + (((ch >> 2) * 3 + t) * 4 + (ch & 3)) * 4;
-            row[a] = __builtin_bit_cast(unsigned short, o[t]);
-            if (a == 0) row[3] = 0;
-        }
-    }
 }
 
 extern "C" size_t buf_patch_voxelize_ws_bytes(int ncentres)
 {
     if (ncentres <= 0) return 0;
-    return 256 + sizeof(unsigned short) * ((size_t)VOX_THREADS * VOX_K + 4 * 3 * 4 * 4);
+    return 256 + sizeof(unsigned short) * (size_t)VOX_THREADS * VOX_K;
 }
 
 extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int npatch, int npts, float des_r,
@@ -383,7 +336,7 @@ extern "C" int buf_patch_voxelize(const float* patches, const float* axis, int n
         for (int j = 0; j < 3; j++) M.w[ch][j] = bn_scale[ch] * mlp_w[3 * ch + j];
         M.b[ch] = bn_scale[ch] * mlp_b[ch] + bn_shift[ch];
     }
-    k_vox_ctab<<<1, VOX_THREADS, 0, (hipStream_t)stream>>>(centres, ncentres, voxel_r, voxel_r * voxel_r, M, hdr, tab);
+    k_vox_ctab<<<1, VOX_THREADS, 0, (hipStream_t)stream>>>(centres, ncentres, voxel_r, voxel_r * voxel_r, hdr, tab);
     k_patch_rotation<<<(npatch + 255) / 256, 256, 0, (hipStream_t)stream>>>(axis, npatch, out_R, out_rand);
     BUF_LAUNCH_CHECK();
     const size_t W = (size_t)((npts + 31) / 32);

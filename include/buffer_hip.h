@@ -239,8 +239,9 @@ int     buf_vn_std(const float* x, const float* z, int n, int c, float* out, voi
  * centres f32[ncentres,3]; azi_cs f32[azi_n,2] = cos,sin of -i*2pi/azi_n; mlp_* are HOST arrays
  * (w[16,3], b[16], bn_scale[16], bn_shift[16]).  out_x f32[np,16,ncentres]; out_R f32[np,3,3];
  * out_rand f32[np,3]; out_patches (nullable) f32[np,npts,3].
- * ws: device workspace of buf_patch_voxelize_ws_bytes(ncentres) bytes (cell -> candidate-centre lookup grid,
- * rebuilt by every call; BUF_EWORKSPACE when too small).
+ * ws: device workspace of buf_patch_voxelize_ws_bytes(ncentres) bytes (the split-f16 operand tables of the distance and
+ * MLP matrix instructions, rebuilt by every call; BUF_EWORKSPACE when too small).  The hit decisions are the reference's
+ * fp32 test `d2 < r2` bit for bit (csrc/voxelize.hip: matrix-pipe filter + fp32 re-test of the pairs it cannot call).
  */
 size_t  buf_patch_voxelize_ws_bytes(int ncentres);
 int     buf_patch_voxelize(const float* patches, const float* axis, int npatch, int npts, float des_r,
