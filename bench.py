@@ -168,6 +168,19 @@ def voxelize_entry(timed, traffic, patches):
     return e
 
 
+def nn1_entry(timed):
+    """A12 since round 4: k_nn1f_sweep ranks all pairs with 3 v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block in each of its two
+    passes (min, then candidates) and forms the reference's fp32 sum for the candidates only: achieved = ISSUED f16 flops
+    (6 x the 2 b q n 32 of the distance form) / HIP-event time of the whole call (prep + sweep + fallback launch)."""
+    e = roof_entry(timed, 'nn1', 'k_nn1f_sweep (A12 mutual 1-NN: split-f16 MFMA ranking of all pairs, fp32 sum of the candidates)', 'mfma',
+                   MFMA_F16_PEAK_TFLOPS, 'TFLOP/s', 1e12)
+    if e:
+        e['achieved'] *= 6.0
+        e['frac'] = e['achieved'] / e['peak']
+        e['avg_issued_flops'] = 6.0 * e['avg_algorithmic_flops']
+    return e
+
+
 def traffic_of(pmc, kernel, units):
     """HBM bytes per launch from the committed PMC summary (profiles/traffic.json: bytes per unit of work, measured with
     separate --pmc FETCH_SIZE / WRITE_SIZE passes and the gfx950 FETCH correction) x the units of this run's launch."""
@@ -209,7 +222,7 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
         voxelize_entry(timed, traffic_of(pmc, 'k_patch_voxelize', units.get('patches')), units.get('patches')),
         roof_entry(timed, 'desc_head', 'k_desc_head (A11 attention pooling + normalisation)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_desc_head', units.get('patches'))),
-        roof_entry(timed, 'nn1', 'k_nn1 (A12 mutual 1-NN, exact fp32 VALU)', 'valu', MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', 1e12),
+        nn1_entry(timed),
     ]
     n, ms, rounds = timed['fps']
     if n:

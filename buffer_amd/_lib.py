@@ -60,6 +60,7 @@ _SIGNATURES = {
     "buf_compact_ws_bytes": (_sz, [_i]),
     "buf_compact_greater": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "buf_knn_ws_bytes": (_sz, [_i, _i, _i]),
+    "buf_knn1_ws_bytes": (_sz, [_i, _i, _i]),
     "buf_knn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "buf_fps_ragged": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "buf_svd3x3_batched": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),

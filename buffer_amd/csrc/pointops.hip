@@ -784,6 +784,271 @@ __global__ void __launch_bounds__(256) k_nn1_finish(const unsigned long long* __
     idx[t] = (long long)(key & 0xffffffffu);
 }
 
+// ---- k = 1, d = 32 through the f16 matrix pipe (round 4) ---------------------------------------------------------------------
+// The exact kernel above spends ~100 vector instructions per (query, reference) pair.  Here a split-f16 MFMA form ranks the
+// pairs and only the ones it cannot separate from the best go through the exact sum:
+//   S(q, r) = |r|^2 - 2 q.r   (|q|^2 is the same for every r)  ~  ssd(q, r) - |q|^2  to within eps,
+//   three v_mfma_f32_16x16x32_f16 per 16 references x 16 queries (hi.hi, hi.lo, lo.hi of x = hi + lo, both f16; -2 folded into
+//   the query planes, |r|^2 -- summed in fp64 -- is the accumulator's start value),
+//   pass 1: min_r S per query (half a v_min3 per pair and lane); pass 2: every pair with S <= min + 2 eps is a CANDIDATE and gets
+//   the reference's own sum (same operations in the same order as k_nn1) and the same 64-bit atomicMin key.
+// The reference's arg-min r* has S(r*) <= S(r) + 2 eps for every r (eps >= error of S + error of the fp32 sum), so it is among the
+// candidates together with everything that ties with it; the key then decides exactly as k_nn1 does.  eps = 8e-6 (|q|max + |r|max)^2:
+// the fp32 sum's own rounding (34 x 2^-24 d^2), the 22-bit operand forms (2^-22 |q||r| incl. the dropped lo.lo), the unscaled
+// f16 low parts (subnormal below 2^-14: <= 2^-25 per component), and 99 products + 3 partial sums accumulated in fp32.
+// Inputs outside the comfortable f16 range or not finite (flag `bad`), and query groups with more candidates than NNF_BUDGET
+// (clouds of duplicated descriptors), go to k_nn1f_fallback, the exact scan for just those groups.
+typedef _Float16 nnh8 __attribute__((ext_vector_type(8)));
+typedef float nnf4 __attribute__((ext_vector_type(4)));
+#define NNF_QT 4                       // query tiles of 16 per wavefront
+#define NNF_QW (16 * NNF_QT)           // queries per wavefront
+#define NNF_BUDGET 2048                // exact sums per wavefront before its group is handed to the fallback kernel
+
+struct NnfHdr {                        // device header at the head of the workspace (zeroed per call)
+    unsigned qmax_bits, rmax_bits;     // max |q|^2, |r|^2 as float bits (non-negative floats order as integers)
+    unsigned bad;                      // a non-finite input, or a norm beyond what the f16 planes may carry
+    unsigned nfall;                    // query groups handed to the fallback kernel
+};
+
+// one thread per row: x f32[32] -> planes hi = f16(s x), lo = f16(s x - hi) (row-major, 64 B per row), |x|^2 (fp64 sum, rows >= n
+// of the padded tail: zero planes and a norm no minimum will pick)
+__global__ void __launch_bounds__(256) k_nn1f_prep(const float* __restrict__ x, int b, int n, int npad, float scale,
+                                                  unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                  float* __restrict__ norm, unsigned* __restrict__ max_bits, unsigned* __restrict__ bad)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)b * npad) return;
+    const int e = (int)(t / npad), i = (int)(t - (long long)e * npad);
+    uint4 h4[4], l4[4];
+    double nn = 0.0;
+    if (i < n) {
+        const float4* src = reinterpret_cast<const float4*>(x + ((size_t)e * n + i) * 32);
+        _Float16 h[32], l[32];
+#pragma unroll
+        for (int c4 = 0; c4 < 8; c4++) {
+            const float4 v = src[c4];
+            const float a[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                nn += (double)a[j] * (double)a[j];
+                const float sv = a[j] * scale;                   // (power of two: exact)
+                h[4 * c4 + j] = (_Float16)sv;
+                l[4 * c4 + j] = (_Float16)(sv - (float)h[4 * c4 + j]);
+            }
+        }
+        memcpy(h4, h, 64); memcpy(l4, l, 64);
+        const float nf = (float)nn;
+        if (!(nf <= 1e6f)) atomicOr(bad, 1u);                    // also catches NaN / infinity
+        else atomicMax(max_bits, __float_as_uint(nf));
+    } else {
+        for (int j = 0; j < 4; j++) { h4[j] = make_uint4(0, 0, 0, 0); l4[j] = make_uint4(0, 0, 0, 0); }
+    }
+    uint4* ho = reinterpret_cast<uint4*>(hi + (size_t)t * 32);
+    uint4* lw = reinterpret_cast<uint4*>(lo + (size_t)t * 32);
+    for (int j = 0; j < 4; j++) { ho[j] = h4[j]; lw[j] = l4[j]; }
+    if (norm) norm[t] = i < n ? (float)nn : 3e38f;
+}
+
+// the reference's sum, exactly as k_nn1 forms it (two 16-byte pieces of each row in flight: the register budget of the sweep)
+__device__ __forceinline__ unsigned long long nn1_exact_key(const float* __restrict__ r, const float* __restrict__ q, int idx)
+{
+    const float4* r4 = reinterpret_cast<const float4*>(r);
+    const float4* q4 = reinterpret_cast<const float4*>(q);
+    float ssd = 0.f;
+#pragma unroll 2
+    for (int c4 = 0; c4 < 8; c4++) {
+        const float4 a = r4[c4], b = q4[c4];
+        float t0 = __fsub_rn(a.x, b.x); ssd = __fadd_rn(ssd, __fmul_rn(t0, t0));
+        float t1 = __fsub_rn(a.y, b.y); ssd = __fadd_rn(ssd, __fmul_rn(t1, t1));
+        float t2 = __fsub_rn(a.z, b.z); ssd = __fadd_rn(ssd, __fmul_rn(t2, t2));
+        float t3 = __fsub_rn(a.w, b.w); ssd = __fadd_rn(ssd, __fmul_rn(t3, t3));
+    }
+    return ((unsigned long long)__float_as_uint(ssd) << 32) | (unsigned int)idx;
+}
+
+__global__ void __launch_bounds__(256) k_nn1f_sweep(const float* __restrict__ ref, const float* __restrict__ query, int n, int nq,
+                                                   int npad, int nqpad, const unsigned short* __restrict__ rhi,
+                                                   const unsigned short* __restrict__ rlo, const float* __restrict__ rnorm,
+                                                   const unsigned short* __restrict__ qhi, const unsigned short* __restrict__ qlo,
+                                                   NnfHdr* __restrict__ hdr, unsigned* __restrict__ fall,
+                                                   unsigned long long* __restrict__ best, int b)
+{
+    if (hdr->bad) return;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const int groups = nqpad / NNF_QW;
+    const int task = blockIdx.x * 4 + w;                         // (batch element, query group): consecutive groups of one element
+    const int e = task / groups, g = task - e * groups;
+    if (e >= b) return;
+    const int col = lane & 15, kg = lane >> 4;
+    const float eps = 8e-6f * (sqrtf(__uint_as_float(hdr->qmax_bits)) + sqrtf(__uint_as_float(hdr->rmax_bits))) *
+                              (sqrtf(__uint_as_float(hdr->qmax_bits)) + sqrtf(__uint_as_float(hdr->rmax_bits)));
+    nnh8 Bh[NNF_QT], Bl[NNF_QT];
+#pragma unroll
+    for (int j = 0; j < NNF_QT; j++) {
+        const size_t row = (size_t)e * nqpad + (size_t)g * NNF_QW + 16 * j + col;
+        Bh[j] = *reinterpret_cast<const nnh8*>(qhi + row * 32 + 8 * kg);
+        Bl[j] = *reinterpret_cast<const nnh8*>(qlo + row * 32 + 8 * kg);
+    }
+    const nnh8* Ah = reinterpret_cast<const nnh8*>(rhi + ((size_t)e * npad + col) * 32 + 8 * kg);
+    const nnh8* Al = reinterpret_cast<const nnh8*>(rlo + ((size_t)e * npad + col) * 32 + 8 * kg);
+    const nnf4* Nr = reinterpret_cast<const nnf4*>(rnorm + (size_t)e * npad) + kg;
+    const int nt = npad / 16;
+    // reference tiles two ahead in registers (A planes + norms: 12 registers per tile; the loads are L2 round trips)
+    nnh8 ah[3], al[3];
+    nnf4 nr[3];
+    auto fetch = [&](int t, int slot) __attribute__((always_inline)) {
+        const int tt = t < nt ? t : nt - 1;
+        ah[slot] = Ah[(size_t)tt * 64]; al[slot] = Al[(size_t)tt * 64];      // 16 rows x 64 B = 64 nnh8 per tile
+        nr[slot] = Nr[(size_t)tt * 4];
+    };
+    auto tile = [&](int slot, nnf4 (&acc)[NNF_QT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NNF_QT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[slot], Bh[j], nr[slot], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NNF_QT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[slot], Bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NNF_QT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[slot], Bh[j], acc[j], 0, 0, 0);
+    };
+    // pass 1: the smallest S per query (a lane sees references 4 kg + r of every tile for query column `col`)
+    float m[NNF_QT];
+#pragma unroll
+    for (int j = 0; j < NNF_QT; j++) m[j] = 3.4e38f;
+    fetch(0, 0); fetch(1, 1);
+    for (int t0 = 0; t0 < nt; t0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            if (t0 + u >= nt) break;
+            fetch(t0 + u + 2, (u + 2) % 3);
+            nnf4 acc[NNF_QT];
+            tile(u, acc);
+#pragma unroll
+            for (int j = 0; j < NNF_QT; j++) m[j] = fminf(fminf(fminf(m[j], acc[j][0]), acc[j][1]), fminf(acc[j][2], acc[j][3]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NNF_QT; j++) {
+        m[j] = fminf(m[j], __shfl_xor(m[j], 16, WAVE));
+        m[j] = fminf(m[j], __shfl_xor(m[j], 32, WAVE));
+        m[j] += 2.f * eps;                                       // the candidate threshold of query 16 j + col
+    }
+    // pass 2: candidates (query, reference) into a queue of the wavefront; whenever 64 are waiting every lane forms one reference
+    // sum (same operations, same order as k_nn1) and its 64-bit key
+    __shared__ unsigned queue[4][128];
+    unsigned* qw = queue[w];
+    int nqueued = 0, rounds = 0;
+    auto drain = [&](int count) __attribute__((always_inline)) {          // the first `count` (<= 64) entries
+        if (lane < count) {
+            const unsigned c = qw[lane];
+            const int qi = g * NNF_QW + (int)(c >> 26), ri = (int)(c & 0x3ffffffu);
+            if (ri < n) {
+            const unsigned long long key = nn1_exact_key(ref + ((size_t)e * n + ri) * 32, query + ((size_t)e * nq + qi) * 32, ri);
+            atomicMin(&best[(size_t)e * nq + qi], key);
+            }
+        }
+        rounds++;
+    };
+    bool over = false;
+    unsigned qvalid = 0u;                                        // queries of the padded tail (zero planes: every reference ties) take no part
+#pragma unroll
+    for (int j = 0; j < NNF_QT; j++) qvalid |= (g * NNF_QW + 16 * j + col < nq ? 0xfu : 0u) << (4 * j);
+    fetch(0, 0); fetch(1, 1);
+    for (int t0 = 0; t0 < nt && !over; t0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int t = t0 + u;
+            if (t >= nt) break;
+            fetch(t + 2, (u + 2) % 3);
+            nnf4 acc[NNF_QT];
+            tile(u, acc);
+            unsigned hits = 0u;                                  // bit 4 j + r: reference 16 t + 4 kg + r is a candidate of query 16 j + col
+#pragma unroll
+            for (int j = 0; j < NNF_QT; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) hits |= (acc[j][r] <= m[j] ? 1u : 0u) << (4 * j + r);
+            hits &= qvalid;
+            while (__any(hits != 0u)) {                          // one candidate per lane and round into the queue
+                const bool has = hits != 0u;
+                const unsigned long long bal = __ballot(has);
+                if (has) {
+                    const int bi = __ffs(hits) - 1;
+                    hits &= hits - 1u;
+                    const int qi = 16 * (bi >> 2) + col, ri = 16 * t + 4 * kg + (bi & 3);
+                    const int slot = nqueued + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (g * NNF_QW + qi < nq && ri < n) qw[slot] = ((unsigned)qi << 26) | (unsigned)ri;
+                    else qw[slot] = ((unsigned)(16 * (bi >> 2) + col) << 26) | 0x3ffffffu;          // padding rows: dropped at the drain
+                }
+                nqueued += __popcll(bal);
+                if (nqueued >= 64) {
+                    drain(64);
+                    if (lane < nqueued - 64) qw[lane] = qw[64 + lane];
+                    nqueued -= 64;
+                }
+            }
+            over = rounds > NNF_BUDGET / 64;                      // (uniform)
+        }
+    }
+    if (!over && nqueued > 0) drain(nqueued);
+    if (over && lane == 0) fall[atomicAdd(&hdr->nfall, 1u)] = (unsigned)task;
+}
+
+// the exact scan for the query groups the filter gave up on (or all of them when the inputs were `bad`): a workgroup takes work
+// items (group, reference split) off the list; same sums, same keys as k_nn1
+__global__ void __launch_bounds__(256) k_nn1f_fallback(const float* __restrict__ ref, const float* __restrict__ query, int b, int n, int nq,
+                                                      int nqpad, const NnfHdr* __restrict__ hdr, const unsigned* __restrict__ fall,
+                                                      unsigned long long* __restrict__ best)
+{
+    __shared__ float4 tile[NN1_SPLIT * 8];
+    __shared__ unsigned long long red[4][WAVE];
+    const int groups = nqpad / NNF_QW, splits = (n + NN1_SPLIT - 1) / NN1_SPLIT;
+    const bool all = hdr->bad != 0;
+    const long long items = (long long)(all ? b * groups : (int)hdr->nfall) * splits;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int task = all ? (int)(it / splits) : (int)fall[it / splits], sp = (int)(it % splits);
+        const int e = task / groups, g = task - e * groups;
+        const int q = g * NNF_QW + lane, base = sp * NN1_SPLIT, cnt = min(NN1_SPLIT, n - base);
+        __syncthreads();
+        const float4* R4 = reinterpret_cast<const float4*>(ref + ((size_t)e * n + base) * 32);
+        for (int t = threadIdx.x; t < cnt * 8; t += 256) tile[t] = R4[t];
+        float qv[32];
+        const float* Q = query + ((size_t)e * nq + (q < nq ? q : 0)) * 32;
+#pragma unroll
+        for (int c = 0; c < 32; c++) qv[c] = Q[c];
+        __syncthreads();
+        unsigned long long mine = ~0ull;
+        for (int i = w; i < cnt; i += 4) {
+            float ssd = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; c4++) {
+                const float4 r = tile[i * 8 + c4];
+                float t0 = __fsub_rn(r.x, qv[4 * c4]);     ssd = __fadd_rn(ssd, __fmul_rn(t0, t0));
+                float t1 = __fsub_rn(r.y, qv[4 * c4 + 1]); ssd = __fadd_rn(ssd, __fmul_rn(t1, t1));
+                float t2 = __fsub_rn(r.z, qv[4 * c4 + 2]); ssd = __fadd_rn(ssd, __fmul_rn(t2, t2));
+                float t3 = __fsub_rn(r.w, qv[4 * c4 + 3]); ssd = __fadd_rn(ssd, __fmul_rn(t3, t3));
+            }
+            const unsigned long long key = ((unsigned long long)__float_as_uint(ssd) << 32) | (unsigned int)(base + i);
+            mine = key < mine ? key : mine;
+        }
+        red[w][lane] = mine;
+        __syncthreads();
+        if (w == 0 && q < nq) {
+            unsigned long long mm = red[0][lane];
+            for (int i = 1; i < 4; i++) mm = red[i][lane] < mm ? red[i][lane] : mm;
+            atomicMin(&best[(size_t)e * nq + q], mm);
+        }
+    }
+}
+
+static size_t nnf_round(size_t x) { return (x + 255) & ~(size_t)255; }
+// workspace of the matrix-pipe 1-NN: best keys | header | fallback list | reference planes + norms | query planes
+extern "C" size_t buf_knn1_ws_bytes(int b, int n, int q)
+{
+    if (b <= 0 || n <= 0 || q <= 0) return 256;
+    const size_t npad = ((size_t)n + 15) / 16 * 16, qpad = ((size_t)q + NNF_QW - 1) / NNF_QW * NNF_QW;
+    return nnf_round(8 * (size_t)b * q) + 256 + nnf_round(4 * (size_t)b * (qpad / NNF_QW)) + 2 * nnf_round(64 * (size_t)b * npad) +
+           nnf_round(4 * (size_t)b * npad) + 2 * nnf_round(64 * (size_t)b * qpad) + 256;
+}
+
 extern "C" size_t buf_knn_ws_bytes(int b, int q, int k) { return k == 1 ? sizeof(unsigned long long) * (size_t)b * q + 256 : 256; }
 
 extern "C" int buf_knn(const float* ref, const float* query, int b, int n, int nq, int d, int k, float* dist,
@@ -794,6 +1059,33 @@ extern "C" int buf_knn(const float* ref, const float* query, int b, int n, int n
     BUF_REQUIRE(k <= 64, BUF_EINVAL, "buf_knn: k=%d > 64", k);
     if ((long long)b * nq == 0) return BUF_OK;
     BUF_REQUIRE(query && dist && idx && (n == 0 || ref), BUF_EINVAL, "buf_knn: null argument");
+    static const bool nn1_exact_scan = getenv("BUF_NN1_EXACT_SCAN") != nullptr;        // development switch: the round-1..3 kernel
+    if (k == 1 && d == 32 && n > 0 && ws && ws_bytes >= buf_knn1_ws_bytes(b, n, nq) && !nn1_exact_scan) {
+        hipStream_t s = (hipStream_t)stream;
+        const int npad = (n + 15) / 16 * 16, qpad = (nq + NNF_QW - 1) / NNF_QW * NNF_QW, groups = qpad / NNF_QW;
+        char* p = (char*)ws;
+        unsigned long long* best = (unsigned long long*)p;  p += nnf_round(8 * (size_t)b * nq);
+        NnfHdr* hdr = (NnfHdr*)p;                            p += 256;
+        unsigned* fall = (unsigned*)p;                       p += nnf_round(4 * (size_t)b * groups);
+        unsigned short* rhi = (unsigned short*)p;            p += nnf_round(64 * (size_t)b * npad);
+        unsigned short* rlo = (unsigned short*)p;            p += nnf_round(64 * (size_t)b * npad);
+        float* rnorm = (float*)p;                            p += nnf_round(4 * (size_t)b * npad);
+        unsigned short* qhi = (unsigned short*)p;            p += nnf_round(64 * (size_t)b * qpad);
+        unsigned short* qlo = (unsigned short*)p;
+        BUF_CHECK_HIP(hipMemsetAsync(best, 0xff, sizeof(unsigned long long) * (size_t)b * nq, s));
+        BUF_CHECK_HIP(hipMemsetAsync(hdr, 0, 256, s));
+        TimedSpan span;
+        bool timed = timing_begin(s, &span, 2.0 * b * nq * (double)n * 32, BUF_TIMED_NN1);
+        k_nn1f_prep<<<cdiv((long long)b * npad, 256), 256, 0, s>>>(ref, b, n, npad, 1.f, rhi, rlo, rnorm, &hdr->rmax_bits, &hdr->bad);
+        k_nn1f_prep<<<cdiv((long long)b * qpad, 256), 256, 0, s>>>(query, b, nq, qpad, -2.f, qhi, qlo, nullptr, &hdr->qmax_bits, &hdr->bad);
+        k_nn1f_sweep<<<cdiv((long long)b * groups, 4), 256, 0, s>>>(ref, query, n, nq, npad, qpad, rhi, rlo, rnorm, qhi, qlo, hdr, fall, best, b);
+        k_nn1f_fallback<<<256, 256, 0, s>>>(ref, query, b, n, nq, qpad, hdr, fall, best);
+        if (timed) timing_end(s, &span);
+        long long total = (long long)b * nq;
+        k_nn1_finish<<<cdiv(total, 256), 256, 0, s>>>(best, total, dist, idx);
+        BUF_LAUNCH_CHECK();
+        return BUF_OK;
+    }
     if (k == 1 && d == 32 && n > 0 && ws && ws_bytes >= sizeof(unsigned long long) * (size_t)b * nq) {
         hipStream_t s = (hipStream_t)stream;
         unsigned long long* best = (unsigned long long*)ws;

@@ -279,7 +279,7 @@ def knn(ref, query, k):
     q = query.shape[1]
     dist = torch.empty((b, q, k), dtype=torch.float32, device=ref.device)
     idx = torch.empty((b, q, k), dtype=torch.int64, device=ref.device)
-    nbytes = L.buf_knn_ws_bytes(b, q, int(k))
+    nbytes = L.buf_knn1_ws_bytes(b, n, q) if (int(k) == 1 and d == 32 and n > 0) else L.buf_knn_ws_bytes(b, q, int(k))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
     check(L.buf_knn(_ptr(ref), _ptr(query), b, n, q, d, int(k), _ptr(dist), _ptr(idx), _ptr(ws), nbytes, _stream()),
           "buf_knn")

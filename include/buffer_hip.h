@@ -186,6 +186,10 @@ int     buf_compact_greater(const float* x, int stride, int n, float threshold, 
 /* knn_cuda.KNN(k, transpose_mode=True) (README.md:32; models/BUFFER.py:347,352):
  * ref f32[b,n,d], query f32[b,q,d] -> dist f32[b,q,k] (Euclidean, ascending), idx int64[b,q,k]. d,k <= 64. */
 size_t  buf_knn_ws_bytes(int b, int q, int k);
+/* k = 1, d = 32 (the mutual-matching calls): with a workspace of buf_knn1_ws_bytes(b, n, q) bytes buf_knn ranks the pairs on the
+ * f16 matrix pipe and forms the reference's fp32 sum only for the pairs it cannot separate from the best one (csrc/pointops.hip,
+ * k_nn1f_*): same indices and distances, bit for bit, as the exact scan it falls back to with the smaller workspace. */
+size_t  buf_knn1_ws_bytes(int b, int n, int q);
 int     buf_knn(const float* ref, const float* query, int b, int n, int q, int d, int k, float* dist,
                 long long* idx, void* ws, size_t ws_bytes, void* stream);
 

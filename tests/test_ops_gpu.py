@@ -94,6 +94,69 @@ def test_knn(k, d, oracle, dev):
     np.testing.assert_allclose(gd.cpu().numpy(), wd, rtol=1e-6, atol=0)
 
 
+def _knn1_both(ref, qry, dev):
+    """buf_knn (k = 1, d = 32) with the large workspace (matrix-pipe ranking + fp32 sums of the candidates) and with the small one
+    (the exact scan of rounds 1-3), through the C ABI."""
+    import ctypes as C
+    from buffer_amd import _lib
+    L = _lib.lib()
+    r, q = torch.from_numpy(ref).to(dev).contiguous(), torch.from_numpy(qry).to(dev).contiguous()
+    b, n, d = r.shape
+    nq = q.shape[1]
+    out = []
+    for nbytes in (L.buf_knn1_ws_bytes(b, n, nq), L.buf_knn_ws_bytes(b, nq, 1)):
+        dist = torch.empty((b, nq, 1), dtype=torch.float32, device=dev)
+        idx = torch.empty((b, nq, 1), dtype=torch.int64, device=dev)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = L.buf_knn(r.data_ptr(), q.data_ptr(), b, n, nq, d, 1, dist.data_ptr(), idx.data_ptr(), ws.data_ptr(), nbytes,
+                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, L.buf_last_error()
+        torch.cuda.synchronize()
+        out.append((dist.cpu().numpy(), idx.cpu().numpy()))
+    assert L.buf_knn1_ws_bytes(b, n, nq) > L.buf_knn_ws_bytes(b, nq, 1)
+    return out
+
+
+@pytest.mark.parametrize("case", ["unit", "clustered", "duplicates", "zeros", "ragged", "huge", "nan", "tiny"])
+def test_knn1_matrix_pipe_ranking_equals_exact_scan(case, oracle, dev):
+    """The 1-NN of the mutual-matching calls ranks the pairs with a split-f16 MFMA form and forms the reference's fp32 sum only for
+    the pairs within eps of the best: indices AND distances must be those of the exact scan bit for bit -- for ordinary unit
+    descriptors, for clouds of near-duplicates (many candidates), exact duplicates / all zeros (every pair ties: the query groups
+    go to the exact fallback), sizes that are no multiple of the tiles, and inputs the f16 planes cannot carry (fallback for all)."""
+    rng = np.random.default_rng(7)
+    b, n, nq = 3, 2000, 1500
+    if case == "ragged":
+        b, n, nq = 2, 777, 130
+    if case == "tiny":
+        b, n, nq = 1, 5, 3
+    ref = rng.normal(size=(b, n, 32)).astype(np.float32)
+    qry = rng.normal(size=(b, nq, 32)).astype(np.float32)
+    ref /= np.linalg.norm(ref, axis=-1, keepdims=True)
+    qry /= np.linalg.norm(qry, axis=-1, keepdims=True)
+    if case == "clustered":                              # 20 prototypes + 1e-6 noise: hundreds of references within eps of the best
+        proto = ref[:, :20]
+        ref = (proto[:, rng.integers(0, 20, n)] + 1e-6 * rng.normal(size=(b, n, 32))).astype(np.float32)
+        qry = (proto[:, rng.integers(0, 20, nq)] + 1e-6 * rng.normal(size=(b, nq, 32))).astype(np.float32)
+    if case == "duplicates":
+        ref[:, 1::2] = ref[:, 0::2]                      # every reference twice: the lower index must win
+        qry[:, :200] = ref[:, 100:300]                   # distance exactly 0
+    if case == "zeros":
+        ref[:] = 0
+        qry[1] = 0
+    if case == "huge":
+        ref *= 3000.0
+        qry *= 3000.0
+    if case == "nan":
+        ref[0, 5, 3] = np.nan
+        qry[1, 7, 0] = np.inf
+    (gd, gi), (wd, wi) = _knn1_both(ref, qry, dev)
+    assert np.array_equal(gi, wi)
+    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+    if case in ("unit", "duplicates", "ragged", "tiny"):
+        od, oi = oracle.knn(ref, qry, 1)
+        assert np.array_equal(gi, oi)
+
+
 def test_three_nn(oracle, dev):
     from buffer_amd import ops
     rng = np.random.default_rng(1)
