@@ -2,7 +2,8 @@
 
 (a) HIP path vs the CPU oracle (oracle/pipeline_ref.register_pair: the restated reference, compiled reference cores where
     built) pair by pair at the reference's 1500 keypoints, two pairs per overlap class, same permutations and seeds:
-    keypoints and mutual matches identical, pose within 1e-4.  The oracle runs in worker processes beside the GPU.
+    keypoints and mutual matches identical, pose within 1e-4 -- with the fp32-MFMA CNN kernels and with the split-f16 ones
+    (cnn_arith='split') against the same oracle run.  The oracle runs in worker processes beside the GPU.
 (b) the product's 4096-hypothesis GPU RANSAC (csrc/registration.hip k_ransac) vs the restated open3d 0.13
     registration_ransac_based_on_correspondence the reference calls (models/BUFFER.py:314-326; oracle/ransac_o3d.py), on the
     SAME correspondences of 64 pairs, 2 seeds each, both followed by the same post-refinement and scored with the 3DMatch
@@ -44,16 +45,19 @@ def test_hip_equals_cpu_oracle_pair_by_pair_at_1500_keypoints(dev, oracle):
         cmd = [sys.executable, os.path.join(ROOT, 'tests', 'oracle_worker.py'), '--pairs', ','.join(map(str, mine)),
                '--keypts', '1500', '--threads', str(threads), '--out', out]
         workers.append((subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), out))
-    pipe = BufferPipeline(cfg, dev)
-    limits = pipe.calibrate([make(0)])
-    got = {}
-    for i in ids:
-        s = make(i)
-        rng = np.random.default_rng(i)
-        perms = [rng.permutation(len(s['src_fds_pts'])), rng.permutation(len(s['tgt_fds_pts']))]
-        pose, d = pipe.register(pipe.upload(s), seed=i, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
-        got[i] = dict(pose=pose.cpu().numpy().astype(np.float64), kp=[k.cpu().numpy() for k in d['kpts']],
-                      smids=d['s_mids'].cpu().numpy(), tmids=d['t_mids'].cpu().numpy(), gt=s['relt_pose'])
+    runs = {}
+    for arith in ('f32', 'split'):                           # the fp32-MFMA CNN kernels, and the split-f16 ones (cnn_arith='split')
+        pipe = BufferPipeline(replace(cfg, cnn_arith=arith), dev)
+        limits = pipe.calibrate([make(0)])
+        got = {}
+        for i in ids:
+            s = make(i)
+            rng = np.random.default_rng(i)
+            perms = [rng.permutation(len(s['src_fds_pts'])), rng.permutation(len(s['tgt_fds_pts']))]
+            pose, d = pipe.register(pipe.upload(s), seed=i, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
+            got[i] = dict(pose=pose.cpu().numpy().astype(np.float64), kp=[k.cpu().numpy() for k in d['kpts']],
+                          smids=d['s_mids'].cpu().numpy(), tmids=d['t_mids'].cpu().numpy(), gt=s['relt_pose'])
+        runs[arith] = got
     want = {}
     for p, out in workers:
         log = p.communicate(timeout=600)[0].decode()
@@ -61,24 +65,25 @@ def test_hip_equals_cpu_oracle_pair_by_pair_at_1500_keypoints(dev, oracle):
         z = np.load(out)
         assert [int(x) for x in z['limits']] == [int(x) for x in limits], 'neighbour limits: oracle vs device calibration'
         want.update({k: z[k] for k in z.files})
-    worst, rows = 0.0, []
-    for i in ids:
-        g = got[i]
-        assert np.array_equal(g['kp'][0], want[f'kp0_{i}']) and np.array_equal(g['kp'][1], want[f'kp1_{i}']), f'pair {i}: keypoints differ'
-        # mutual 1-NN matches: the same set, except where two descriptors are equidistant to fp32 round-off (a match then
-        # appears on one side only): at most 2 of ~500 per pair
-        mg = set(zip(g['smids'].tolist(), g['tmids'].tolist()))
-        mo = set(zip(want[f'smids_{i}'].tolist(), want[f'tmids_{i}'].tolist()))
-        sym = len(mg ^ mo)
-        assert sym <= 2, f'pair {i}: {sym} matches differ'
-        dp = float(np.abs(g['pose'] - want[f'pose_{i}']).max())
-        ok_g, ok_o = dgr_success(g['pose'], g['gt'])[0], dgr_success(want[f'pose_{i}'], g['gt'])[0]
-        rows.append(dict(pair=i, matches=int(len(g['smids'])), matches_differing=sym, dpose=dp, ok=bool(ok_g), ok_oracle=bool(ok_o)))
-        worst = max(worst, dp)
-    print('RR_ORACLE ' + json.dumps(dict(worst_dpose=worst, matches_differing=[r['matches_differing'] for r in rows], pairs=rows)))
-    assert worst < 1e-4, worst
-    assert all(r['ok'] == r['ok_oracle'] for r in rows)
-    assert sum(r['matches_differing'] == 0 for r in rows) >= len(rows) - 2
+    for arith, got in runs.items():
+        worst, rows = 0.0, []
+        for i in ids:
+            g = got[i]
+            assert np.array_equal(g['kp'][0], want[f'kp0_{i}']) and np.array_equal(g['kp'][1], want[f'kp1_{i}']), f'pair {i}: keypoints differ'
+            # mutual 1-NN matches: the same set, except where two descriptors are equidistant to fp32 round-off (a match then
+            # appears on one side only): at most 2 of ~500 per pair
+            mg = set(zip(g['smids'].tolist(), g['tmids'].tolist()))
+            mo = set(zip(want[f'smids_{i}'].tolist(), want[f'tmids_{i}'].tolist()))
+            sym = len(mg ^ mo)
+            assert sym <= 2, f'{arith}, pair {i}: {sym} matches differ'
+            dp = float(np.abs(g['pose'] - want[f'pose_{i}']).max())
+            ok_g, ok_o = dgr_success(g['pose'], g['gt'])[0], dgr_success(want[f'pose_{i}'], g['gt'])[0]
+            rows.append(dict(pair=i, matches=int(len(g['smids'])), matches_differing=sym, dpose=dp, ok=bool(ok_g), ok_oracle=bool(ok_o)))
+            worst = max(worst, dp)
+        print('RR_ORACLE ' + json.dumps(dict(cnn_arith=arith, worst_dpose=worst, matches_differing=[r['matches_differing'] for r in rows], pairs=rows)))
+        assert worst < 1e-4, (arith, worst)
+        assert all(r['ok'] == r['ok_oracle'] for r in rows)
+        assert sum(r['matches_differing'] == 0 for r in rows) >= len(rows) - 2
 
 
 def test_gpu_ransac_registration_recall_equals_open3d_restatement(dev):
