@@ -75,6 +75,7 @@ _SIGNATURES = {
                                 _vp, _vp, _sz, _vp]),
     "buf_cylindrical_net_wg": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_cylindrical_net_split": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_cylindrical_net_split_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_split_gemm_count": (C.c_longlong, [_i, _i, _i, _i]),
     "buf_split_tile_gemm": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "buf_cost_volume_net_split": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

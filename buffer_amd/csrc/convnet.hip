@@ -19,15 +19,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // params (DEVICE, DH_NPARAM floats): w0[16][32] (pool_layer.0 with pool_layer.1 BatchNorm folded), b0[16],
 // w3[16] (pool_layer.3 with pool_layer.4 folded), b3
 
-__global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restrict__ y, const float* __restrict__ params,
-                                                       float* __restrict__ desc, float* __restrict__ equi)
+// The head on a map that already sits in LDS (ys[32][140] fp32; wgt, nrm [140], fs [32], hp [DH_NPARAM + 3] LDS scratch): used by
+// k_desc_head below and, fused behind the last layer, by k_cyl_net_h3 (csrc/convnet_h3.hip) -- one body, identical results.
+// All DH_THREADS threads of the workgroup call it; the caller has synchronised after filling ys.
+__device__ __forceinline__ void dh_body(const float* ys, float* wgt, float* nrm, float* fs, float* hp, const float* __restrict__ params,
+                                        float* __restrict__ desc, float* __restrict__ equi, int patch, int tid)
 {
-    __shared__ __attribute__((aligned(16))) float ys[DH_C * CN_POS];
-    __shared__ __attribute__((aligned(16))) float wgt[CN_POS], nrm[CN_POS], fs[DH_C];
-    __shared__ __attribute__((aligned(16))) float hp[DH_NPARAM + 3];
-    const int patch = blockIdx.x, tid = threadIdx.x;
-    const f32x4* src = reinterpret_cast<const f32x4*>(y + (size_t)patch * DH_C * CN_POS);
-    for (int i = tid; i < DH_C * CN_POS / 4; i += DH_THREADS) reinterpret_cast<f32x4*>(ys)[i] = src[i];
     // w0 [hidden][channel] lands transposed, [channel][hidden]: the 16 weights of a channel are four 16-byte broadcast reads
     // in the loop below (one ds_read_b32 per weight made 512 LDS instructions per lane: 3.4 -> 2.x ms per 320 000 patches)
     for (int i = tid; i < DH_NPARAM; i += DH_THREADS)
@@ -79,6 +76,18 @@ __global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restric
         for (int c = 0; c < DH_C; c++) ss += fs[c] * fs[c];
         desc[(size_t)patch * DH_C + tid] = fs[tid] / fmaxf(sqrtf(ss), 1e-12f);
     }
+}
+
+__global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restrict__ y, const float* __restrict__ params,
+                                                       float* __restrict__ desc, float* __restrict__ equi)
+{
+    __shared__ __attribute__((aligned(16))) float ys[DH_C * CN_POS];
+    __shared__ __attribute__((aligned(16))) float wgt[CN_POS], nrm[CN_POS], fs[DH_C];
+    __shared__ __attribute__((aligned(16))) float hp[DH_NPARAM + 3];
+    const int patch = blockIdx.x, tid = threadIdx.x;
+    const f32x4* src = reinterpret_cast<const f32x4*>(y + (size_t)patch * DH_C * CN_POS);
+    for (int i = tid; i < DH_C * CN_POS / 4; i += DH_THREADS) reinterpret_cast<f32x4*>(ys)[i] = src[i];
+    dh_body(ys, wgt, nrm, fs, hp, params, desc, equi, patch, tid);
 }
 
 // y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].  params: DEVICE f32[545] = w0 [16][32], b0 [16], w3 [16], b3 (BN folded).

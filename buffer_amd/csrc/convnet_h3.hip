@@ -58,6 +58,9 @@ struct CylH3Params {
     const float* bias[H3_LAYERS];
     int cin[H3_LAYERS], cout[H3_LAYERS], relu[H3_LAYERS];
     int* status;                        // nullable: bit 0 set when an activation left the f16 range (|v| >= 65504)
+    const float* head;                  // nullable: parameters of the attention-pooling head (csrc/convnet.hip dh_body) -> fused behind the last layer
+    float* desc;                        // with head: desc f32[np,32], equi f32[np,32,140] instead of y
+    float* equi;
 #ifdef H3_STAMP
     long long* stamps;
 #endif
@@ -199,7 +202,7 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
 // C/D layout gives a lane 4 consecutive output channels of one position: one ds_write_b64 per plane) or y[32][140] in fp32.
 template <int PT, bool LAST>
 __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT], const h3f4 (&ac)[2][PT], int relu, int ct, int pt0, unsigned lane,
-                                         float* __restrict__ y, int* status)
+                                         float* __restrict__ y, int* status, bool to_lds = false)
 {
     const int li = lane & 15, lk = lane >> 4;
     float amax = 0.f;
@@ -218,7 +221,13 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(ac[n][t][r], 1.f / 2048.f, am[n][t][r]);     // the bias started the hi-sum
             if constexpr (LAST) {
-                if (p < H3_NPOS) {
+                if (to_lds) {                                    // fused head: the fp32 map [32][140] at the start of the (now free) image
+                    if (p < H3_NPOS) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            *(__attribute__((address_space(3))) float*)(size_t)(lds0 + (unsigned)((c + r) * H3_NPOS + p) * 4u) = relu ? fmaxf(v[r], 0.f) : v[r];
+                    }
+                } else if (p < H3_NPOS) {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu ? fmaxf(v[r], 0.f) : v[r]), yrs,
@@ -247,7 +256,7 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
 
 template <int PT, int KS>
 __device__ __forceinline__ void h3_layer(unsigned lds0, const void* wt, const float* bias, int relu, int ct, int pt0, unsigned lane, bool last,
-                                         float* y, int* status)
+                                         float* y, int* status, bool to_lds)
 {
     h3f4 am[2][PT], ac[2][PT];
 #pragma unroll
@@ -264,21 +273,21 @@ __device__ __forceinline__ void h3_layer(unsigned lds0, const void* wt, const fl
     H3_STAMP_AT(31)
     unsigned lane_s = lane;
     asm volatile("" : "+v"(lane_s));                             // the store addresses are formed here, not hoisted out of the layer loop (and spilled)
-    if (last) h3_store<PT, true>(lds0, am, ac, relu, ct, pt0, lane_s, y, status);
+    if (last) h3_store<PT, true>(lds0, am, ac, relu, ct, pt0, lane_s, y, status, to_lds);
     else h3_store<PT, false>(lds0, am, ac, relu, ct, pt0, lane_s, y, status);
 }
 
 template <int KS>
 __device__ __forceinline__ void h3_dispatch(unsigned lds0, const void* wt, const float* bias, int relu, int cout, int w, unsigned lane, bool last,
-                                            float* y, int* status)
+                                            float* y, int* status, bool to_lds)
 {
-    if (cout == 128) h3_layer<9, KS>(lds0, wt, bias, relu, w, 0, lane, last, y, status);
+    if (cout == 128) h3_layer<9, KS>(lds0, wt, bias, relu, w, 0, lane, last, y, status, to_lds);
     else if (cout == 64) {
-        if (w < 2) h3_layer<4, KS>(lds0, wt, bias, relu, w & 1, 0, lane, last, y, status);
-        else h3_layer<5, KS>(lds0, wt, bias, relu, w & 1, 4, lane, last, y, status);
+        if (w < 2) h3_layer<4, KS>(lds0, wt, bias, relu, w & 1, 0, lane, last, y, status, to_lds);
+        else h3_layer<5, KS>(lds0, wt, bias, relu, w & 1, 4, lane, last, y, status, to_lds);
     } else {
-        if (w == 3) h3_layer<3, KS>(lds0, wt, bias, relu, 0, 6, lane, last, y, status);
-        else h3_layer<2, KS>(lds0, wt, bias, relu, 0, 2 * w, lane, last, y, status);
+        if (w == 3) h3_layer<3, KS>(lds0, wt, bias, relu, 0, 6, lane, last, y, status, to_lds);
+        else h3_layer<2, KS>(lds0, wt, bias, relu, 0, 2 * w, lane, last, y, status, to_lds);
     }
 }
 
@@ -337,9 +346,9 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         const int ks = (P.cin[l] + 31) >> 5, cout = P.cout[l];
         const bool last = l == H3_LAYERS - 1;
         float* yo = y + (size_t)patch * cout * H3_NPOS;
-        if (ks == 4) h3_dispatch<4>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status);
-        else if (ks == 2) h3_dispatch<2>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status);
-        else h3_dispatch<1>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status);
+        if (ks == 4) h3_dispatch<4>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, last && P.head != nullptr);
+        else if (ks == 2) h3_dispatch<2>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, last && P.head != nullptr);
+        else h3_dispatch<1>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, last && P.head != nullptr);
 #ifdef H3_STAMP
         if ((threadIdx.x & 63) == 0) {      // gemm end / barrier end of this layer (slots 30, 31) -> per-layer slots
             long long* q = h3_stamp_ptr + ((size_t)blockIdx.x * 4 + threadIdx.x / 64) * 32;
@@ -348,6 +357,11 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
 #endif
         H3_STAMP_AT(3 + 3 * l)
         __syncthreads();
+    }
+    if (P.head) {                                                // attention pooling + normalisation on the map the last layer left in LDS
+        float* ys = reinterpret_cast<float*>(h3_smem);
+        float* wgt = ys + DH_C * CN_POS;
+        dh_body(ys, wgt, wgt + CN_POS, wgt + 2 * CN_POS, wgt + 2 * CN_POS + DH_C, P.head, P.desc, P.equi, patch, tid);
     }
 }
 
@@ -413,12 +427,33 @@ extern "C" int buf_split_tile_filters(const float* w_host, int cout, int cin, un
 }
 
 // x f32[np,Cin0,140] -> y f32[np,32,140] with fp32-equivalent arithmetic on the f16 matrix pipe (header: buf_cylindrical_net_split).
+static int h3_launch(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host, const int* cin_host,
+                     const int* cout_host, const int* relu_host, float* y, const float* head, float* desc, float* equi, int* status_dev, void* stream);
+
 extern "C" int buf_cylindrical_net_split(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host,
                                          const int* cin_host, const int* cout_host, const int* relu_host, float* y, int* status_dev, void* stream)
 {
+    return h3_launch(x, npatch, wt_host, bias_host, cin_host, cout_host, relu_host, y, nullptr, nullptr, nullptr, status_dev, stream);
+}
+
+// The same stack with the descriptor head (buf_descriptor_head: attention pooling + normalisation) fused behind the last layer: the
+// [32][140] map never goes to HBM.  head_params: DEVICE f32[545] as for buf_descriptor_head -> desc f32[np,32], equi f32[np,32,140],
+// bit-identical to buf_cylindrical_net_split followed by buf_descriptor_head.
+extern "C" int buf_cylindrical_net_split_head(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host,
+                                              const int* cin_host, const int* cout_host, const int* relu_host, const float* head_params,
+                                              float* desc, float* equi, int* status_dev, void* stream)
+{
+    BUF_REQUIRE(npatch <= 0 || (head_params && desc && equi), BUF_EINVAL, "buf_cylindrical_net_split_head: null argument");
+    return h3_launch(x, npatch, wt_host, bias_host, cin_host, cout_host, relu_host, nullptr, head_params, desc, equi, status_dev, stream);
+}
+
+static int h3_launch(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host, const int* cin_host,
+                     const int* cout_host, const int* relu_host, float* y, const float* head, float* desc, float* equi, int* status_dev, void* stream)
+{
     BUF_REQUIRE(npatch >= 0, BUF_EINVAL, "buf_cylindrical_net_split: npatch=%d", npatch);
     if (npatch == 0) return BUF_OK;
-    BUF_REQUIRE(x && y && wt_host && bias_host && cin_host && cout_host && relu_host, BUF_EINVAL, "buf_cylindrical_net_split: null argument");
+    BUF_REQUIRE(x && (y || head) && wt_host && bias_host && cin_host && cout_host && relu_host, BUF_EINVAL, "buf_cylindrical_net_split: null argument");
+    static_assert(DH_THREADS == H3_THREADS && DH_C == 32 && CN_POS == H3_NPOS, "the fused head runs on the kernel's own workgroup and map");
     CylH3Params P;
     for (int l = 0; l < H3_LAYERS; l++) {
         P.wt[l] = wt_host[l]; P.bias[l] = bias_host[l];
@@ -431,6 +466,7 @@ extern "C" int buf_cylindrical_net_split(const float* x, int npatch, const void*
     }
     BUF_REQUIRE(P.cout[H3_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_split: the last layer must have 32 channels");
     P.status = status_dev;
+    P.head = head; P.desc = desc; P.equi = equi;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cyl_net_h3, H3_LDS, grant)) return rc;
     double macs = 0;

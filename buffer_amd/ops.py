@@ -604,6 +604,18 @@ class CylindricalNetSplit:
               self.entry)
         return y
 
+    def with_head(self, x, head):
+        """x f32[P,16,420] -> (desc f32[P,32], equi f32[P,32,7,20]) with DescriptorHead `head` fused behind the last layer: the
+        [32][140] map never leaves LDS; bit-identical to head(self(x))."""
+        L = _lib.lib()
+        x = x.contiguous()
+        P = x.shape[0]
+        desc = torch.empty((P, 32), dtype=torch.float32, device=x.device)
+        equi = torch.empty((P, 32, 7, 20), dtype=torch.float32, device=x.device)
+        check(L.buf_cylindrical_net_split_head(_ptr(x), P, self._wp, self._bp, self._ci, self._co, self._re, _ptr(head.params),
+                                               _ptr(desc), _ptr(equi), _ptr(self.status), _stream()), "buf_cylindrical_net_split_head")
+        return desc, equi
+
     def check_range(self):
         if int(self.status.item()) != 0:
             self.status.zero_()

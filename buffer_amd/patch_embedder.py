@@ -5,6 +5,8 @@ align / voxelise / point-MLP (csrc/voxelize.hip), the dense Cylindrical_Net stac
 as one fp32-MFMA implicit GEMM with the circular-azimuth / zero-elevation padding folded into its addressing,
 and the attention-pooling head (csrc/convnet.hip).  No library convolution runs in the product.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -81,7 +83,10 @@ class PatchEmbedder:
         x, R, rand_axis, pn = ops.patch_voxelize(patches, ax, cfg.des_r, self.centres, self.azi_cs,
                                                  cfg.delta / cfg.rad_n, cfg.voxel_sample, self.mlp_w, self.mlp_b,
                                                  self.mlp_s, self.mlp_t, cfg.azi_n, want_patches)
-        f, e = self.head(self.fused(x))
+        if hasattr(self.fused, 'with_head') and not os.environ.get('BUF_NO_FUSED_HEAD'):   # split-f16 kernel: the head runs behind the last layer, in LDS
+            f, e = self.fused.with_head(x, self.fused_head)
+        else:
+            f, e = self.head(self.fused(x))
         return dict(desc=f, equi=e, R=R, rand_axis=rand_axis, x=x, patches=pn)
 
     def __call__(self, pts, kpts, axis, perm=None, want_patches=False):

@@ -287,6 +287,11 @@ long long buf_split_filter_count(int cout, int cin);                            
 int     buf_split_tile_filters(const float* w_host, int cout, int cin, unsigned short* out_host);   /* host only */
 int     buf_cylindrical_net_split(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host,
                                   const int* cin_host, const int* cout_host, const int* relu_host, float* y, int* status_dev, void* stream);
+/* The same stack with buf_descriptor_head fused behind its last layer (the [32][140] map stays in LDS): head_params = DEVICE
+ * f32[545] as for buf_descriptor_head -> desc f32[np,32], equi f32[np,32,140]; bit-identical to the two calls in sequence. */
+int     buf_cylindrical_net_split_head(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host,
+                                       const int* cin_host, const int* cout_host, const int* relu_host, const float* head_params,
+                                       float* desc, float* equi, int* status_dev, void* stream);
 
 /* A11 (head)  attention pooling + normalisation (models/patch_embedder.py:66-72,81-84): pool_layer
  * (Conv2d 1x1 32->16 + BN + ReLU, Conv2d 1x1 16->1 + BN + ReLU), desc = normalize(mean(y * w)),

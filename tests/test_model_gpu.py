@@ -89,6 +89,14 @@ def test_patch_embedder_split_arithmetic_vs_reference(W, dev):
     ref = PatchEmbedder(W, dev, THREEDMATCH)(t(f['raw']), t(f['kpts']), t(f['kaxis']), t(f['perm']))
     assert (out['desc'] - ref['desc']).abs().max().item() < 2e-6
     pe.fused.check_range()
+    # the head fused behind the last layer (what embed_patches runs) == the two launches in sequence, bit for bit
+    x = out['x']
+    d2, e2 = pe.head(pe.fused(x))
+    d1, e1 = pe.fused.with_head(x, pe.fused_head)
+    assert torch.equal(d1, d2) and torch.equal(e1, e2)
+    assert torch.equal(d1, out['desc']) and torch.equal(e1, out['equi'])
+    d0, e0 = pe.fused.with_head(x[:0], pe.fused_head)
+    assert d0.shape == (0, 32) and e0.shape == (0, 32, 7, 20)
     with pytest.raises(ValueError):
         PatchEmbedder(W, dev, replace(THREEDMATCH, cnn_arith='bf16'))
 
