@@ -22,7 +22,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // The head on a map that already sits in LDS (ys[32][140] fp32; wgt, nrm [140], fs [32], hp [DH_NPARAM + 3] LDS scratch): used by
 // k_desc_head below and, fused behind the last layer, by k_cyl_net_h3 (csrc/convnet_h3.hip) -- one body, identical results.
 // All DH_THREADS threads of the workgroup call it; the caller has synchronised after filling ys.
-__device__ __forceinline__ void dh_body(const float* ys, float* wgt, float* nrm, float* fs, float* hp, const float* __restrict__ params,
+typedef __attribute__((address_space(3))) float dh_lds;        // LDS-qualified: ds_read / ds_write in every caller (a generic pointer makes them flat accesses)
+typedef __attribute__((address_space(3))) f32x4 dh_lds4;
+__device__ __forceinline__ void dh_body(const dh_lds* ys, dh_lds* wgt, dh_lds* nrm, dh_lds* fs, dh_lds* hp, const float* __restrict__ params,
                                         float* __restrict__ desc, float* __restrict__ equi, int patch, int tid)
 {
     // w0 [hidden][channel] lands transposed, [channel][hidden]: the 16 weights of a channel are four 16-byte broadcast reads
@@ -30,9 +32,9 @@ __device__ __forceinline__ void dh_body(const float* ys, float* wgt, float* nrm,
     for (int i = tid; i < DH_NPARAM; i += DH_THREADS)
         hp[i < DH_HID * DH_C ? (i % DH_C) * DH_HID + i / DH_C : i] = params[i];
     __syncthreads();
-    const float* w0 = hp;
-    const float* b0 = hp + DH_HID * DH_C;
-    const float* w3 = b0 + DH_HID;
+    const dh_lds* w0 = hp;
+    const dh_lds* b0 = hp + DH_HID * DH_C;
+    const dh_lds* w3 = b0 + DH_HID;
     if (tid < CN_POS) {
         float h[DH_HID];
 #pragma unroll
@@ -41,7 +43,7 @@ __device__ __forceinline__ void dh_body(const float* ys, float* wgt, float* nrm,
         for (int c = 0; c < DH_C; c++) {
             const float v = ys[c * CN_POS + tid];
             ss += v * v;
-            const f32x4* wr = reinterpret_cast<const f32x4*>(w0 + c * DH_HID);    // LDS broadcast reads, 16 bytes each
+            const dh_lds4* wr = reinterpret_cast<const dh_lds4*>(w0 + c * DH_HID);    // LDS broadcast reads, 16 bytes each
             const f32x4 wq[4] = { wr[0], wr[1], wr[2], wr[3] };
 #pragma unroll
             for (int j = 0; j < DH_HID; j++) h[j] += wq[j >> 2][j & 3] * v;
@@ -56,8 +58,8 @@ __device__ __forceinline__ void dh_body(const float* ys, float* wgt, float* nrm,
     float* eq = equi + (size_t)patch * DH_C * CN_POS;
     static_assert(CN_POS % 4 == 0, "a float4 of the map stays inside one channel");
     for (int i = tid; i < DH_C * CN_POS / 4; i += DH_THREADS) {          // four positions at a time: one index computation, 16-byte accesses
-        const f32x4 v = reinterpret_cast<const f32x4*>(ys)[i];
-        const f32x4 n = reinterpret_cast<const f32x4*>(nrm)[i % (CN_POS / 4)];
+        const f32x4 v = reinterpret_cast<const dh_lds4*>(ys)[i];
+        const f32x4 n = reinterpret_cast<const dh_lds4*>(nrm)[i % (CN_POS / 4)];
         reinterpret_cast<f32x4*>(eq)[i] = (f32x4){ v[0] / n[0], v[1] / n[1], v[2] / n[2], v[3] / n[3] };
     }
     {   // f[c] = mean_pos y[c][pos] * w[pos]: 8 lanes per channel
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restric
     const int patch = blockIdx.x, tid = threadIdx.x;
     const f32x4* src = reinterpret_cast<const f32x4*>(y + (size_t)patch * DH_C * CN_POS);
     for (int i = tid; i < DH_C * CN_POS / 4; i += DH_THREADS) reinterpret_cast<f32x4*>(ys)[i] = src[i];
-    dh_body(ys, wgt, nrm, fs, hp, params, desc, equi, patch, tid);
+    dh_body((dh_lds*)ys, (dh_lds*)wgt, (dh_lds*)nrm, (dh_lds*)fs, (dh_lds*)hp, params, desc, equi, patch, tid);
 }
 
 // y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].  params: DEVICE f32[545] = w0 [16][32], b0 [16], w3 [16], b3 (BN folded).

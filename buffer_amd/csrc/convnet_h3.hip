@@ -359,8 +359,8 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         __syncthreads();
     }
     if (P.head) {                                                // attention pooling + normalisation on the map the last layer left in LDS
-        float* ys = reinterpret_cast<float*>(h3_smem);
-        float* wgt = ys + DH_C * CN_POS;
+        dh_lds* ys = (dh_lds*)reinterpret_cast<float*>(h3_smem);
+        dh_lds* wgt = ys + DH_C * CN_POS;
         dh_body(ys, wgt, wgt + CN_POS, wgt + 2 * CN_POS, wgt + 2 * CN_POS + DH_C, P.head, P.desc, P.equi, patch, tid);
     }
 }

@@ -83,7 +83,7 @@ class PatchEmbedder:
         x, R, rand_axis, pn = ops.patch_voxelize(patches, ax, cfg.des_r, self.centres, self.azi_cs,
                                                  cfg.delta / cfg.rad_n, cfg.voxel_sample, self.mlp_w, self.mlp_b,
                                                  self.mlp_s, self.mlp_t, cfg.azi_n, want_patches)
-        if hasattr(self.fused, 'with_head') and not os.environ.get('BUF_NO_FUSED_HEAD'):   # split-f16 kernel: the head runs behind the last layer, in LDS
+        if hasattr(self.fused, 'with_head') and not os.environ.get('BUF_NO_FUSED_HEAD'):   # split-f16 kernel: the head runs behind the last layer, in LDS (inside the fp32-MFMA kernel it costs more than it saves: DESIGN section 5)
             f, e = self.fused.with_head(x, self.fused_head)
         else:
             f, e = self.head(self.fused(x))
