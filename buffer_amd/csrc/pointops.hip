@@ -470,6 +470,7 @@ extern "C" int buf_permute_clouds(const float* const* clouds_host, const int* le
     return BUF_OK;
 }
 
+#define SPB_SCAN 4
 // One wavefront per keypoint; blockIdx.y = cloud.  kpts: m keypoints per cloud, stacked; patches f32[nc*m, nsample, 3].
 __global__ void __launch_bounds__(SPB_WAVES * WAVE) k_select_patches_grid(const CellGrid* __restrict__ grids, const int* __restrict__ table,
                                                                       const float4* __restrict__ sorted, const float* __restrict__ pts,
@@ -525,13 +526,14 @@ __global__ void __launch_bounds__(SPB_WAVES * WAVE) k_select_patches_grid(const 
         const int nw = (n + 63) >> 6;
         for (int i = lane; i < nw; i += WAVE) M[i] = 0ull;
         wave_sync();
-        for (int c0 = 0; c0 < total; c0 += WAVE) {
-            const int cc = c0 + lane;
-            int off = st[0];
-#pragma unroll
-            for (int j = 1; j < 9; j++) off = cc >= pre[j] ? st[j] : off;
-            if (cc < total) {
-                const float4 p = sorted[cc + off];
+        // run by run (each a contiguous piece of the cell-ordered array): no per-candidate search for the run a flat candidate
+        // number falls into (8 compare + select pairs of the ~35 instructions per 64 candidates), at the price of a partly
+        // filled last step per run
+#pragma unroll 1
+        for (int j = 0; j < 9; j++) {
+            const int sj = __builtin_amdgcn_readlane(rs, j), lj = __builtin_amdgcn_readlane(len, j);
+            for (int c0 = lane; c0 < lj; c0 += WAVE) {
+                const float4 p = sorted[sj + c0];
                 if (sqdist3(qx, qy, qz, p.x, p.y, p.z) < r2) {
                     const int k = __float_as_int(p.w) - lo;                  // index inside the cloud
                     atomicOr(&M[k >> 6], 1ull << (k & 63));
@@ -559,19 +561,30 @@ __global__ void __launch_bounds__(SPB_WAVES * WAVE) k_select_patches_grid(const 
             }
         }
     } else {
-        for (int base = 0; base < n && cnt < keep; base += WAVE) {           // index-ordered scan with early exit
-            const int k = base + lane;
-            bool hit = false;
-            Pt3 p = { 0.f, 0.f, 0.f };
-            if (k < n) {
-                p = *reinterpret_cast<const Pt3*>(P + 3 * (size_t)k);
-                hit = sqdist3(qx, qy, qz, p.x, p.y, p.z) < r2;
+        // index-ordered scan with early exit, SPB_SCAN blocks of 64 indices per step: their loads are independent of the count and
+        // go out together (one block per step left every step waiting on its own L2 round trip)
+        for (int base = 0; base < n && cnt < keep; base += SPB_SCAN * WAVE) {
+            Pt3 p[SPB_SCAN];
+            bool hit[SPB_SCAN];
+#pragma unroll
+            for (int u = 0; u < SPB_SCAN; u++) {
+                const int k = base + u * WAVE + lane;
+                p[u] = Pt3{ 0.f, 0.f, 0.f };
+                if (k < n) p[u] = *reinterpret_cast<const Pt3*>(P + 3 * (size_t)k);
             }
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                const int slot = cnt + lane_prefix(mask, lane);
-                if (hit && slot < keep) *reinterpret_cast<Pt3*>(row + 3 * slot) = p;
-                cnt += __popcll(mask);
+#pragma unroll
+            for (int u = 0; u < SPB_SCAN; u++) {
+                const int k = base + u * WAVE + lane;
+                hit[u] = k < n && sqdist3(qx, qy, qz, p[u].x, p[u].y, p[u].z) < r2;
+            }
+#pragma unroll
+            for (int u = 0; u < SPB_SCAN; u++) {
+                const unsigned long long mask = __ballot(hit[u]);
+                if (mask) {
+                    const int slot = cnt + lane_prefix(mask, lane);
+                    if (hit[u] && slot < keep) *reinterpret_cast<Pt3*>(row + 3 * slot) = p[u];
+                    cnt += __popcll(mask);
+                }
             }
         }
     }
