@@ -893,7 +893,10 @@ __global__ void __launch_bounds__(256) k_nn1f_sweep(const float* __restrict__ re
     const int e = task / groups, g = task - e * groups;
     if (e >= b) return;
     const int col = lane & 15, kg = lane >> 4;
-    const float eps = 8e-6f * (sqrtf(__uint_as_float(hdr->qmax_bits)) + sqrtf(__uint_as_float(hdr->rmax_bits))) *
+#ifndef NNF_EPS_SCALE
+#define NNF_EPS_SCALE 1.f          // development builds (-DNNF_EPS_SCALE=...): how far the bound can shrink before a result changes
+#endif
+    const float eps = NNF_EPS_SCALE * 8e-6f * (sqrtf(__uint_as_float(hdr->qmax_bits)) + sqrtf(__uint_as_float(hdr->rmax_bits))) *
                               (sqrtf(__uint_as_float(hdr->qmax_bits)) + sqrtf(__uint_as_float(hdr->rmax_bits)));
     nnh8 Bh[NNF_QT], Bl[NNF_QT];
 #pragma unroll

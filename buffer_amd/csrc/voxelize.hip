@@ -33,6 +33,9 @@ static_assert(VOX_MAXPTS <= 32 * 32, "the non-empty-word summary of a hit mask i
 #define VOX_CH 16
 #define VOX_MAXS 16           // max samples per voxel kept in the hit list
 #define VOX_K 16              // K slots of the distance MFMA = f16 values per point / centre vector
+#ifndef VOX_EPS_SCALE
+#define VOX_EPS_SCALE 1.f           // development builds (-DVOX_EPS_SCALE=...): how far eps can shrink before a hit mask changes
+#endif
 #define VOX_BIG 30000.f       // D of a pair that cannot hit (unreachable point, lane past the last centre)
 
 typedef _Float16 voxh8 __attribute__((ext_vector_type(8)));
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(VOX_THREADS) k_vox_ctab(const float* __restric
         const float reach = (cmax + r) * 1.001f + 1e-3f;
         const float S = (cmax + reach) * (cmax + reach);
         // centre sets too large for the f16 pieces (|c|^2 - r^2 must stay far below 65504): eps = +inf sends EVERY lane to the fp32 test
-        hdr[0] = reach * reach; hdr[1] = cmax <= 64.f ? 1e-5f * fmaxf(S, 1.f) : __builtin_inff(); hdr[2] = cmax; hdr[3] = 0.f;
+        hdr[0] = reach * reach; hdr[1] = cmax <= 64.f ? VOX_EPS_SCALE * 1e-5f * fmaxf(S, 1.f) : __builtin_inff(); hdr[2] = cmax; hdr[3] = 0.f;
     }
     _Float16 v[VOX_K];
     for (int i = 0; i < VOX_K; i++) v[i] = (_Float16)0.f;
