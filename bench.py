@@ -44,11 +44,23 @@ CYL_NET_EXECUTED_FRACTION = 40 * 1024 / (9 * 140 * 4 * 16)   # k_cyl_net_wg runs
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_16x16x32_f16), ~2.5 PFLOP/s
 VALU_ISSUE_PEAK_GINSTR = 256 * 4 * 2.4 / 4          # G wave-instructions/s: 1024 SIMDs, one 64-lane VALU instruction per 4 cycles, 2.4 GHz
-VOX_VALU_INSTR_PER_PATCH = 17250                     # SQ_INSTS_VALU per patch of k_patch_voxelize (512 points, 420 voxels, 10 samples)
+# SQ_INSTS_VALU per patch of k_patch_voxelize and the library version it was counted on: profiles/instr.json (tools/make_instr.py)
 CYL_NET_DENSE_FLOPS_PER_PATCH = 118702080.0       # 2 x 140 x sum 9 Cin Cout
-# csrc/convnet_h3.hip issues 3 v_mfma_f32_16x16x32_f16 (16384 flops each) per (16 outputs, 16 positions, 32 channels): 9 position
-# tiles for the 140 positions, layer 0's 48 channels as two k-steps: 22842 matrix instructions per patch
-CYL_NET_SPLIT_ISSUED_FLOPS_PER_PATCH = 22842 * 16384.0
+CYL_NET_WIDTHS = (48, 64, 64, 128, 128, 64, 64, 32, 32)       # Cylindrical_Net channels (patchnet.py:15-85; layer 0 = the 3 x 16 radial x point-MLP planes)
+
+
+def cyl_net_split_mfmas_per_patch(widths=CYL_NET_WIDTHS):
+    """csrc/convnet_h3.hip issues 3 v_mfma_f32_16x16x32_f16 per (tap, 16 outputs, 16 positions, 32 channels): 9 taps, 9 position
+    tiles for the 140 positions, k-steps of 32 input channels (layer 0's 48 as two): 22842 matrix instructions per patch."""
+    return sum(3 * 9 * 9 * (co // 16) * ((ci + 31) // 32) for ci, co in zip(widths[:-1], widths[1:]))
+
+
+CYL_NET_SPLIT_ISSUED_FLOPS_PER_PATCH = cyl_net_split_mfmas_per_patch() * 16384.0
+
+
+def load_instr():
+    p = os.path.join(ROOT, 'profiles', 'instr.json')
+    return json.load(open(p)) if os.path.exists(p) else {}
 
 # library timing ids (include/buffer_hip.h BUF_TIMED_*)
 TIMED = {'grid_query': 0, 'cyl_net': 1, 'cost_net': 2, 'select_patches': 3, 'patch_voxelize': 4, 'fps': 5, 'nn1': 6,
@@ -86,7 +98,7 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(sample, cfg, limits):
+def cpu_baseline(sample, cfg, limits, hip_register=None):
     """The CPU path on THIS box's host cores, one pair, full size (no sampling of keypoints, nothing extrapolated):
     pyramid = the reference's cpp_wrappers cores (oracle/_ref, kind 'reference'; the plain-C port where that library was
     not built) on min(16, nproc) concurrent workers like the reference's DataLoader (ThreeDMatch/config.py:22), each
@@ -111,9 +123,20 @@ def cpu_baseline(sample, cfg, limits):
     t_pyr = (time.perf_counter() - t0) / workers   # seconds per pair at `workers` loaders
     tm = {}
     t0 = time.perf_counter()
-    pipeline_ref.register_pair(sample, W, limits, cfg, 0, perms, use_ref=use_ref, timings=tm)
-    wall = time.perf_counter() - t0
+    want, wd = pipeline_ref.register_pair(sample, W, limits, cfg, 0, perms, use_ref=use_ref, timings=tm)
     t_model = sum(v for k, v in tm.items() if k != 'pyramid')
+    parity = None
+    if hip_register is not None:
+        got, gd = hip_register(perms, 0)
+        kp_equal = all(np.array_equal(gd['kpts'][i].cpu().numpy(), wd['kpts'][i].numpy()) for i in range(2))
+        mine = set(zip(gd['s_mids'].cpu().numpy().tolist(), gd['t_mids'].cpu().numpy().tolist()))
+        ref = set(zip(np.asarray(wd['s_mids']).tolist(), np.asarray(wd['t_mids']).tolist()))
+        parity = dict(keypoints_equal=bool(kp_equal), matches=len(ref), matches_differing=len(mine ^ ref),
+                      pose_max_abs_diff=float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max()),
+                      desc_max_abs_diff=float(max((gd['desc'][i]['desc'].cpu() - wd['desc'][i]['desc']).abs().max().item() for i in range(2)))
+                      if kp_equal else None,
+                      what=f'HIP register() vs oracle/pipeline_ref.register_pair on this pair at {cfg.num_keypts} keypoints/fragment, '
+                           'same permutations, seed 0')
     # the reference overlaps its loader workers with the model process: steady-state rate = the slower of the two legs
     return dict(value=1.0 / max(t_pyr, t_model), unit='pairs/s', cores=torch.get_num_threads(), workers=workers,
                 kind='reference cores (pyramid) + restated model' if use_ref else 'port',
@@ -121,7 +144,7 @@ def cpu_baseline(sample, cfg, limits):
                        f'{"reference cpp_wrappers cores" if use_ref else "plain-C port"} on {workers} workers ({t_pyr * 1e3:.1f} ms/pair), '
                        f'model stages = torch-CPU restatement, {torch.get_num_threads()} threads ({t_model:.1f} s/pair); '
                        f'value = 1 / max(loader leg, model leg)',
-                stages_s={k: round(v, 3) for k, v in tm.items()}, pyramid_s_per_pair_at_workers=round(t_pyr, 4))
+                stages_s={k: round(v, 3) for k, v in tm.items()}, pyramid_s_per_pair_at_workers=round(t_pyr, 4), parity=parity)
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -152,19 +175,23 @@ def roof_entry(timed, name, label, bound, peak, unit, scale, traffic=None, **ext
     return e
 
 
-def voxelize_entry(timed, traffic, patches):
+def voxelize_entry(timed, traffic, patches, lib_version=None):
     """k_patch_voxelize is vector-ALU issue bound (SQ counters, profiles/r04_voxelize_sq.txt: the vector ALUs are busy 94 % of the
     kernel's cycles): achieved = wave-level VALU instructions per second (the measured count per patch x this launch's patches /
     HIP-event time), peak = 1024 SIMDs x one wave instruction per 4 cycles at 2.4 GHz.  The byte rate rides along."""
     e = roof_entry(timed, 'patch_voxelize', 'k_patch_voxelize (A9 + A10 + point MLP)', 'valu', HBM_PEAK_GBS, 'GB/s', 1e9, traffic)
-    if not e or not patches:
+    instr = load_instr()
+    per_patch = instr.get('kernels', {}).get('k_patch_voxelize', {}).get('valu_per_patch')
+    if not e or not patches or not per_patch:
         return e
     e['hbm_gbps'], e['hbm_frac'] = e['achieved'], e['frac']
-    e['valu_wave_instructions_per_patch'] = VOX_VALU_INSTR_PER_PATCH
-    e['achieved'] = VOX_VALU_INSTR_PER_PATCH * patches / (e['avg_us'] * 1e-6) / 1e9
+    e['valu_wave_instructions_per_patch'] = per_patch
+    e['achieved'] = per_patch * patches / (e['avg_us'] * 1e-6) / 1e9
     e['peak'], e['unit'] = VALU_ISSUE_PEAK_GINSTR, 'G wave-instructions/s'
     e['frac'] = e['achieved'] / e['peak']
-    e['source'] = 'SQ_INSTS_VALU / patches of tools/vox_pmc.sh (profiles/r04_voxelize_sq.txt)'
+    e['source'] = 'SQ_INSTS_VALU / patches, profiles/instr.json (tools/make_instr.py)'
+    e['instr_lib_version'] = instr.get('lib_version')
+    e['instr_current'] = None if lib_version is None else bool(instr.get('lib_version') == lib_version)
     return e
 
 
@@ -188,7 +215,7 @@ def traffic_of(pmc, kernel, units):
     return k['hbm_bytes_per_unit'] * units if k and units else None
 
 
-def rooflines(timed, pmc, fps_bytes_per_launch, units):
+def rooflines(timed, pmc, fps_bytes_per_launch, units, lib_version=None):
     """`roofline` (dominant kernel) + `roofline_other` (every other kernel with a roofline class in SURVEY 8d)."""
     main = roof_entry(timed, 'cyl_net', 'k_cyl_net_wg (A11 Cylindrical_Net, fused fp32 MFMA, Winograd F(2x2,3x3))', 'mfma', MFMA_F32_PEAK_TFLOPS,
                       'TFLOP/s', 1e12, traffic_of(pmc, 'k_cyl_net_wg', units.get('patches')),
@@ -219,7 +246,7 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units):
                    traffic_of(pmc, 'k_vn_gather', units.get('pairs'))),
         roof_entry(timed, 'select_patches', 'k_select_patches_grid (A8 ball query + grouping)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_select_patches_grid', units.get('patches_per_select'))),
-        voxelize_entry(timed, traffic_of(pmc, 'k_patch_voxelize', units.get('patches')), units.get('patches')),
+        voxelize_entry(timed, traffic_of(pmc, 'k_patch_voxelize', units.get('patches')), units.get('patches'), lib_version),
         roof_entry(timed, 'desc_head', 'k_desc_head (A11 attention pooling + normalisation)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_desc_head', units.get('patches'))),
         nn1_entry(timed),
@@ -249,7 +276,7 @@ def roofline_split(timed, pmc, units, err):
          'frac': issued / sec / 1e12 / MFMA_F16_PEAK_TFLOPS, 'traffic': traffic_of(pmc, 'k_cyl_net_h3', patches),
          'launches': n, 'avg_us': ms / n * 1e3, 'avg_issued_flops': issued, 'avg_algorithmic_flops': work / n,
          'dense_equivalent_tflops': work / n / sec / 1e12,
-         'flops': 'achieved = 22842 issued MFMAs per patch x 16384 flops / HIP-event time; dense algorithmic count 0.1187 GFLOP/patch'}
+         'flops': f'achieved = {cyl_net_split_mfmas_per_patch()} issued MFMAs per patch (layer shapes) x 16384 flops / HIP-event time; dense algorithmic count 0.1187 GFLOP/patch'}
     e.update(err or {})
     nc, msc, wc = timed['cost_net_split']
     if nc:                                           # csrc/costnet_h3.hip rides along: dense-equivalent rate only (work = SURVEY 8d's 0.160 GFLOP/match)
@@ -518,8 +545,9 @@ def main():
             lat_s = float(np.median(ts[1:]))
         if rank == 0:
             dpose = float((mine_s - mine).abs().max().item()) if mine.numel() else 0.0
-            split = dict(elapsed=elapsed_s, timed=timed_s, ok=dgr_ok(mine_s.cpu().numpy(), gts), dpose=dpose, latency=lat_s,
-                         err=cnn_error_vs_float64(pipe, pipe_s, dev))
+            # (the 64-patch float64 probe stays out of the PMC-profiled runs: full-step launches only there)
+            err = None if os.environ.get('BUF_NO_TRAFFIC') else cnn_error_vs_float64(pipe, pipe_s, dev)
+            split = dict(elapsed=elapsed_s, timed=timed_s, ok=dgr_ok(mine_s.cpu().numpy(), gts), dpose=dpose, latency=lat_s, err=err)
 
     if rank == 0:
         pairs = job_pairs_per_step * a.steps
@@ -534,7 +562,7 @@ def main():
         if a.arith == 'split':
             main_roof = roofline_split(timed, pmc, units, None)
         units['patches_per_select'] = 2 * keypts * per_launch
-        _, other = rooflines(timed_alone, pmc, fps_bytes, units)              # the others: each kernel alone on the chip
+        _, other = rooflines(timed_alone, pmc, fps_bytes, units, int(L.buf_version()))     # the others: each kernel alone on the chip
         alone_steps = 2 if timed_alone is not timed else a.steps
         label = ('KITTI-shape scan pair (~120k returns per scan, 0.05 / 0.30 m voxels, KITTI constants), full BUFFER inference '
                  '(BASELINE configs[3])') if kitti else 'one 3DMatch-shape fragment pair, full BUFFER inference (BASELINE configs[1])'
@@ -554,7 +582,9 @@ def main():
                        'setup_s': round(setup_s, 1)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits)
+            def hip_register(perms, seed):
+                return pipe.register(inputs[0], seed=seed, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
+            out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits, hip_register)
         out['roofline'] = main_roof
         detail = dict(out, roofline_other=other, timed_kernel_ms_per_step={k: v[1] / alone_steps for k, v in timed_alone.items() if v[0]})
         if split:

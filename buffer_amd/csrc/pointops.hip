@@ -806,10 +806,16 @@ __global__ void __launch_bounds__(256) k_nn1_finish(const unsigned long long* __
 //   pass 1: min_r S per query (half a v_min3 per pair and lane); pass 2: every pair with S <= min + 2 eps is a CANDIDATE and gets
 //   the reference's own sum (same operations in the same order as k_nn1) and the same 64-bit atomicMin key.
 // The reference's arg-min r* has S(r*) <= S(r) + 2 eps for every r (eps >= error of S + error of the fp32 sum), so it is among the
-// candidates together with everything that ties with it; the key then decides exactly as k_nn1 does.  eps = 8e-6 (|q|max + |r|max)^2:
-// the fp32 sum's own rounding (34 x 2^-24 d^2), the 22-bit operand forms (2^-22 |q||r| incl. the dropped lo.lo), the unscaled
-// f16 low parts (subnormal below 2^-14: <= 2^-25 per component), and 99 products + 3 partial sums accumulated in fp32.
-// Inputs outside the comfortable f16 range or not finite (flag `bad`), and query groups with more candidates than NNF_BUDGET
+// candidates together with everything that ties with it; the key then decides exactly as k_nn1 does.
+// Round 5: the planes hold sc x with sc an exact power of two per BATCH ELEMENT that brings the element's largest norm
+// (max over its queries and references, k_nn1f_norm) into [0.7, 1.42): the ranking S' = sc^2 S is that of S, and the bound no longer
+// depends on the magnitude of the data (unscaled, the f16 planes of inputs with norms below ~1e-2 sank into the f16 subnormals:
+// absolute plane error 2^-25 per component against an eps that shrinks like the norm squared).
+// eps = 8e-6 (|q|max + |r|max)^2 + 6e-7 (|q|max + |r|max) in the scaled domain: the fp32 sum's own rounding (34 x 2^-24 d^2), the
+// 22-bit operand forms (2^-22 |q||r| incl. the dropped lo.lo) and 99 products + 3 partial sums accumulated in fp32 are the quadratic
+// term; the f16 low parts (subnormal below 2^-14) and any high part of a small row carry an ABSOLUTE error <= 2^-25 per component,
+// i.e. <= 2^-25 sqrt(32) (|r| + 2 |q|) in S: the linear term (rows much smaller than the element's largest).
+// Inputs that are not finite or beyond 1e15 in norm (flag `bad`), and query groups with more candidates than NNF_BUDGET
 // (clouds of duplicated descriptors), go to k_nn1f_fallback, the exact scan for just those groups.
 typedef _Float16 nnh8 __attribute__((ext_vector_type(8)));
 typedef float nnf4 __attribute__((ext_vector_type(4)));
@@ -818,25 +824,62 @@ typedef float nnf4 __attribute__((ext_vector_type(4)));
 #define NNF_BUDGET 2048                // exact sums per wavefront before its group is handed to the fallback kernel
 
 struct NnfHdr {                        // device header at the head of the workspace (zeroed per call)
-    unsigned qmax_bits, rmax_bits;     // max |q|^2, |r|^2 as float bits (non-negative floats order as integers)
-    unsigned bad;                      // a non-finite input, or a norm beyond what the f16 planes may carry
+    unsigned bad;                      // a non-finite input, or a norm beyond 1e15
     unsigned nfall;                    // query groups handed to the fallback kernel
 };
+// per batch element, behind the header: max |q|^2 and max |r|^2 as float bits (non-negative floats order as integers)
+struct NnfMax { unsigned q_bits, r_bits; };
 
-// one thread per row: x f32[32] -> planes hi = f16(s x), lo = f16(s x - hi) (row-major, 64 B per row), |x|^2 (fp64 sum, rows >= n
-// of the padded tail: zero planes and a norm no minimum will pick)
+// the element's plane scale: the power of two 2^k with (2^k)^2 max(|q|^2max, |r|^2max) in [0.5, 2)
+__device__ __forceinline__ float nnf_scale(const NnfMax mx)
+{
+    const float m = fmaxf(__uint_as_float(mx.q_bits), __uint_as_float(mx.r_bits));
+    if (!(m > 0.f)) return 1.f;
+    int ex;
+    frexpf(m, &ex);                                              // m = f 2^ex, f in [0.5, 1)
+    int k = -(ex >> 1);                                          // floor(ex / 2)
+    k = k > 60 ? 60 : (k < -60 ? -60 : k);
+    return ldexpf(1.f, k);
+}
+
+// one thread per row of the references and of the queries: |x|^2 (fp64 sum, rounded once) -> the element's maxima
+__global__ void __launch_bounds__(256) k_nn1f_norm(const float* __restrict__ ref, const float* __restrict__ query, int b, int n, int nq,
+                                                  NnfMax* __restrict__ emax, unsigned* __restrict__ bad)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nr = (long long)b * n;
+    if (t >= nr + (long long)b * nq) return;
+    const bool isq = t >= nr;
+    const long long row = isq ? t - nr : t;
+    const int e = (int)(row / (isq ? nq : n));
+    const float4* src = reinterpret_cast<const float4*>((isq ? query : ref) + (size_t)row * 32);
+    double nn = 0.0;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; c4++) {
+        const float4 v = src[c4];
+        nn += (double)v.x * (double)v.x; nn += (double)v.y * (double)v.y; nn += (double)v.z * (double)v.z; nn += (double)v.w * (double)v.w;
+    }
+    const float nf = (float)nn;
+    if (!(nf <= 1e30f)) atomicOr(bad, 1u);                       // also catches NaN / infinity
+    else atomicMax(isq ? &emax[e].q_bits : &emax[e].r_bits, __float_as_uint(nf));
+}
+
+// one thread per row: x f32[32] -> planes hi = f16(s x), lo = f16(s x - hi) with s = scale * nnf_scale(element) (row-major, 64 B per
+// row), sc^2 |x|^2 (fp64 sum; rows >= n of the padded tail: zero planes and a norm no minimum will pick)
 __global__ void __launch_bounds__(256) k_nn1f_prep(const float* __restrict__ x, int b, int n, int npad, float scale,
                                                   unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-                                                  float* __restrict__ norm, unsigned* __restrict__ max_bits, unsigned* __restrict__ bad)
+                                                  float* __restrict__ norm, const NnfMax* __restrict__ emax)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)b * npad) return;
     const int e = (int)(t / npad), i = (int)(t - (long long)e * npad);
     uint4 h4[4], l4[4];
     double nn = 0.0;
+    const float sc = nnf_scale(emax[e]);
     if (i < n) {
         const float4* src = reinterpret_cast<const float4*>(x + ((size_t)e * n + i) * 32);
         _Float16 h[32], l[32];
+        const float s2 = scale * sc;
 #pragma unroll
         for (int c4 = 0; c4 < 8; c4++) {
             const float4 v = src[c4];
@@ -844,22 +887,19 @@ __global__ void __launch_bounds__(256) k_nn1f_prep(const float* __restrict__ x, 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 nn += (double)a[j] * (double)a[j];
-                const float sv = a[j] * scale;                   // (power of two: exact)
+                const float sv = a[j] * s2;                      // (power of two: exact unless the product leaves the fp32 range -- `bad` rows)
                 h[4 * c4 + j] = (_Float16)sv;
                 l[4 * c4 + j] = (_Float16)(sv - (float)h[4 * c4 + j]);
             }
         }
         memcpy(h4, h, 64); memcpy(l4, l, 64);
-        const float nf = (float)nn;
-        if (!(nf <= 1e6f)) atomicOr(bad, 1u);                    // also catches NaN / infinity
-        else atomicMax(max_bits, __float_as_uint(nf));
     } else {
         for (int j = 0; j < 4; j++) { h4[j] = make_uint4(0, 0, 0, 0); l4[j] = make_uint4(0, 0, 0, 0); }
     }
     uint4* ho = reinterpret_cast<uint4*>(hi + (size_t)t * 32);
     uint4* lw = reinterpret_cast<uint4*>(lo + (size_t)t * 32);
     for (int j = 0; j < 4; j++) { ho[j] = h4[j]; lw[j] = l4[j]; }
-    if (norm) norm[t] = i < n ? (float)nn : 3e38f;
+    if (norm) norm[t] = i < n ? (float)(nn * (double)sc * (double)sc) : 3e38f;
 }
 
 // the reference's sum, exactly as k_nn1 forms it (two 16-byte pieces of each row in flight: the register budget of the sweep)
@@ -883,7 +923,7 @@ __global__ void __launch_bounds__(256) k_nn1f_sweep(const float* __restrict__ re
                                                    int npad, int nqpad, const unsigned short* __restrict__ rhi,
                                                    const unsigned short* __restrict__ rlo, const float* __restrict__ rnorm,
                                                    const unsigned short* __restrict__ qhi, const unsigned short* __restrict__ qlo,
-                                                   NnfHdr* __restrict__ hdr, unsigned* __restrict__ fall,
+                                                   NnfHdr* __restrict__ hdr, const NnfMax* __restrict__ emax, unsigned* __restrict__ fall,
                                                    unsigned long long* __restrict__ best, int b)
 {
     if (hdr->bad) return;
@@ -896,8 +936,10 @@ __global__ void __launch_bounds__(256) k_nn1f_sweep(const float* __restrict__ re
 #ifndef NNF_EPS_SCALE
 #define NNF_EPS_SCALE 1.f          // development builds (-DNNF_EPS_SCALE=...): how far the bound can shrink before a result changes
 #endif
-    const float eps = NNF_EPS_SCALE * 8e-6f * (sqrtf(__uint_as_float(hdr->qmax_bits)) + sqrtf(__uint_as_float(hdr->rmax_bits))) *
-                              (sqrtf(__uint_as_float(hdr->qmax_bits)) + sqrtf(__uint_as_float(hdr->rmax_bits)));
+    const NnfMax mx = emax[e];
+    const float sc = nnf_scale(mx);
+    const float nsum = sc * (sqrtf(__uint_as_float(mx.q_bits)) + sqrtf(__uint_as_float(mx.r_bits)));     // in the scaled domain: [0.7, 2.9)
+    const float eps = NNF_EPS_SCALE * (8e-6f * nsum * nsum + 6e-7f * nsum);
     nnh8 Bh[NNF_QT], Bl[NNF_QT];
 #pragma unroll
     for (int j = 0; j < NNF_QT; j++) {
@@ -995,14 +1037,20 @@ __global__ void __launch_bounds__(256) k_nn1f_sweep(const float* __restrict__ re
                 }
                 nqueued += __popcll(bal);
                 if (nqueued >= 64) {
+                    wave_sync();                                 // queue stores of other lanes before the drain reads them
                     drain(64);
-                    if (lane < nqueued - 64) qw[lane] = qw[64 + lane];
+                    unsigned mv = 0u;
+                    if (lane < nqueued - 64) mv = qw[64 + lane];
+                    wave_sync();
+                    if (lane < nqueued - 64) qw[lane] = mv;
+                    wave_sync();
                     nqueued -= 64;
                 }
             }
             over = rounds > NNF_BUDGET / 64;                      // (uniform)
         }
     }
+    wave_sync();
     if (!over && nqueued > 0) drain(nqueued);
     if (over && lane == 0) fall[atomicAdd(&hdr->nfall, 1u)] = (unsigned)task;
 }
@@ -1061,7 +1109,7 @@ extern "C" size_t buf_knn1_ws_bytes(int b, int n, int q)
 {
     if (b <= 0 || n <= 0 || q <= 0) return 256;
     const size_t npad = ((size_t)n + 15) / 16 * 16, qpad = ((size_t)q + NNF_QW - 1) / NNF_QW * NNF_QW;
-    return nnf_round(8 * (size_t)b * q) + 256 + nnf_round(4 * (size_t)b * (qpad / NNF_QW)) + 2 * nnf_round(64 * (size_t)b * npad) +
+    return nnf_round(8 * (size_t)b * q) + 256 + nnf_round(8 * (size_t)b) + nnf_round(4 * (size_t)b * (qpad / NNF_QW)) + 2 * nnf_round(64 * (size_t)b * npad) +
            nnf_round(4 * (size_t)b * npad) + 2 * nnf_round(64 * (size_t)b * qpad) + 256;
 }
 
@@ -1082,6 +1130,7 @@ extern "C" int buf_knn(const float* ref, const float* query, int b, int n, int n
         char* p = (char*)ws;
         unsigned long long* best = (unsigned long long*)p;  p += nnf_round(8 * (size_t)b * nq);
         NnfHdr* hdr = (NnfHdr*)p;                            p += 256;
+        NnfMax* emax = (NnfMax*)p;                           p += nnf_round(8 * (size_t)b);
         unsigned* fall = (unsigned*)p;                       p += nnf_round(4 * (size_t)b * groups);
         unsigned short* rhi = (unsigned short*)p;            p += nnf_round(64 * (size_t)b * npad);
         unsigned short* rlo = (unsigned short*)p;            p += nnf_round(64 * (size_t)b * npad);
@@ -1089,12 +1138,13 @@ extern "C" int buf_knn(const float* ref, const float* query, int b, int n, int n
         unsigned short* qhi = (unsigned short*)p;            p += nnf_round(64 * (size_t)b * qpad);
         unsigned short* qlo = (unsigned short*)p;
         BUF_CHECK_HIP(hipMemsetAsync(best, 0xff, sizeof(unsigned long long) * (size_t)b * nq, s));
-        BUF_CHECK_HIP(hipMemsetAsync(hdr, 0, 256, s));
+        BUF_CHECK_HIP(hipMemsetAsync(hdr, 0, 256 + nnf_round(8 * (size_t)b), s));          // header + per-element maxima
         TimedSpan span;
         bool timed = timing_begin(s, &span, 2.0 * b * nq * (double)n * 32, BUF_TIMED_NN1);
-        k_nn1f_prep<<<cdiv((long long)b * npad, 256), 256, 0, s>>>(ref, b, n, npad, 1.f, rhi, rlo, rnorm, &hdr->rmax_bits, &hdr->bad);
-        k_nn1f_prep<<<cdiv((long long)b * qpad, 256), 256, 0, s>>>(query, b, nq, qpad, -2.f, qhi, qlo, nullptr, &hdr->qmax_bits, &hdr->bad);
-        k_nn1f_sweep<<<cdiv((long long)b * groups, 4), 256, 0, s>>>(ref, query, n, nq, npad, qpad, rhi, rlo, rnorm, qhi, qlo, hdr, fall, best, b);
+        k_nn1f_norm<<<cdiv((long long)b * (n + nq), 256), 256, 0, s>>>(ref, query, b, n, nq, emax, &hdr->bad);
+        k_nn1f_prep<<<cdiv((long long)b * npad, 256), 256, 0, s>>>(ref, b, n, npad, 1.f, rhi, rlo, rnorm, emax);
+        k_nn1f_prep<<<cdiv((long long)b * qpad, 256), 256, 0, s>>>(query, b, nq, qpad, -2.f, qhi, qlo, nullptr, emax);
+        k_nn1f_sweep<<<cdiv((long long)b * groups, 4), 256, 0, s>>>(ref, query, n, nq, npad, qpad, rhi, rlo, rnorm, qhi, qlo, hdr, emax, fall, best, b);
         k_nn1f_fallback<<<256, 256, 0, s>>>(ref, query, b, n, nq, qpad, hdr, fall, best);
         if (timed) timing_end(s, &span);
         long long total = (long long)b * nq;

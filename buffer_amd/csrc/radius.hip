@@ -751,8 +751,9 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
     // algorithmic bytes of this launch: queries + supports + the index table
     TimedSpan span;
     bool timed = timing_begin(s, &span, 12.0 * nq + 12.0 * g->ns + 4.0 * (double)nq * k_out);
-    // todo list (query ids of rows longer than QW_CAP) is carved behind the caller's output: it needs at
-    // most nq ints; the first k_out==0 launch never produces one.
+    // todo list (query ids of rows longer than QW_CAP, and -- cell-centric self queries, the count-only k_out == 0 pass included --
+    // queries whose 27-cell candidate set exceeds the LDS stage): caller's workspace of nq ints; invariant: whenever q_order is the
+    // grid's own order the workspace must hold nq ints, at k_out == 0 too (include/buffer_hip.h, todo_ws).
     // 2-D launch: y = batch element, x = chunks of 16 queries of the longest element (chunks past an element's end exit at once)
     int qmax = 0;
     for (int bb = 0; bb < g->nb; bb++) qmax = q_batches_host[bb] > qmax ? q_batches_host[bb] : qmax;

@@ -407,7 +407,7 @@ extern "C" int buf_vn_gather_block_pre(const float* q_pts, const float* s_pts, c
     BUF_REQUIRE(ws && ws_bytes >= buf_vn_gather_pre_ws_bytes(ns, cout), BUF_EWORKSPACE, "buf_vn_gather_block_pre: workspace of %zu bytes, need %zu",
                 ws_bytes, buf_vn_gather_pre_ws_bytes(ns, cout));
     const size_t lds = sizeof(float) * 2 * (size_t)cout * (cin + 1);
-    BUF_REQUIRE(lds <= 64 * 1024, BUF_EINVAL, "buf_vn_gather_block_pre: weights exceed 64 KiB of LDS");
+    BUF_REQUIRE(lds <= 48 * 1024, BUF_EINVAL, "buf_vn_gather_block_pre: weights of %zu bytes exceed the 48 KiB of LDS a launch gets without opting in", lds);
     const VnParams P = make_params(wf, wd, bn_scale, bn_shift, slope);
     TimedSpan span;
     bool timed = timing_begin((hipStream_t)stream, &span, 4.0 * nq * k + 12.0 * nq + 12.0 * nq * cin + 12.0 * nq * cout, BUF_TIMED_VN_GATHER);

@@ -22,6 +22,14 @@ class BufferPipeline:
         self.inlier = registration.CostVolume(W, self.device, cfg.azi_n, getattr(cfg, 'cnn_arith', 'f32'))
         self.limits = None if limits is None else [int(x) for x in limits]
 
+    def check_range(self):
+        """cnn_arith='split': raise FloatingPointError if an activation of either CNN ever left the f16 range (the kernels set a device
+        flag; reading it synchronises).  No-op on the fp32 kernels.  register() / register_batch() / register_batches() call it
+        before they return, so no driver reports poses computed behind an overflow."""
+        for m in (self.desc.fused, self.inlier.fused):
+            if hasattr(m, 'check_range'):
+                m.check_range()
+
     def calibrate(self, samples):
         self.limits = [int(x) for x in pyramid.calibrate_limits(samples, self.cfg, self.device)]
         return self.limits
@@ -74,6 +82,7 @@ class BufferPipeline:
                           res[1]['equi'][t_mids][:, :, 1:e - 1].contiguous())
         pose, diag = registration.recover_pose(ind, ss_kpts, tt_kpts, res[0]['R'][s_mids].contiguous(),
                                                res[1]['R'][t_mids].contiguous(), cfg, seed)
+        self.check_range()
         if detail:
             out.update(dict(pyr=pyr, axis=axis, eps=eps, score=score, kpts=kp, kaxis=ka, desc=res, s_mids=s_mids,
                             t_mids=t_mids, ind=ind, **diag))
@@ -86,7 +95,9 @@ class BufferPipeline:
         blocks, FPS (one workgroup per cloud), patch selection, voxelisation, both CNNs and the 1-NN search all take the
         stacked batch; only the per-pair pose recovery loops).  inps: list of upload() dicts ->
         list of pose f32[4,4] device tensors.  Per pair the arithmetic is that of register()."""
-        return self._describe_and_match(self._keypoints(inps, seeds, perms))
+        poses = self._describe_and_match(self._keypoints(inps, seeds, perms))
+        self.check_range()
+        return poses
 
     @torch.no_grad()
     def register_batches(self, batches, seeds=None):
@@ -127,6 +138,7 @@ class BufferPipeline:
             # side stream only, while the current stream is busy with the kernels queued above
             nxt = stage1(i + 1) if i + 1 < len(batches) else None
             out.append(self._match(st))
+        self.check_range()
         return out
 
     def _keypoints(self, inps, seeds, perms):

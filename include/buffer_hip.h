@@ -112,7 +112,8 @@ int     buf_grid_query(const buf_grid_t* g, const float* queries, int nq, const 
 /* todo_ws: int32[nq] scratch (rows longer than 64 neighbours -- and, in the cell-centric self query, cells whose 27-cell
  * candidate set exceeds the LDS stage -- are redone by a second, unbounded pass).  It may be null ONLY when k_out == 0 and
  * either q_order is null or the call is a self query (queries == the grid's supports, nq == ns, q_order == g->order); a
- * self query without it runs on the query-centric kernel.
+ * self query without it runs on the query-centric kernel.  A self query WITH it may write the list in the count-only
+ * (k_out == 0) pass as well (stage-overflow queries), so the workspace must hold nq ints there too.
  * Build + query in one call (what batch_query does); ws >= buf_grid_ws_bytes(ns,nb,0) + 4*nq bytes. */
 int     buf_radius_neighbors(const float* queries, int nq, const float* supports, int ns,
                              const int* q_batches_host, const int* s_batches_host, int nb, float radius,

@@ -53,6 +53,10 @@ def test_bench_json_line(dev, tmp_path):
     c = d['cpu_baseline']
     assert c['kind'] in ('reference cores (pyramid) + restated model', 'port') and c['cores'] >= 1 and c['workers'] >= 1 and c['value'] > 0 and c['unit'] == 'pairs/s'
     assert 'nothing scaled' in c['sample'] and c['stages_s']['descriptors'] > 0
+    # the oracle run of the baseline leg is also the checker of the product path on the same pair (same permutations, seed 0)
+    par = c['parity']
+    assert set(par) >= {'keypoints_equal', 'matches_differing', 'pose_max_abs_diff'}
+    assert par['keypoints_equal'] is True and par['matches_differing'] <= max(2, par['matches'] // 200) and par['pose_max_abs_diff'] < 1e-4
     assert d['config']['registered_ok'].startswith('8/8') and d['config']['distinct_pairs_per_gpu'] == 4      # = pairs per step
     # the driver keeps the last 2000 characters of the line: the four round-4 keys and every compact entry must be inside them
     line = json.dumps(d)
@@ -61,6 +65,9 @@ def test_bench_json_line(dev, tmp_path):
         assert k in tail, k
     full = json.load(open(detail))
     assert full['roofline_other'][0]['launches'] > 0 and 'timed_kernel_ms_per_step' in full
+    # instruction counts the vector-issue roofline is priced with come from profiles/instr.json, measured on THIS library version
+    vox = [o for o in full['roofline_other'] if o['kernel'].startswith('k_patch_voxelize')][0]
+    assert vox['bound'] == 'valu' and vox['instr_current'] is True, 'profiles/instr.json is stale: re-run tools/profile_round.sh (make_instr.py)'
 
 
 def test_bench_strong_scaling_mode_two_ranks_over_gloo(dev):

@@ -117,12 +117,15 @@ def _knn1_both(ref, qry, dev):
     return out
 
 
-@pytest.mark.parametrize("case", ["unit", "clustered", "duplicates", "zeros", "ragged", "huge", "nan", "tiny"])
+@pytest.mark.parametrize("case", ["unit", "clustered", "duplicates", "zeros", "ragged", "huge", "nan", "tiny", "scale1e-3", "scale1e-5",
+                                  "scale1e-12", "scale1e+8", "mixed_elements", "mixed_rows", "clustered1e-4"])
 def test_knn1_matrix_pipe_ranking_equals_exact_scan(case, oracle, dev):
     """The 1-NN of the mutual-matching calls ranks the pairs with a split-f16 MFMA form and forms the reference's fp32 sum only for
     the pairs within eps of the best: indices AND distances must be those of the exact scan bit for bit -- for ordinary unit
     descriptors, for clouds of near-duplicates (many candidates), exact duplicates / all zeros (every pair ties: the query groups
-    go to the exact fallback), sizes that are no multiple of the tiles, and inputs the f16 planes cannot carry (fallback for all)."""
+    go to the exact fallback), sizes that are no multiple of the tiles, inputs that are not finite (fallback for all), and -- round 5,
+    ADVICE r4 -- data of ANY magnitude: the planes carry a per-element power-of-two scale, so descriptors of norm 1e-3, 1e-5, 1e-12 or
+    3000, elements of different magnitude in one call and rows far smaller than their element's largest are ranked like unit ones."""
     rng = np.random.default_rng(7)
     b, n, nq = 3, 2000, 1500
     if case == "ragged":
@@ -146,13 +149,27 @@ def test_knn1_matrix_pipe_ranking_equals_exact_scan(case, oracle, dev):
     if case == "huge":
         ref *= 3000.0
         qry *= 3000.0
+    if case.startswith("scale"):
+        ref *= np.float32(case[5:])
+        qry *= np.float32(case[5:])
+    if case == "clustered1e-4":                          # near-duplicates at a small magnitude: candidates decided by the exact sum
+        proto = ref[:, :20]
+        ref = ((proto[:, rng.integers(0, 20, n)] + 1e-6 * rng.normal(size=(b, n, 32))) * 1e-4).astype(np.float32)
+        qry = ((proto[:, rng.integers(0, 20, nq)] + 1e-6 * rng.normal(size=(b, nq, 32))) * 1e-4).astype(np.float32)
+    if case == "mixed_elements":                         # one call, three magnitudes
+        for e, f in enumerate((1.0, 1e-4, 250.0)):
+            ref[e] *= np.float32(f)
+            qry[e] *= np.float32(f)
+    if case == "mixed_rows":                             # rows 1e-3 .. 1e-6 of their element's largest norm
+        ref *= (10.0 ** rng.uniform(-6, 0, size=(b, n, 1))).astype(np.float32)
+        qry *= (10.0 ** rng.uniform(-3, 0, size=(b, nq, 1))).astype(np.float32)
     if case == "nan":
         ref[0, 5, 3] = np.nan
         qry[1, 7, 0] = np.inf
     (gd, gi), (wd, wi) = _knn1_both(ref, qry, dev)
     assert np.array_equal(gi, wi)
     assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
-    if case in ("unit", "duplicates", "ragged", "tiny"):
+    if case in ("unit", "duplicates", "ragged", "tiny", "scale1e-3", "scale1e-5", "mixed_elements"):
         od, oi = oracle.knn(ref, qry, 1)
         assert np.array_equal(gi, oi)
 

@@ -1,3 +1,4 @@
+#!/bin/bash
 # Development aid: the same parity checks with the error bounds of the two matrix-pipe filters scaled down (builds with
 # -DNNF_EPS_SCALE / -DVOX_EPS_SCALE): how much margin do the shipped bounds have?
 cd "$(dirname "$0")/.."

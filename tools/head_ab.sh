@@ -1,3 +1,4 @@
+#!/bin/bash
 # Development aid: split-path step time with and without the fused descriptor head, alternating in one GPU session
 for i in 1 2; do
   for v in "" 1; do   # (fused | unfused)

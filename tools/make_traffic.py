@@ -14,17 +14,33 @@ fetch_csv, write_csv, bench_file, out = sys.argv[1:5]
 bench = json.load(open(bench_file))            # the uncompacted record (bench.py --detail-json)
 
 
+# kernels whose launch covers a FIXED number of units (one workgroup per patch): only the dispatches with the full-step grid count.
+# (Round 4 averaged one 64-patch accuracy-probe launch of each CNN kernel into the mean: traffic under-reported by 1/6 and 1/4.)
+FULL_GRID_ONLY = ('k_cyl_net_wg', 'k_cyl_net_h3', 'k_desc_head', 'k_patch_voxelize', 'k_select_patches_grid')
+dropped = collections.defaultdict(int)
+
+
 def per_launch(path, counter):
-    """mean counter value per dispatch and kernel (the profiled bench runs issue full-step launches only: BUF_NO_TRAFFIC=1 turns
-    the single-pair latency measurements of bench.py off)"""
-    agg, disp = collections.defaultdict(float), collections.defaultdict(set)
+    """mean counter value per dispatch and kernel over the FULL-STEP launches (BUF_NO_TRAFFIC=1 turns the single-pair latency
+    measurements and the 64-patch float64 probe of bench.py off; a dispatch of a fixed-unit kernel with a smaller grid than the
+    largest one seen is dropped anyway and counted in `launches_dropped`)"""
+    rows = collections.defaultdict(dict)              # kernel -> dispatch id -> [grid, value]
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
         k = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
-        agg[k] += float(r['Counter_Value'])
-        disp[k].add(r['Dispatch_Id'])
-    return {k: agg[k] / len(disp[k]) * 1024.0 for k in agg}, {k: len(v) for k, v in disp.items()}
+        e = rows[k].setdefault(r['Dispatch_Id'], [int(r['Grid_Size']), 0.0])
+        e[1] += float(r['Counter_Value'])
+    mean, n = {}, {}
+    for k, d in rows.items():
+        vals = list(d.values())
+        if k in FULL_GRID_ONLY:
+            g = max(v[0] for v in vals)
+            dropped[k] = max(dropped[k], sum(1 for v in vals if v[0] != g))
+            vals = [v for v in vals if v[0] == g]
+        mean[k] = sum(v[1] for v in vals) / len(vals) * 1024.0
+        n[k] = len(vals)
+    return mean, n
 
 
 fetch, n_f = per_launch(fetch_csv, 'FETCH_SIZE')
@@ -71,10 +87,10 @@ for k, (u, unit, alg) in units.items():
         continue
     hbm = 2.0 * fetch[k] + write[k]
     kernels[k] = dict(fetch_size_bytes_per_launch_raw=fetch[k], write_size_bytes_per_launch=write[k], hbm_bytes_per_launch=hbm,
-                      launches_profiled=n_f[k], units_per_launch=u, unit=unit, hbm_bytes_per_unit=hbm / u,
+                      launches_profiled=n_f[k], launches_dropped=dropped.get(k, 0), units_per_launch=u, unit=unit, hbm_bytes_per_unit=hbm / u,
                       algorithmic_bytes_per_unit=alg)
 json.dump(dict(source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on the bench.py command of '
-                      'the line in `bench`; per-dispatch means',
+                      'the line in `bench`; per-dispatch means over the full-step launches',
                correction='gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; '
                           'counters are in KB (1024 B)',
                bench=dict(value=bench['value'], config=cfg), kernels=kernels), open(out, 'w'), indent=1)

@@ -1,3 +1,4 @@
+#!/bin/bash
 # kernel-trace of a short bench run; prints which kernels run beside the cost-volume CNN (overlap of the matching stage)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

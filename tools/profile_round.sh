@@ -3,7 +3,7 @@
 # headline command, the two HBM-traffic PMC passes, SQ counters.  Everything lands in gpurun_out/<tag>/; copy what is to be
 # judged into profiles/.
 set -ex
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -14,6 +14,9 @@ tools/prof.sh ${tag}_fetch pmc "FETCH_SIZE" -- python3 bench.py --steps 2 --warm
 tools/prof.sh ${tag}_write pmc "WRITE_SIZE" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
 python tools/make_traffic.py $(find $R/gpurun_out/${tag}_fetch -name "*counter_collection.csv") $(find $R/gpurun_out/${tag}_write -name "*counter_collection.csv") $O/bench_pmc.json $O/traffic.json
 cp $O/traffic.json $R/profiles/traffic.json     # the bench lines below replay THIS build's measured bytes per unit
+tools/prof.sh ${tag}_instr pmc "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+python tools/make_instr.py $(find $R/gpurun_out/${tag}_instr -name "*counter_collection.csv") $O/bench_pmc.json $O/instr.json
+cp $O/instr.json $R/profiles/instr.json         # ... and price the vector-issue roofline with THIS build's instruction counts
 unset BUF_NO_TRAFFIC
 python bench.py --steps 20 --warmup 5 --detail-json $O/bench_detail.json > $O/bench.json 2> $O/bench.err
 python bench.py --workload stream > $O/stream.json 2>> $O/bench.err
@@ -26,5 +29,5 @@ tools/prof.sh ${tag}_sq pmc "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
 python tools/pmc_summary.py $(find $R/gpurun_out/${tag}_sq -name "*counter_collection.csv") > $O/pmc_sq.txt
 python tools/pmc_summary.py $(find $R/gpurun_out/${tag}_fetch -name "*counter_collection.csv") > $O/pmc_FETCH_SIZE.txt
 python tools/pmc_summary.py $(find $R/gpurun_out/${tag}_write -name "*counter_collection.csv") > $O/pmc_WRITE_SIZE.txt
-rm -rf $R/gpurun_out/${tag}_stats $R/gpurun_out/${tag}_fetch $R/gpurun_out/${tag}_write $R/gpurun_out/${tag}_sq
+rm -rf $R/gpurun_out/${tag}_instr $R/gpurun_out/${tag}_stats $R/gpurun_out/${tag}_fetch $R/gpurun_out/${tag}_write $R/gpurun_out/${tag}_sq
 ls -la $O

@@ -1,3 +1,4 @@
+#!/bin/bash
 # Development aid: bitwise A/B of the voxelisation kernel, in-tree library against build/libbuffer_old.so
 cd "$(dirname "$0")/.."
 BUF_LIB_PATH=$PWD/build/libbuffer_old.so python3 tools/vox_ab.py gen gpurun_out/vox_old.npz 2>&1 | tail -8
