@@ -25,6 +25,80 @@ def init(local_rank):
     return rank, world, dev, (dev if backend == 'nccl' else torch.device('cpu'))
 
 
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _gpu_numa_nodes(sys_root='/sys'):
+    """NUMA node of every AMD GPU in PCI-address order (the order HIP enumerates them in when no *_VISIBLE_DEVICES mask reorders),
+    read from sysfs: nothing here touches the GPU runtime."""
+    base = os.path.join(sys_root, 'bus', 'pci', 'devices')
+    nodes = []
+    try:
+        for bdf in sorted(os.listdir(base)):
+            d = os.path.join(base, bdf)
+            try:
+                if open(os.path.join(d, 'vendor')).read().strip() != '0x1002':
+                    continue
+                if not open(os.path.join(d, 'class')).read().strip().startswith(('0x0302', '0x0380', '0x0300', '0x1200')):
+                    continue
+                nodes.append(int(open(os.path.join(d, 'numa_node')).read().strip()))
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        pass
+    return nodes
+
+
+def rank_cpus(local_rank, local_world, allowed=None, sys_root='/sys'):
+    """The host cores of local rank `local_rank` of `local_world` on this node -> (sorted cpu list, numa node or None).
+    If sysfs names a NUMA node for as many GPUs as there are local ranks, a rank gets the cores of ITS GPU's node (shared evenly
+    with the other ranks of that node); otherwise the allowed cores are cut into `local_world` contiguous shares (sockets own
+    contiguous core ranges, so neighbouring ranks stay on one socket).  Pure host logic (tests/test_host_cpu.py)."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    local_world = max(int(local_world), 1)
+    local_rank = int(local_rank) % local_world
+    nodes = _gpu_numa_nodes(sys_root)
+    if len(nodes) >= local_world and all(n >= 0 for n in nodes[:local_world]):
+        node = nodes[local_rank]
+        try:
+            cpus = [c for c in _parse_cpulist(open(os.path.join(sys_root, 'devices', 'system', 'node', f'node{node}', 'cpulist')).read())
+                    if c in set(allowed)]
+        except OSError:
+            cpus = []
+        mates = [r for r in range(local_world) if nodes[r] == node]
+        if len(cpus) >= len(mates):
+            i, m = mates.index(local_rank), len(mates)
+            lo, hi = i * len(cpus) // m, (i + 1) * len(cpus) // m
+            return cpus[lo:hi], node
+    if len(allowed) >= local_world:
+        lo, hi = local_rank * len(allowed) // local_world, (local_rank + 1) * len(allowed) // local_world
+        return allowed[lo:hi], None
+    return allowed, None
+
+
+def pin_rank(local_rank=None, local_world=None):
+    """Pin this process (and every worker it forks later) to rank_cpus(...).  Call BEFORE anything touches the GPU and before
+    pools are forked.  -> dict(cpus=count, first=.., last=.., numa_node=..) for the per-rank diagnostics; {} when a single rank
+    owns the node (nothing to separate) or BUFFER_NO_PIN is set."""
+    local_rank = int(os.environ.get('LOCAL_RANK', 0)) if local_rank is None else local_rank
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', 1))) if local_world is None else local_world
+    if local_world <= 1 or os.environ.get('BUFFER_NO_PIN'):
+        return {}
+    cpus, node = rank_cpus(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return {}
+    return dict(cpus=len(cpus), first=cpus[0], last=cpus[-1], numa_node=node)
+
+
 def shard_indices(n_pairs, rank, world):
     """pair i is processed by rank i mod world."""
     return list(range(rank, n_pairs, world))

@@ -1,5 +1,7 @@
 """End-to-end registration of one fragment pair on one GPU (the inference branch of buffer.forward,
 models/BUFFER.py:231-333, with the collate stage of ThreeDMatch/dataloader.py:115-245 moved on device)."""
+import time
+
 import numpy as np
 import torch
 
@@ -21,6 +23,7 @@ class BufferPipeline:
         self.desc = PatchEmbedder(W, self.device, cfg)
         self.inlier = registration.CostVolume(W, self.device, cfg.azi_n, getattr(cfg, 'cnn_arith', 'f32'))
         self.limits = None if limits is None else [int(x) for x in limits]
+        self.host_wait_s = 0.0        # seconds the enqueueing thread spent blocked in the path's host round trips (diagnostics)
 
     def check_range(self):
         """cnn_arith='split': raise FloatingPointError if an activation of either CNN ever left the f16 range (the kernels set a device
@@ -161,7 +164,9 @@ class BufferPipeline:
         cloud_id = torch.repeat_interleave(torch.arange(2 * B, device=dev), cloud_len)
         axis_o = orient_axes(axis, pts0)                                                    # BUFFER.py:244-249 (row-wise)
         keep = ops.compact_greater(score[:, 0], cfg.keypts_th).long()                        # :255-259, ascending
-        counts = torch.bincount(cloud_id[keep], minlength=2 * B).cpu().numpy()
+        t0 = time.perf_counter()
+        counts = torch.bincount(cloud_id[keep], minlength=2 * B).cpu().numpy()           # host round trip 1 (candidate counts for FPS)
+        self.host_wait_s += time.perf_counter() - t0
         st = dict(inps=inps, seeds=seeds, perms=perms, B=B)
         if (counts == 0).any():                             # rare: some cloud has no point above the threshold
             st['starved'] = set(int(c) // 2 for c in np.nonzero(counts == 0)[0])
@@ -218,7 +223,9 @@ class BufferPipeline:
         mm = torch.nonzero(st['mutual'])                                                    # (pair, s) ascending
         pair_of, s_mid = mm[:, 0], mm[:, 1]
         t_mid = s_nn[pair_of, s_mid]
-        m_counts = torch.bincount(pair_of, minlength=B).cpu().numpy()
+        t0 = time.perf_counter()
+        m_counts = torch.bincount(pair_of, minlength=B).cpu().numpy()                     # host round trip 2 (match counts)
+        self.host_wait_s += time.perf_counter() - t0
         src_row = (2 * pair_of) * P + s_mid
         tgt_row = (2 * pair_of + 1) * P + t_mid
         ind = self.inlier.gathered(emb['equi'], src_row, tgt_row)      # BUFFER.py:291-292 rows 1..ele_n-2, gathered in-kernel

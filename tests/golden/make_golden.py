@@ -357,6 +357,160 @@ def make_kitti_fixture():
     sys.modules.pop('KITTI.config', None)
 
 
+def make_full_fixture(seed=4242, P=1500):
+    """F8 `full_1500.npz` (round 5): ONE synth.make_pair at the full 3DMatch shape through the reference's OWN
+    buffer.forward (models/BUFFER.py:231-333, unmodified) at the reference's 1500 keypoints: the collate of
+    ThreeDMatch/dataloader.py, Ref, Keypt, FPS, Desc x 2, mutual matching, Inlier, hypotheses, RANSAC, post_refinement.
+    Third-party operators are the stubs named at the top of this file; open3d's RANSAC is replaced by the numpy restatement of
+    the PRODUCT's deterministic sampler (oracle/pipeline_ref.ransac_kabsch, seed = the pair seed) so that the refined pose of
+    the reference's forward is comparable with the device pose.  Stored: the seed (inputs are regenerated by synth.make_pair;
+    float64 checksums guard the generator), neighbour limits, layer sizes, every keypoint index, match ids, `ind`, inlier
+    counts, the winner and its inlier list, RANSAC and refined poses, sampled rows of desc / equi / axis / score and float64
+    checksums of the full tensors."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    from oracle import pipeline_ref
+    from ThreeDMatch import dataloader as dl
+    cfg, model, _ = load_reference_model()
+    assert cfg.point.num_keypts == P
+    sample = synth.make_pair(seed)
+    limits = dl.calibrate_neighbors([sample], cfg, dl.collate_fn_descriptor)
+    batch = dl.collate_fn_descriptor([sample], cfg, limits)
+    rng = np.random.default_rng(seed)
+    perms = [rng.permutation(len(sample['src_fds_pts'])), rng.permutation(len(sample['tgt_fds_pts']))]
+    cap = dict(fps=[], desc=[], perm_calls=0)
+
+    # --- open3d surface of models/BUFFER.py:314-326 and utils/common.py:569-578 (third-party: stubbed) ---
+    class _PC:
+        points = None
+        colors = None
+
+    def ransac(pcd0, pcd1, corr, max_dist, est, n, checkers, criteria):
+        c = np.asarray(corr)
+        T, info = pipeline_ref.ransac_kabsch(np.asarray(pcd0.points), np.asarray(pcd1.points), c[:, 0], 4096, seed, max_dist,
+                                             cfg.match.similar_th)
+        cap.update(corr=c.copy(), init_pose=np.asarray(T, np.float64), ransac_info=info)
+        return types.SimpleNamespace(transformation=np.asarray(T, np.float64))
+
+    ident = lambda *a, **k: (a[0] if a else None)
+    reg = types.SimpleNamespace(registration_ransac_based_on_correspondence=ransac, TransformationEstimationPointToPoint=ident,
+                                CorrespondenceCheckerBasedOnEdgeLength=ident, CorrespondenceCheckerBasedOnDistance=ident,
+                                RANSACConvergenceCriteria=lambda *a: a)
+    o3d = types.SimpleNamespace(geometry=types.SimpleNamespace(PointCloud=_PC),
+                                utility=types.SimpleNamespace(Vector3dVector=lambda x: np.asarray(x, np.float64),
+                                                              Vector2iVector=lambda x: np.asarray(x, np.int64)),
+                                pipelines=types.SimpleNamespace(registration=reg))
+    import models.BUFFER as MB
+    import utils.common as UC
+    MB.o3d = o3d
+    UC.open3d = o3d
+
+    # --- spies: FPS inputs / outputs, the two Desc calls, the pinned shuffles of select_patches ---
+    pu = sys.modules['pointnet2_ops.pointnet2_utils']
+    orig_fps = pu.furthest_point_sample
+
+    def spy_fps(xyz, m):
+        idx = orig_fps(xyz, m)
+        cap['fps'].append((xyz[0].numpy().copy(), idx[0].numpy().copy()))
+        return idx
+
+    pu.furthest_point_sample = spy_fps
+    MB.pnt2.furthest_point_sample = spy_fps
+    orig_choice = np.random.choice
+
+    def pinned_choice(n, size=None, replace=True):
+        p = perms[cap['perm_calls']]
+        cap['perm_calls'] += 1
+        assert len(p) == n
+        return p
+
+    np.random.choice = pinned_choice
+    orig_desc = model.Desc.forward
+
+    def spy_desc(*a, **k):
+        out = orig_desc(*a, **k)
+        cap['desc'].append({kk: v.numpy().copy() for kk, v in out.items() if isinstance(v, torch.Tensor)})
+        return out
+
+    model.Desc.forward = spy_desc
+    orig_mm = model.mutual_matching
+
+    def spy_mm(a, b):
+        s_mids, t_mids = orig_mm(a, b)
+        cap['s_mids'], cap['t_mids'] = np.asarray(s_mids, np.int64), np.asarray(t_mids, np.int64)
+        return s_mids, t_mids
+
+    model.mutual_matching = spy_mm
+    hook = model.Inlier.register_forward_hook(lambda m, i, o: cap.update(ind=o.numpy().copy()))
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        pose, src_axis, tgt_axis = model(batch)
+        axis, eps, branch = model.Ref(batch)              # (again, for the sampled rows: forward does not return them)
+        score = model.Keypt(batch, branch)
+    print('F8 reference forward', round(time.time() - t0, 1), 's')
+    hook.remove()
+    np.random.choice = orig_choice
+    pu.furthest_point_sample = orig_fps
+    MB.pnt2.furthest_point_sample = orig_fps
+    model.Desc.forward = orig_desc
+    model.mutual_matching = orig_mm
+    assert cap['perm_calls'] == 2 and len(cap['fps']) == 2 and len(cap['desc']) == 2
+
+    n_src = int(batch['stack_lengths'][0][0])
+    sc = score[:, 0].numpy()
+    det = [np.nonzero(sc[:n_src] > cfg.point.keypts_th)[0], np.nonzero(sc[n_src:] > cfg.point.keypts_th)[0]]
+    kp_idx = [det[i][cap['fps'][i][1].astype(np.int64)] for i in range(2)]            # rows of the src / tgt halves of points[0]
+    pts0 = batch['points'][0].numpy()
+    for i, off in enumerate((0, n_src)):
+        assert np.array_equal(pts0[off + kp_idx[i]], cap['desc'][i]['patches'][:, -1] * 0 + pts0[off + kp_idx[i]])
+    # hypotheses / scoring as the forward computed them (recomputed here from the captured pieces: forward keeps them local)
+    s_mids, t_mids, ind = cap['s_mids'], cap['t_mids'], cap['ind']
+    kp = [torch.from_numpy(pts0[kp_idx[0]]), torch.from_numpy(pts0[n_src + kp_idx[1]])]
+    ss, tt = kp[0][s_mids], kp[1][t_mids]
+    import kornia.geometry.conversions as Convert
+    angle = torch.from_numpy(ind) * 2 * np.pi / cfg.patch.azi_n + 1e-6
+    aa = torch.zeros_like(ss)
+    aa[:, -1] = 1
+    azi_R = Convert.angle_axis_to_rotation_matrix(aa * angle[:, None])
+    Rh = torch.from_numpy(cap['desc'][1]['R'])[t_mids] @ azi_R @ torch.from_numpy(cap['desc'][0]['R'])[s_mids].transpose(-1, -2)
+    th = tt - (Rh @ ss.unsqueeze(-1)).squeeze()
+    diffs = torch.sqrt(torch.sum((ss[None] @ Rh.transpose(-1, -2) + th[:, None] - tt[None]) ** 2, dim=-1))
+    thr = torch.sqrt(torch.sum(ss ** 2, dim=-1)) * np.pi / cfg.patch.azi_n * cfg.match.inlier_th
+    inlier_num = torch.sum(diffs < thr[None], dim=-1)
+    best = int(torch.argmax(inlier_num))
+    assert np.array_equal(np.nonzero((diffs < thr[None])[best].numpy())[0], cap['corr'][:, 0])
+
+    r = np.random.default_rng(1)
+    rows_p = np.sort(r.choice(P, 256, replace=False))           # sampled keypoint rows (desc, R)
+    rows_e = rows_p[:48]                                        # ... of them for the 17.9 KB equivariant maps
+    rows_n = np.sort(r.choice(pts0.shape[0], 1024, replace=False))
+    f64 = lambda a: np.array([np.asarray(a, np.float64).sum(), np.abs(np.asarray(a, np.float64)).sum()])
+    out = dict(seed=seed, num_keypts=P, limits=np.asarray(limits, np.int32),
+               layer_sizes=np.array([p.shape[0] for p in batch['points']], np.int32), n_src=n_src,
+               in_checksums=np.stack([f64(sample[k]) for k in ('src_fds_pts', 'tgt_fds_pts', 'src_sds_pts', 'tgt_sds_pts')]),
+               in_shapes=np.array([sample[k].shape[0] for k in ('src_fds_pts', 'tgt_fds_pts', 'src_sds_pts', 'tgt_sds_pts')]),
+               relt_pose=np.asarray(sample['relt_pose'], np.float64),
+               kp_idx_src=kp_idx[0].astype(np.int32), kp_idx_tgt=kp_idx[1].astype(np.int32),
+               n_candidates=np.array([len(d) for d in det], np.int32),
+               s_mids=s_mids, t_mids=t_mids, ind=ind, inlier_num=inlier_num.numpy().astype(np.int32), best=best,
+               inlier_ind=cap['corr'][:, 0].astype(np.int32), init_pose=cap['init_pose'], pose=np.asarray(pose, np.float64),
+               ransac_info=np.array(cap['ransac_info'], np.int64),
+               rows_p=rows_p, rows_e=rows_e, rows_n=rows_n,
+               axis_rows=axis.numpy()[rows_n], eps_rows=eps.numpy()[rows_n], score_rows=score.numpy()[rows_n],
+               axis_sum=f64(axis.numpy()), eps_sum=f64(eps.numpy()), score_sum=f64(score.numpy()))
+    for i, nm in enumerate(('src', 'tgt')):
+        d = cap['desc'][i]
+        out.update({f'{nm}_desc_rows': d['desc'][rows_p], f'{nm}_equi_rows': d['equi'][rows_e], f'{nm}_R_rows': d['R'][rows_p],
+                    f'{nm}_rand_axis_rows': d['rand_axis'][rows_p], f'{nm}_desc_sum': f64(d['desc']), f'{nm}_equi_sum': f64(d['equi']),
+                    f'{nm}_patches_sum': f64(d['patches']), f'{nm}_equi_rowsum': np.asarray(d['equi'], np.float64).sum((1, 2, 3))})
+    np.savez_compressed(os.path.join(GOLD, 'full_1500.npz'), **out)
+    err = np.abs(np.asarray(pose) - sample['relt_pose']).max()
+    print('F8: layers', out['layer_sizes'], 'limits', limits, 'candidates', out['n_candidates'], 'matches', len(s_mids),
+          'best inliers', int(inlier_num[best]), 'ransac', cap['ransac_info'], '|pose - gt|', float(err),
+          'size', os.path.getsize(os.path.join(GOLD, 'full_1500.npz')))
+
+
 def make_rr_fixture():
     src = open(f'{REF}/ThreeDMatch/test.py').read()
     # only the function definitions above `if __name__` are needed; exec them in a module namespace
@@ -420,6 +574,12 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'kitti':     
     install_stubs()
     os.makedirs(GOLD, exist_ok=True)
     make_kitti_fixture()
+    sys.exit(0)
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'full':        # only F8 (leaves F1-F7 untouched)
+    cpu.build(ref=True)
+    install_stubs()
+    make_full_fixture()
     sys.exit(0)
 
 if __name__ == '__main__':

@@ -18,6 +18,9 @@ def main():
     ap.add_argument('--keypts', type=int, default=1500)
     ap.add_argument('--threads', type=int, default=0)
     ap.add_argument('--out', required=True)
+    ap.add_argument('--dataset', choices=['3dmatch', 'kitti'], default='3dmatch',
+                    help="kitti: synth.make_kitti_pair(2000 + i) (the pairs of bench.py --workload kitti), KITTI constants and weights")
+    ap.add_argument('--limits', default=None, help='neighbour limits a,b,c (default: calibrated here on pair 0)')
     a = ap.parse_args()
     if a.threads:
         os.environ['OMP_NUM_THREADS'] = str(a.threads)
@@ -28,13 +31,19 @@ def main():
     import torch
     if a.threads:
         torch.set_num_threads(a.threads)
-    from buffer_amd.config import THREEDMATCH
+    from buffer_amd import synth
+    from buffer_amd.config import KITTI, THREEDMATCH
     from buffer_amd.weights import load_weights
     from oracle import cpu, pipeline_ref, torch_ref
     from tests.eval_recall import make
-    cfg = replace(THREEDMATCH, num_keypts=a.keypts)
+    if a.dataset == 'kitti':
+        make = lambda i: synth.make_kitti_pair(2000 + i)      # noqa: E731
+    cfg = replace(KITTI if a.dataset == 'kitti' else THREEDMATCH, num_keypts=a.keypts)
     cpu.build(ref=False)
-    limits = [int(x) for x in torch_ref.calibrate_limits([make(0)])]
+    if a.limits:
+        limits = [int(x) for x in a.limits.split(',')]
+    else:
+        limits = [int(x) for x in torch_ref.calibrate_limits([make(0)], cfg.voxel_size_0, cfg.conv_radius)]
     W = {k: torch.from_numpy(v) for k, v in load_weights(cfg.weights).items()}
     out = dict(limits=np.array(limits))
     for i in [int(x) for x in a.pairs.split(',')]:

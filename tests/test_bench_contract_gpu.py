@@ -85,6 +85,14 @@ def test_bench_two_ranks_on_one_device_over_gloo(dev):
              env={'BENCH_BACKEND': 'gloo'})
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and 'cpu_baseline' not in d
     assert d['config']['parallelism'] == 'pair-sharded x2' and d['config']['gathered_poses'] == [6, 6]     # steps x pairs, per rank
+    # first-contact diagnostics: every rank's own clock, host share, set-up time, dominant-kernel time and core share
+    pr = d['config']['per_rank']
+    assert [r['rank'] for r in pr] == [0, 1]
+    for r in pr:
+        assert set(r) == {'rank', 'elapsed_s', 'host_busy_frac', 'setup_s', 'main_kernel_ms', 'pinned_cpus', 'numa_node'}
+        assert 0 < r['elapsed_s'] <= d['ms_per_step'] * 2e-3 + 1e-3 and 0 <= r['host_busy_frac'] <= 1.5 and r['main_kernel_ms'] > 0
+        assert r['pinned_cpus'] >= 1                       # two ranks on one node: each pinned to its own share of the cores
+    assert abs(max(r['elapsed_s'] for r in pr) - d['ms_per_step'] * 2e-3) < 1e-3
     assert abs(d['value'] - 2 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']                      # whole-job pairs / max-rank time
     assert d['config']['registered_ok'].startswith('6/6')
 

@@ -1,0 +1,100 @@
+"""Fixture F8 (`tests/golden/full_1500.npz`, written by tests/golden/make_golden.py `full`): ONE pair of the full 3DMatch
+shape through the REFERENCE'S OWN buffer.forward (models/BUFFER.py:231-333, imported unmodified) at the reference's 1500
+keypoints, against the HIP path on the same seeded pair with the same pinned permutations: the reference pins the device path
+at that size directly, not through the restated oracle/torch_ref.py."""
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+import torch
+
+from buffer_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'full_1500.npz')
+
+
+def _f64(a):
+    a = np.asarray(a, np.float64)
+    return np.array([a.sum(), np.abs(a).sum()])
+
+
+@pytest.fixture(scope='module')
+def full():
+    f = np.load(GOLD)
+    s = synth.make_pair(int(f['seed']))
+    keys = ('src_fds_pts', 'tgt_fds_pts', 'src_sds_pts', 'tgt_sds_pts')
+    assert [s[k].shape[0] for k in keys] == [int(x) for x in f['in_shapes']], 'synth.make_pair no longer regenerates the fixture pair'
+    assert np.array_equal(np.stack([_f64(s[k]) for k in keys]), f['in_checksums']), 'synth.make_pair no longer regenerates the fixture pair'
+    return f, s
+
+
+@pytest.mark.parametrize('arith', ['f32', 'split'])
+def test_hip_path_equals_the_reference_forward_at_1500_keypoints(full, dev, arith):
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.pipeline import BufferPipeline
+    from util import assert_close
+    f, s = full
+    seed, P = int(f['seed']), int(f['num_keypts'])
+    cfg = replace(THREEDMATCH, num_keypts=P, cnn_arith=arith)
+    pipe = BufferPipeline(cfg, dev)
+    assert pipe.calibrate([s]) == [int(x) for x in f['limits']]                    # calibrate_neighbors of the reference on this pair
+    rng = np.random.default_rng(seed)
+    perms = [rng.permutation(len(s['src_fds_pts'])), rng.permutation(len(s['tgt_fds_pts']))]
+    pose, d = pipe.register(pipe.upload(s), seed=seed, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
+    pyr = d['pyr']
+    assert [int(p.shape[0]) for p in pyr['points']] == [int(x) for x in f['layer_sizes']]
+    n_src = int(f['n_src'])
+    # point learner: sampled rows + float64 checksums of the whole tensors
+    rows = torch.from_numpy(f['rows_n']).to(dev)
+    assert_close(d['axis'][rows].cpu().numpy(), f['axis_rows'], 6e-5, 1.2e-5, 'F8 axis rows')
+    assert_close(d['eps'][rows].cpu().numpy(), f['eps_rows'], 1.3e-4, 2.6e-5, 'F8 eps rows')
+    assert_close(d['score'][rows].cpu().numpy(), f['score_rows'], 1e-3, 2e-4, 'F8 score rows')
+    for name in ('axis', 'eps', 'score'):
+        got, want = _f64(d[name].cpu().numpy()), f[name + '_sum']
+        assert abs(got[1] - want[1]) <= 2e-5 * want[1], (name, got, want)
+    # threshold + FPS: every keypoint index (bit-exact candidates -> bit-exact samples)
+    sc = d['score'][:, 0].cpu().numpy()
+    assert [int((sc[:n_src] > cfg.keypts_th).sum()), int((sc[n_src:] > cfg.keypts_th).sum())] == [int(x) for x in f['n_candidates']]
+    pts0 = pyr['points'][0].cpu().numpy()
+    want_kp = [pts0[f['kp_idx_src']], pts0[n_src + f['kp_idx_tgt']]]
+    for i in range(2):
+        assert np.array_equal(d['kpts'][i].cpu().numpy(), want_kp[i]), f'keypoints of cloud {i} differ from the reference forward'
+    # descriptors: sampled rows (+ equivariant maps of 48 of them) and a float64 sum per row of every map
+    rp, re = f['rows_p'], f['rows_e']
+    flips = 0
+    for i, nm in enumerate(('src', 'tgt')):
+        r = d['desc'][i]
+        assert np.array_equal(r['R'][rp].cpu().numpy().shape, f[f'{nm}_R_rows'].shape)
+        np.testing.assert_allclose(r['R'][rp].cpu().numpy(), f[f'{nm}_R_rows'], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r['rand_axis'][rp].cpu().numpy(), f[f'{nm}_rand_axis_rows'], rtol=0, atol=4e-6)
+        # a patch point ON a voxel ball's surface may fall on either side of it when the aligned coordinates differ in the last
+        # bit: such a row sees another sample in one voxel (bench.py cpu_baseline.parity: ~5 rows in 10^4); all others to 1e-4
+        dd = np.abs(r['desc'][rp].cpu().numpy() - f[f'{nm}_desc_rows']).max(1)
+        de = np.abs(r['equi'][re].cpu().numpy() - f[f'{nm}_equi_rows']).max((1, 2, 3))
+        flips += int((dd > 2e-5 + 1e-4 * 0.5).sum()) + int((de > 2e-5 + 1e-4).sum())
+        rs = r['equi'].double().sum((1, 2, 3)).cpu().numpy()
+        bad = np.abs(rs - f[f'{nm}_equi_rowsum']) > 1e-4 * np.abs(r['equi']).double().sum((1, 2, 3)).cpu().numpy()
+        print(f'F8 {nm} ({arith}): sampled desc rows max diff {np.median(dd):.2e} median / {dd.max():.2e} max; equi rows {de.max():.2e} max; '
+              f'maps whose float64 sum differs by > 1e-4 of their abs sum: {int(bad.sum())} / {P}')
+        assert bad.sum() <= 4
+        got, want = _f64(r['desc'].cpu().numpy()), f[f'{nm}_desc_sum']
+        assert abs(got[1] - want[1]) <= 1e-5 * want[1]
+    assert flips <= 2
+    # matching: ids, ind, all-vs-all inlier counts, the winner and its inliers
+    mg = set(zip(d['s_mids'].cpu().numpy().tolist(), d['t_mids'].cpu().numpy().tolist()))
+    mo = set(zip(f['s_mids'].tolist(), f['t_mids'].tolist()))
+    print(f'F8 ({arith}): matches {len(mg)} vs reference {len(mo)}, differing {len(mg ^ mo)}')
+    assert len(mg ^ mo) <= 2
+    if len(mg ^ mo) == 0:
+        assert_close(d['ind'].cpu().numpy(), f['ind'], 1e-4, 5e-4, 'F8 ind')
+        num = d['inlier_num'].cpu().numpy().astype(np.int64)
+        assert (np.abs(num - f['inlier_num']) <= 1).all() and (num != f['inlier_num']).mean() <= 0.01      # one borderline residual at most
+        assert int(d['best']) == int(f['best'])
+        assert np.array_equal(torch.nonzero(d['inlier_mask']).flatten().cpu().numpy(), f['inlier_ind'])
+    # the pose of the reference's forward (its RANSAC call bound to the restated sampler of the product, then ITS post_refinement)
+    got = pose.cpu().numpy().astype(np.float64)
+    dp = float(np.abs(got - f['pose']).max())
+    print(f'F8 ({arith}): |pose - reference forward| = {dp:.2e}; |pose - gt| = {np.abs(got - f["relt_pose"]).max():.2e}')
+    assert dp < 1e-4

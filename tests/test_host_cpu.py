@@ -199,6 +199,41 @@ def test_pair_sharding_eight_gloo_ranks_uneven_and_empty_shards(tmp_path):
         assert f"ok {r}" in o
 
 
+def test_rank_cpus_follow_the_numa_node_of_the_rank_s_gpu(tmp_path):
+    """dist.rank_cpus on a fake sysfs tree: 8 GPUs, four per socket, 2 x 64 cores -> every rank 16 cores of ITS socket, disjoint,
+    all cores used; without NUMA information: contiguous equal shares; more ranks than cores: everything shared."""
+    from buffer_amd import dist as bd
+    root = tmp_path / 'sys'
+    for i in range(8):
+        d = root / 'bus' / 'pci' / 'devices' / f'0000:{0x10 + 0x10 * i:02x}:00.0'
+        d.mkdir(parents=True)
+        (d / 'vendor').write_text('0x1002\n')
+        (d / 'class').write_text('0x120000\n')           # processing accelerator
+        (d / 'numa_node').write_text(f'{i // 4}\n')
+    nic = root / 'bus' / 'pci' / 'devices' / '0000:05:00.0'
+    nic.mkdir(parents=True)
+    (nic / 'vendor').write_text('0x15b3\n'); (nic / 'class').write_text('0x020000\n'); (nic / 'numa_node').write_text('0\n')
+    for n, cl in enumerate(('0-31,64-95', '32-63,96-127')):
+        d = root / 'devices' / 'system' / 'node' / f'node{n}'
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(cl + '\n')
+    allowed = list(range(128))
+    shares = [bd.rank_cpus(r, 8, allowed, str(root)) for r in range(8)]
+    assert [n for _, n in shares] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert all(len(c) == 16 for c, _ in shares)
+    assert sorted(c for cs, _ in shares for c in cs) == allowed
+    node0 = set(bd._parse_cpulist('0-31,64-95'))
+    assert all(set(cs) <= node0 for cs, _ in shares[:4]) and all(not (set(cs) & node0) for cs, _ in shares[4:])
+    # a cgroup that only allows socket 1: ranks of node 0 have no local core left -> contiguous shares of what is allowed
+    cs, node = bd.rank_cpus(0, 8, list(range(32, 64)), str(root))
+    assert node is None and cs == [32, 33, 34, 35]
+    # no sysfs information at all
+    plain = [bd.rank_cpus(r, 4, list(range(10)), str(tmp_path / 'none')) for r in range(4)]
+    assert [c for c, _ in plain] == [[0, 1], [2, 3, 4], [5, 6], [7, 8, 9]] and all(n is None for _, n in plain)
+    assert bd.rank_cpus(2, 8, [0, 1], str(tmp_path / 'none')) == ([0, 1], None)
+    assert bd.pin_rank(0, 1) == {}                        # a single rank owns the node: nothing to pin
+
+
 def test_shard_indices_cover_everything():
     from buffer_amd import dist as bd
     for n in (0, 1, 7, 1623):

@@ -1,5 +1,6 @@
 """BASELINE config #4: KITTI-shape LiDAR pair (ring pattern, 0.05 / 0.30 m voxels, KITTI constants and weights):
 device pyramid vs oracle collate, full registration vs the CPU oracle pipeline."""
+import os
 from dataclasses import replace
 
 import numpy as np
@@ -113,3 +114,72 @@ def test_cross_dataset_presets(kitti_pair, dev):
     rre = np.degrees(np.arccos(np.clip((np.trace(pose[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
     print('3DMatch->KITTI on the synthetic scan pair: RTE', rte, 'RRE', rre)
     assert np.isfinite(pose).all() and rte < 0.6 and rre < 5.0, (rte, rre)
+
+
+KITTI_PARITY_PAIRS = [int(x) for x in os.environ.get('BUF_KITTI_PARITY_PAIRS', '0,1,2,3,4,5,6,7').split(',')]
+
+
+def test_kitti_hip_equals_cpu_oracle_pair_by_pair(dev, oracle):
+    """Round 5: the KITTI-shape pairs of `bench.py --workload kitti` (synth.make_kitti_pair(2000 + i), 1500
+    keypoints, KITTI constants / weights, no refinement) through the HIP path AND through the CPU oracle in worker processes:
+    keypoints identical, mutual matches identical (at most 2 per pair where two descriptors tie to fp32 round-off), pose within
+    1e-4 (rotation entries; translation relative to the 80 m extent), and the same success flag under BOTH criteria: the
+    reference's own (KITTI/test.py:66-72 as coded: RTE < 0.3 m and RRE < 1 deg) and the bench's (RTE < 0.3 m, RRE < 15 deg).
+    A pair the bench counts as failed must fail in the oracle too: the failure is the model's on that scan pair, not a kernel's."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    from buffer_amd.config import KITTI
+    from buffer_amd.evaluate import dgr_success
+    from buffer_amd.pipeline import BufferPipeline
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = replace(KITTI, num_keypts=1500)
+    ids = KITTI_PARITY_PAIRS
+    pipe = BufferPipeline(cfg, dev)
+    limits = pipe.calibrate([synth.make_kitti_pair(1000)])          # bench.py's calibration pair
+    nproc = min(8, len(ids))
+    threads = max(1, (os.cpu_count() or 8) // nproc)
+    tmp = tempfile.mkdtemp(prefix='buf_kitti_')
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+    workers = []
+    for w in range(nproc):
+        out = os.path.join(tmp, f'oracle_{w}.npz')
+        cmd = [sys.executable, os.path.join(root, 'tests', 'oracle_worker.py'), '--dataset', 'kitti', '--pairs', ','.join(map(str, ids[w::nproc])),
+               '--keypts', '1500', '--threads', str(threads), '--limits', ','.join(map(str, limits)), '--out', out]
+        workers.append((subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), out))
+    got = {}
+    for i in ids:
+        s = synth.make_kitti_pair(2000 + i)
+        rng = np.random.default_rng(i)
+        perms = [rng.permutation(len(s['src_fds_pts'])), rng.permutation(len(s['tgt_fds_pts']))]
+        pose, d = pipe.register(pipe.upload(s), seed=i, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
+        got[i] = dict(pose=pose.cpu().numpy().astype(np.float64), kp=[k.cpu().numpy() for k in d['kpts']], smids=d['s_mids'].cpu().numpy(),
+                      tmids=d['t_mids'].cpu().numpy(), gt=s['relt_pose'], extent=float(np.abs(s['src_fds_pts']).max()))
+        # the batched form the bench runs gives the pose of the pair-by-pair call (keyed permutations there: compared on the flags below)
+    want = {}
+    for p, out in workers:
+        log = p.communicate(timeout=1500)[0].decode()
+        assert p.returncode == 0, log[-3000:]
+        z = np.load(out)
+        want.update({k: z[k] for k in z.files})
+    rows = []
+    for i in ids:
+        g = got[i]
+        assert np.array_equal(g['kp'][0], want[f'kp0_{i}']) and np.array_equal(g['kp'][1], want[f'kp1_{i}']), f'KITTI pair {i}: keypoints differ'
+        sym = len(set(zip(g['smids'].tolist(), g['tmids'].tolist())) ^ set(zip(want[f'smids_{i}'].tolist(), want[f'tmids_{i}'].tolist())))
+        wp = want[f'pose_{i}']
+        dR, dt = float(np.abs(g['pose'][:3, :3] - wp[:3, :3]).max()), float(np.abs(g['pose'][:3, 3] - wp[:3, 3]).max())
+        ref_g, rte, rre = dgr_success(g['pose'], g['gt'], 0.3, 1.0)       # KITTI/test.py:66-72 as coded
+        ref_o, rte_o, rre_o = dgr_success(wp, g['gt'], 0.3, 1.0)
+        rows.append(dict(pair=i, seed=2000 + i, matches=int(len(g['smids'])), matches_differing=sym, dR=dR, dt=dt, rte=rte, rre=rre,
+                         rte_oracle=rte_o, rre_oracle=rre_o, ok_reference_criterion=ref_g, ok_reference_criterion_oracle=ref_o,
+                         ok_bench_criterion=dgr_success(g['pose'], g['gt'], 0.3, 15.0)[0],
+                         ok_bench_criterion_oracle=dgr_success(wp, g['gt'], 0.3, 15.0)[0], extent=g['extent']))
+    print('KITTI_PARITY ' + json.dumps(dict(limits=limits, pairs=rows)))
+    for r in rows:
+        assert r['matches_differing'] <= 2, r
+        assert r['ok_reference_criterion'] == r['ok_reference_criterion_oracle'] and r['ok_bench_criterion'] == r['ok_bench_criterion_oracle'], r
+        if r['matches_differing'] == 0:
+            assert r['dR'] < 1e-4 and r['dt'] < 1e-4 * r['extent'], r
+    assert sum(r['matches_differing'] == 0 for r in rows) >= len(rows) - 2
