@@ -48,9 +48,9 @@ def test_hip_path_equals_the_reference_forward_at_1500_keypoints(full, dev, arit
     n_src = int(f['n_src'])
     # point learner: sampled rows + float64 checksums of the whole tensors
     rows = torch.from_numpy(f['rows_n']).to(dev)
-    assert_close(d['axis'][rows].cpu().numpy(), f['axis_rows'], 6e-5, 1.2e-5, 'F8 axis rows')
-    assert_close(d['eps'][rows].cpu().numpy(), f['eps_rows'], 1.3e-4, 2.6e-5, 'F8 eps rows')
-    assert_close(d['score'][rows].cpu().numpy(), f['score_rows'], 1e-3, 2e-4, 'F8 score rows')
+    assert_close(d['axis'][rows].cpu().numpy(), f['axis_rows'], 3.6e-5, 7.2e-6, 'F8 axis rows')
+    assert_close(d['eps'][rows].cpu().numpy(), f['eps_rows'], 3.6e-5, 7.3e-6, 'F8 eps rows')
+    assert_close(d['score'][rows].cpu().numpy(), f['score_rows'], 5.6e-4, 1.1e-4, 'F8 score rows')
     for name in ('axis', 'eps', 'score'):
         got, want = _f64(d[name].cpu().numpy()), f[name + '_sum']
         assert abs(got[1] - want[1]) <= 2e-5 * want[1], (name, got, want)
@@ -70,12 +70,12 @@ def test_hip_path_equals_the_reference_forward_at_1500_keypoints(full, dev, arit
         np.testing.assert_allclose(r['R'][rp].cpu().numpy(), f[f'{nm}_R_rows'], rtol=0, atol=2e-6)
         np.testing.assert_allclose(r['rand_axis'][rp].cpu().numpy(), f[f'{nm}_rand_axis_rows'], rtol=0, atol=4e-6)
         # a patch point ON a voxel ball's surface may fall on either side of it when the aligned coordinates differ in the last
-        # bit: such a row sees another sample in one voxel (bench.py cpu_baseline.parity: ~5 rows in 10^4); all others to 1e-4
+        # bit: such a row sees another sample in one voxel (bench.py cpu_baseline.parity: ~5 rows in 10^4); all others to 4e-6 / 5e-6
         dd = np.abs(r['desc'][rp].cpu().numpy() - f[f'{nm}_desc_rows']).max(1)
         de = np.abs(r['equi'][re].cpu().numpy() - f[f'{nm}_equi_rows']).max((1, 2, 3))
-        flips += int((dd > 2e-5 + 1e-4 * 0.5).sum()) + int((de > 2e-5 + 1e-4).sum())
+        flips += int((dd > 4e-6).sum()) + int((de > 5e-6).sum())         # (2 x the largest difference measured: 1.8e-6 / 2.4e-6)
         rs = r['equi'].double().sum((1, 2, 3)).cpu().numpy()
-        bad = np.abs(rs - f[f'{nm}_equi_rowsum']) > 1e-4 * np.abs(r['equi']).double().sum((1, 2, 3)).cpu().numpy()
+        bad = np.abs(rs - f[f'{nm}_equi_rowsum']) > 1e-4 * r['equi'].abs().double().sum((1, 2, 3)).cpu().numpy()
         print(f'F8 {nm} ({arith}): sampled desc rows max diff {np.median(dd):.2e} median / {dd.max():.2e} max; equi rows {de.max():.2e} max; '
               f'maps whose float64 sum differs by > 1e-4 of their abs sum: {int(bad.sum())} / {P}')
         assert bad.sum() <= 4
@@ -88,7 +88,7 @@ def test_hip_path_equals_the_reference_forward_at_1500_keypoints(full, dev, arit
     print(f'F8 ({arith}): matches {len(mg)} vs reference {len(mo)}, differing {len(mg ^ mo)}')
     assert len(mg ^ mo) <= 2
     if len(mg ^ mo) == 0:
-        assert_close(d['ind'].cpu().numpy(), f['ind'], 1e-4, 5e-4, 'F8 ind')
+        assert_close(d['ind'].cpu().numpy(), f['ind'], 1e-4, 6e-5, 'F8 ind')
         num = d['inlier_num'].cpu().numpy().astype(np.int64)
         assert (np.abs(num - f['inlier_num']) <= 1).all() and (num != f['inlier_num']).mean() <= 0.01      # one borderline residual at most
         assert int(d['best']) == int(f['best'])
