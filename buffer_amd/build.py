@@ -31,11 +31,20 @@ def build(force=False, verbose=False, out=None):
            # MFMA accumulators stay VGPRs: k_cyl_net_wg parks held outputs in AGPRs by hand (no scratch); with AGPR-form
            # accumulators the compiler rotates them through v_accvgpr copies inside the pass-0 loops (+3 % on that kernel)
            "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+           # no packed-fp32 vector instructions: beside another wavefront's f16 MFMA they return wrong values in lanes 0..15 now and
+           # then (round 5: tools/race_probe3.py, profiles/r05_packed_fp32_hazard.txt); nothing got slower without them
+           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
            "-o", out, SRC] + os.environ.get("BUF_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    # (the host half of the compilation does not know the device feature and says so once per file: not a diagnostic of ours)
+    err = "\n".join(ln for ln in r.stderr.splitlines() if "is not a recognized feature for this target" not in ln)
+    if err.strip():
+        print(err, file=sys.stderr)
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
     return out
 
 

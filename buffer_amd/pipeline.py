@@ -1,5 +1,6 @@
 """End-to-end registration of one fragment pair on one GPU (the inference branch of buffer.forward,
 models/BUFFER.py:231-333, with the collate stage of ThreeDMatch/dataloader.py:115-245 moved on device)."""
+import os
 import time
 
 import numpy as np
@@ -114,7 +115,7 @@ class BufferPipeline:
         dev = self.device
         main = torch.cuda.current_stream(dev)
         if not hasattr(self, '_kp_stream'):
-            self._kp_stream = torch.cuda.Stream(device=dev, priority=-1)
+            self._kp_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('BUF_KP_STREAM_PRIORITY', -1)))
         side = self._kp_stream
         seeds = [None] * len(batches) if seeds is None else seeds
         out = []

@@ -30,6 +30,26 @@ def test_library_exports_every_declared_symbol():
         assert re.search(rf"\bT {name}\b", nm), f"{name} is not an exported text symbol"
 
 
+def test_library_holds_no_packed_fp32_instruction(tmp_path):
+    """Round 5: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 return wrong values in 16 lanes now and then while another wavefront of
+    the SIMD issues f16 MFMAs (tests/test_concurrency_gpu.py, profiles/r05_packed_fp32_hazard.txt): the build turns them off
+    (-target-feature -packed-fp32-ops).  Disassemble the gfx950 code object of the in-tree library and look."""
+    import shutil
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('no llvm-objdump')
+    from buffer_amd import _lib
+    so = str(tmp_path / 'lib.so')
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, '--offloading', so], capture_output=True, cwd=str(tmp_path), check=True)
+    co = [f for f in os.listdir(tmp_path) if 'gfx950' in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    asm = subprocess.run([objdump, '-d', str(tmp_path / co[0])], capture_output=True, text=True, check=True).stdout
+    assert 'v_mfma_f32_16x16x32_f16' in asm and 'k_vn_gather6_lds' in asm            # the right object, disassembled
+    packed = re.findall(r'v_pk_(?:mul|add|fma)_f32', asm)
+    assert not packed, f'{len(packed)} packed-fp32 instructions in libbuffer_hip.so: build with -target-feature -packed-fp32-ops'
+
+
 def test_ops_fail_loudly_without_device():
     from buffer_amd import ops, _lib
     if torch.cuda.is_available():
