@@ -248,6 +248,56 @@ def test_winograd_and_direct_forms_against_float64(W, dev):
     split.check_range()                                                      # no activation left the f16 range
 
 
+def _stack64(x, layers, dev):
+    h = x.double().reshape(-1, layers[0][0].shape[1], 7, 20)
+    for w, b, relu in layers:                                                # circular azimuth, zero elevation, float64
+        h = torch.cat([h[..., -1:], h, h[..., :1]], -1)
+        h = torch.nn.functional.pad(h, (0, 0, 1, 1))
+        h = torch.nn.functional.conv2d(h, torch.from_numpy(np.ascontiguousarray(w)).double().to(dev), torch.from_numpy(np.ascontiguousarray(b)).double().to(dev))
+        h = torch.relu(h) if relu else h
+    return h
+
+
+@pytest.mark.parametrize("case", ["wide_inputs", "sparse_maps", "wide_weights", "tiny_everything"])
+def test_cnn_kernels_with_wide_dynamic_range_inside_one_contraction(W, dev, case):
+    """both descriptor-CNN kernels against the float64 stack where ONE contraction mixes operands of very
+    different magnitude -- inputs spread over 1e-6 .. 1e3 element by element, maps with 90 % exact zeros (post-ReLU sparsity),
+    synthetic weights spread over 1e-6 .. 3e-2, and a stack whose activations sit in the f16 SUBNORMAL range (inputs ~1e-6: the
+    `hi` plane of the split form is subnormal there and the scaled low part carries the value).  Same bound as the unit-range test:
+    error < 1e-5 of the output scale for both, split-f16 not more than 1.5 x the fp32 kernel's error."""
+    from buffer_amd import ops
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    pe = PatchEmbedder(W, dev, THREEDMATCH)
+    g = torch.Generator(device='cpu').manual_seed(11)
+    layers = pe.layers
+    x = torch.relu(torch.randn((64, 48, 140), generator=g))
+    if case == "wide_inputs":
+        x = x * 10.0 ** (torch.rand((64, 48, 140), generator=g) * 9 - 6)          # 1e-6 .. 1e3 inside every 3 x 3 x 48 window
+    elif case == "sparse_maps":
+        x = x * (torch.rand((64, 48, 140), generator=g) < 0.1) * 10.0 ** (torch.rand((64, 48, 140), generator=g) * 4 - 2)
+    elif case == "tiny_everything":
+        x = x * 1e-6                                                               # every activation below the f16 normal range
+    elif case == "wide_weights":
+        rng = np.random.default_rng(3)
+        layers = []
+        for (w, b, relu) in pe.layers:
+            mag = 10.0 ** rng.uniform(-6, np.log10(3e-2), size=w.shape)
+            layers.append(((mag * rng.choice([-1.0, 1.0], size=w.shape)).astype(np.float32),
+                           (10.0 ** rng.uniform(-6, -2, size=b.shape)).astype(np.float32), relu))
+        x = x * 10.0 ** (torch.rand((64, 48, 140), generator=g) * 5 - 2)          # 1e-2 .. 1e3
+    x = x.to(dev)
+    h = _stack64(x, layers, dev)
+    scale = h.abs().max().item()
+    wg, split = ops.CylindricalNet(layers, dev), ops.CylindricalNetSplit(layers, dev)
+    ew = (wg(x).double() - h).abs().max().item() / scale
+    es = (split(x).double() - h).abs().max().item() / scale
+    split.check_range()
+    print(f'{case}: output scale {scale:.3e}; error vs float64 / scale: fp32 Winograd kernel {ew:.2e}, split-f16 kernel {es:.2e}')
+    assert ew < 1e-5 and es < 1e-5
+    assert es <= 1.5 * ew + 1e-7
+
+
 def test_fused_descriptor_head_vs_library(W, dev):
     """k_desc_head (attention pooling + both normalisations in one launch) == the torch restatement
     (patch_embedder.py:81-84) on conv-net outputs, on an all-zero map (eps clamps) and on P = 0."""
