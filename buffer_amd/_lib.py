@@ -70,6 +70,9 @@ _SIGNATURES = {
     "buf_vn_pointwise": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "buf_gather_max": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "buf_vn_std": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "buf_score_head_ws_bytes": (_sz, [_i, _i]),
+    "buf_score_head": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f,
+                            _vp, _vp, _sz, _vp]),
     "buf_patch_voxelize_ws_bytes": (_sz, [_i]),
     "buf_patch_voxelize": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _sz, _vp]),

@@ -589,3 +589,220 @@ extern "C" int buf_row_linear(const float* x, int n, int cin, int cout, const fl
     BUF_LAUNCH_CHECK();
     return BUF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// One score head (models/point_learner.py:128-136,163-171; vn_layers.py:169-222) in 7 launches instead of 17 (round 5):
+//   k_score_head_a      VNStdFeature (vn1 -> vn2 -> vn_lin -> x . z) + Conv1d 30 -> 20           (was 3 x k_vn_pointwise, k_vn_std, k_row_linear)
+//   k_seg_sum / k_seg_sq   the InstanceNorm statistics (fixed 64-way split per segment, fp64)       (was 4 kernels per norm)
+//   k_row_linear_norm   normalise on load + Conv1d 20 -> 10, then again for 10 -> 1 + activation   (was k_seg_apply + k_row_linear)
+// Every value is formed by the operations of the separate kernels in their order (k_vn_pointwise's fp64 dot products rounded
+// once, vn_epilogue, k_vn_std's three-term sums, k_row_linear's ascending-channel sums, k_seg_partial / k_seg_final's chunked
+// fp64 sums, k_seg_apply's (x - mean) / sqrtf(var + eps)): bit-identical to the 17-launch path (tests/test_model_gpu.py).
+#define SH_C 10        // input vector channels (x f32[n, 30])
+#define SH_C1 10       // vn1
+#define SH_C2 5        // vn2
+#define SH_CZ 3        // vn_lin
+#define SH_H1 20       // Conv1d 30 -> 20
+struct ScoreHeadParams {
+    VnParams vn1, vn2;
+    const float* lin;       // [3][5] map_to_feat of vn_lin (linear only)
+    const float* w0;        // [20][30]
+    const float* b0;        // [20]
+};
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void sh_vn_layer(const float (&in)[CIN * 3], const float* __restrict__ wf, const float* __restrict__ wd,
+                                            const float* __restrict__ bsc, const float* __restrict__ bsh, bool has_bn, float slope,
+                                            float (&out)[COUT * 3])
+{
+#pragma unroll
+    for (int o = 0; o < COUT; o++) {
+        double Px = 0, Py = 0, Pz = 0, Dx = 0, Dy = 0, Dz = 0;
+#pragma unroll
+        for (int c = 0; c < CIN; c++) {
+            double a = wf[o * CIN + c], b = wd[o * CIN + c];
+            double fx = in[3 * c], fy = in[3 * c + 1], fz = in[3 * c + 2];
+            Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
+        }
+        float px = (float)Px, py = (float)Py, pz = (float)Pz, dx = (float)Dx, dy = (float)Dy, dz = (float)Dz;
+        vn_epilogue(px, py, pz, dx, dy, dz, has_bn, has_bn ? bsc[o] : 0.f, has_bn ? bsh[o] : 0.f, slope);
+        out[3 * o] = px; out[3 * o + 1] = py; out[3 * o + 2] = pz;
+    }
+}
+
+__global__ void __launch_bounds__(128) k_score_head_a(const float* __restrict__ x, int n, ScoreHeadParams H, float* __restrict__ h1)
+{
+    __shared__ float w1f[SH_C1 * SH_C], w1d[SH_C1 * SH_C], w2f[SH_C2 * SH_C1], w2d[SH_C2 * SH_C1], wl[SH_CZ * SH_C2];
+    __shared__ float bn[2 * SH_C1 + 2 * SH_C2], w0[SH_H1 * 3 * SH_C], b0[SH_H1];
+    const bool bn1 = H.vn1.bn_scale != nullptr, bn2 = H.vn2.bn_scale != nullptr;
+    for (int t = threadIdx.x; t < SH_C1 * SH_C; t += 128) { w1f[t] = H.vn1.wf[t]; w1d[t] = H.vn1.wd[t]; }
+    for (int t = threadIdx.x; t < SH_C2 * SH_C1; t += 128) { w2f[t] = H.vn2.wf[t]; w2d[t] = H.vn2.wd[t]; }
+    for (int t = threadIdx.x; t < SH_CZ * SH_C2; t += 128) wl[t] = H.lin[t];
+    for (int t = threadIdx.x; t < SH_C1; t += 128) { bn[t] = bn1 ? H.vn1.bn_scale[t] : 0.f; bn[SH_C1 + t] = bn1 ? H.vn1.bn_shift[t] : 0.f; }
+    for (int t = threadIdx.x; t < SH_C2; t += 128) { bn[2 * SH_C1 + t] = bn2 ? H.vn2.bn_scale[t] : 0.f; bn[2 * SH_C1 + SH_C2 + t] = bn2 ? H.vn2.bn_shift[t] : 0.f; }
+    for (int t = threadIdx.x; t < SH_H1 * 3 * SH_C; t += 128) w0[t] = H.w0[t];
+    for (int t = threadIdx.x; t < SH_H1; t += 128) b0[t] = H.b0[t];
+    __syncthreads();
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) return;
+    float xv[3 * SH_C], y1[3 * SH_C1], y2[3 * SH_C2], z[3 * SH_CZ];
+#pragma unroll
+    for (int c = 0; c < 3 * SH_C; c++) xv[c] = x[(size_t)i * 3 * SH_C + c];
+    sh_vn_layer<SH_C, SH_C1>(xv, w1f, w1d, bn, bn + SH_C1, bn1, H.vn1.slope, y1);
+    sh_vn_layer<SH_C1, SH_C2>(y1, w2f, w2d, bn + 2 * SH_C1, bn + 2 * SH_C1 + SH_C2, bn2, H.vn2.slope, y2);
+#pragma unroll
+    for (int o = 0; o < SH_CZ; o++) {                           // vn_lin: plain VNLinear (k_vn_pointwise with wd == null)
+        double Px = 0, Py = 0, Pz = 0;
+#pragma unroll
+        for (int c = 0; c < SH_C2; c++) {
+            double a = wl[o * SH_C2 + c];
+            Px += a * (double)y2[3 * c]; Py += a * (double)y2[3 * c + 1]; Pz += a * (double)y2[3 * c + 2];
+        }
+        z[3 * o] = (float)Px; z[3 * o + 1] = (float)Py; z[3 * o + 2] = (float)Pz;
+    }
+    float hs[3 * SH_C];                                          // k_vn_std: x_std[c*3+k] = sum_j x[c,j] z[k,j]
+#pragma unroll
+    for (int c = 0; c < SH_C; c++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) hs[3 * c + k] = xv[3 * c] * z[3 * k] + xv[3 * c + 1] * z[3 * k + 1] + xv[3 * c + 2] * z[3 * k + 2];
+#pragma unroll 4
+    for (int o = 0; o < SH_H1; o++) {                           // k_row_linear: ascending channel, then the bias
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3 * SH_C; c++) acc += w0[o * 3 * SH_C + c] * hs[c];
+        acc += 0.f; acc += 0.f;                                  // (k_row_linear runs its loop to 32 channels with zeros past cin)
+        acc += b0[o];
+        h1[(size_t)i * SH_H1 + o] = acc;
+    }
+}
+
+// pass 1 / pass 2 of the InstanceNorm statistics: k_seg_partial<false> as it is; the second pass forms the mean from the first pass's
+// partial sums itself (k_seg_final's sum in k_seg_final's order) instead of waiting for a kernel that does
+__global__ void __launch_bounds__(256) k_seg_sq(const float* __restrict__ x, const int* __restrict__ seg_off, int c,
+                                              const double* __restrict__ partial1, double* __restrict__ partial2)
+{
+    __shared__ double sh[256];
+    __shared__ float mu_s[ROWLIN_MAX];
+    const int seg = blockIdx.x, split = blockIdx.y;
+    const int lo = seg_off[seg], hi = seg_off[seg + 1];
+    if (threadIdx.x < c) {
+        double s = 0.0;
+        for (int k = 0; k < SEG_SPLITS; k++) s += partial1[((size_t)seg * SEG_SPLITS + k) * c + threadIdx.x];
+        mu_s[threadIdx.x] = hi > lo ? (float)(s / (double)(hi - lo)) : 0.f;
+    }
+    __syncthreads();
+    const int chunk = (hi - lo + SEG_SPLITS - 1) / SEG_SPLITS;
+    const int r0 = lo + split * chunk, r1 = min(r0 + chunk, hi);
+    const int rpi = blockDim.x / c, ch = threadIdx.x % c, rr = threadIdx.x / c;
+    const float mu = mu_s[ch];
+    double acc = 0.0;
+    for (int r = r0 + rr; r < r1; r += rpi) {
+        float v = x[(size_t)r * c + ch] - mu;
+        acc += (double)v * (double)v;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < c) {
+        double t = 0.0;
+        for (int k = 0; k < rpi; k++) t += sh[k * c + threadIdx.x];
+        partial2[((size_t)seg * SEG_SPLITS + split) * c + threadIdx.x] = t;
+    }
+}
+
+// k_seg_apply + k_row_linear in one: a block's 256 rows touch a few segments; their mean / variance come from the partial sums
+#define RLN_SEGS 8
+__global__ void __launch_bounds__(256) k_row_linear_norm(const float* __restrict__ x, int n, int cin, int cout, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int act, const int* __restrict__ seg_off, int nseg,
+                                                       const double* __restrict__ partial1, const double* __restrict__ partial2, float eps,
+                                                       float* __restrict__ out)
+{
+    __shared__ float ws[ROWLIN_MAX * ROWLIN_MAX + ROWLIN_MAX];
+    __shared__ float mu_s[RLN_SEGS * ROWLIN_MAX], var_s[RLN_SEGS * ROWLIN_MAX];
+    for (int i = threadIdx.x; i < cout * cin; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < cout; i += 256) ws[ROWLIN_MAX * ROWLIN_MAX + i] = b[i];
+    const int row0 = blockIdx.x * 256, rowl = min(row0 + 255, n - 1);
+    const int seg0 = find_elem(seg_off, nseg, row0), seg1 = find_elem(seg_off, nseg, rowl);
+    for (int base = seg0; base <= seg1; base += RLN_SEGS) {          // (more than RLN_SEGS segments inside 256 rows: in rounds)
+        __syncthreads();
+        for (int t = threadIdx.x; t < RLN_SEGS * cin; t += 256) {
+            const int seg = base + t / cin, ch = t % cin;
+            if (seg > seg1) continue;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < SEG_SPLITS; k++) s1 += partial1[((size_t)seg * SEG_SPLITS + k) * cin + ch];
+            for (int k = 0; k < SEG_SPLITS; k++) s2 += partial2[((size_t)seg * SEG_SPLITS + k) * cin + ch];
+            const int cnt = seg_off[seg + 1] - seg_off[seg];
+            mu_s[t] = cnt > 0 ? (float)(s1 / (double)cnt) : 0.f;
+            var_s[t] = cnt > 0 ? (float)(s2 / (double)cnt) : 0.f;
+        }
+        __syncthreads();
+        const int row = row0 + threadIdx.x;
+        if (row >= n) continue;
+        const int seg = find_elem(seg_off, nseg, row);
+        if (seg < base || seg >= base + RLN_SEGS) continue;
+        const float* mu = mu_s + (seg - base) * cin;
+        const float* var = var_s + (seg - base) * cin;
+        float xv[ROWLIN_MAX];
+#pragma unroll
+        for (int c = 0; c < ROWLIN_MAX; c++) xv[c] = c < cin ? (x[(size_t)row * cin + c] - mu[c]) / sqrtf(var[c] + eps) : 0.f;
+        for (int o = 0; o < cout; o++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < ROWLIN_MAX; c++) acc += c < cin ? ws[o * cin + c] * xv[c] : 0.f;
+            acc += ws[ROWLIN_MAX * ROWLIN_MAX + o];
+            if (act == 1) acc = 1.f / (1.f + expf(-acc));
+            else if (act == 2) acc = acc > 20.f ? acc : log1pf(expf(acc));
+            out[(size_t)row * cout + o] = acc;
+        }
+    }
+}
+
+extern "C" size_t buf_score_head_ws_bytes(int n, int nseg)
+{
+    if (n < 0 || nseg <= 0) return 256;
+    return 1024 + sizeof(int) * ((size_t)nseg + 1) + 2 * (sizeof(double) * (size_t)nseg * SH_H1 * SEG_SPLITS + 256) +
+           sizeof(float) * (size_t)(n > 0 ? n : 1) * (SH_H1 + 10) + 512;
+}
+
+// x f32[n,30] (10 vector channels) -> score f32[n,1]; segments = pairs (lens_host[nseg], rows contiguous); widths of the released heads
+// only (VNStdFeature 10 -> 10 -> 5 -> 3, Conv1d 30 -> 20 -> 10 -> 1): anything else is BUF_EINVAL and the caller keeps the per-layer path.
+// vn1_* / vn2_*: map_to_feat, map_to_dir, folded VN-BatchNorm scale / shift (null: none); lin: vn_lin's map_to_feat;
+// w / b: the three Conv1d layers; final_activation: 0 none, 1 sigmoid, 2 softplus.
+extern "C" int buf_score_head(const float* x, int n, const int* lens_host, int nseg,
+                              const float* vn1_wf, const float* vn1_wd, const float* vn1_bsc, const float* vn1_bsh, float vn1_slope,
+                              const float* vn2_wf, const float* vn2_wd, const float* vn2_bsc, const float* vn2_bsh, float vn2_slope,
+                              const float* lin, const float* w0, const float* b0, const float* w1, const float* b1, int c1,
+                              const float* w2, const float* b2, int final_activation, float eps, float* out,
+                              void* ws, size_t ws_bytes, void* stream)
+{
+    BUF_REQUIRE(n >= 0 && nseg > 0 && c1 > 0 && c1 <= ROWLIN_MAX, BUF_EINVAL, "buf_score_head: n=%d nseg=%d c1=%d", n, nseg, c1);
+    BUF_REQUIRE(final_activation >= 0 && final_activation <= 2, BUF_EINVAL, "buf_score_head: activation %d", final_activation);
+    BUF_REQUIRE(lens_host && ws, BUF_EINVAL, "buf_score_head: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver wc(ws, ws_bytes);
+    int* off = wc.take<int>((size_t)nseg + 1);
+    double* p1 = wc.take<double>((size_t)nseg * SH_H1 * SEG_SPLITS);
+    double* p2 = wc.take<double>((size_t)nseg * SH_H1 * SEG_SPLITS);
+    float* h1 = wc.take<float>((size_t)(n > 0 ? n : 1) * SH_H1);
+    float* h2 = wc.take<float>((size_t)(n > 0 ? n : 1) * c1);
+    BUF_REQUIRE(wc.ok && c1 <= 10, BUF_EWORKSPACE, "buf_score_head: workspace %zu < %zu (or c1 > 10)", ws_bytes, wc.used());
+    int rc = upload_offsets(off, lens_host, nseg, n, "buf_score_head", s);
+    if (rc) return rc;
+    if (n == 0) return BUF_OK;
+    BUF_REQUIRE(x && vn1_wf && vn1_wd && vn2_wf && vn2_wd && lin && w0 && b0 && w1 && b1 && w2 && b2 && out, BUF_EINVAL, "buf_score_head: null argument");
+    ScoreHeadParams H;
+    H.vn1 = make_params(vn1_wf, vn1_wd, vn1_bsc, vn1_bsh, vn1_slope);
+    H.vn2 = make_params(vn2_wf, vn2_wd, vn2_bsc, vn2_bsh, vn2_slope);
+    H.lin = lin; H.w0 = w0; H.b0 = b0;
+    k_score_head_a<<<cdiv(n, 128), 128, 0, s>>>(x, n, H, h1);
+    dim3 grid(nseg, SEG_SPLITS);
+    int threads = SH_H1 * (256 / SH_H1);
+    k_seg_partial<false><<<grid, threads, 0, s>>>(h1, off, SH_H1, nullptr, p1);
+    k_seg_sq<<<grid, threads, 0, s>>>(h1, off, SH_H1, p1, p2);
+    k_row_linear_norm<<<cdiv(n, 256), 256, 0, s>>>(h1, n, SH_H1, c1, w1, b1, 0, off, nseg, p1, p2, eps, h2);
+    threads = c1 * (256 / c1);
+    k_seg_partial<false><<<grid, threads, 0, s>>>(h2, off, c1, nullptr, p1);
+    k_seg_sq<<<grid, threads, 0, s>>>(h2, off, c1, p1, p2);
+    k_row_linear_norm<<<cdiv(n, 256), 256, 0, s>>>(h2, n, c1, 1, w2, b2, final_activation, off, nseg, p1, p2, eps, out);
+    BUF_LAUNCH_CHECK();
+    return BUF_OK;
+}

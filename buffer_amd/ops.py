@@ -408,6 +408,32 @@ def row_linear(x, w, b, activation=None):
     return out
 
 
+def score_head(x, seg_lengths, vn1, vn2, lin, w, b, final, eps=1e-5):
+    """One score head (VNStdFeature + Conv1d / InstanceNorm1d stack, point_learner.py:128-136,163-171) in 7 launches:
+    x f32[n,30], seg_lengths int[nseg] (host: rows per pair), vn1 / vn2 / lin VnLayer, w / b the three Conv1d layers -> f32[n,1]."""
+    L = _lib.lib()
+    x = _dev(x, torch.float32, "score_head")
+    n = int(x.shape[0])
+    lens = _host_i32(seg_lengths)
+    nseg = int(lens.shape[0])
+    out = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    nbytes = L.buf_score_head_ws_bytes(n, nseg)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    act = {None: 0, 'sigmoid': 1, 'softplus': 2}[final]
+    check(L.buf_score_head(_ptr(x), n, _hptr(lens), nseg, _ptr(vn1.wf), _ptr(vn1.wd), _ptr(vn1.bsc), _ptr(vn1.bsh), vn1.slope,
+                           _ptr(vn2.wf), _ptr(vn2.wd), _ptr(vn2.bsc), _ptr(vn2.bsh), vn2.slope, _ptr(lin.wf),
+                           _ptr(w[0]), _ptr(b[0]), _ptr(w[1]), _ptr(b[1]), int(w[1].shape[0]), _ptr(w[2]), _ptr(b[2]), act, float(eps),
+                           _ptr(out), _ptr(ws), nbytes, _stream()), "buf_score_head")
+    return out
+
+
+def score_head_supported(x_width, vn1, vn2, lin, w):
+    """the fused head exists for the released widths only (10 -> 10 -> 5 -> 3 vector channels, Conv1d 30 -> 20 -> c <= 10 -> 1)"""
+    return (x_width == 30 and tuple(vn1.wf.shape) == (10, 10) and tuple(vn2.wf.shape) == (5, 10) and tuple(lin.wf.shape) == (3, 5)
+            and vn1.wd is not None and vn2.wd is not None and tuple(w[0].shape) == (20, 30) and w[1].shape[1] == 20 and w[1].shape[0] <= 10
+            and tuple(w[2].shape) == (1, int(w[1].shape[0])))
+
+
 def segment_instance_norm(x, seg_lengths, eps=1e-5):
     """InstanceNorm1d (biased variance) over contiguous row segments: x f32[n,c], seg_lengths int[nseg] (host) -> f32[n,c]."""
     L = _lib.lib()

@@ -1,5 +1,7 @@
 """A4/A5 -- point-wise learner on device: EFCNN (reference axis + eps) and DetNet (saliency)
 (models/point_learner.py:138-204) driven over the fused VN kernels of csrc/vn.hip."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -15,8 +17,9 @@ class _ScoreHead:
         self.lin = ops.VnLayer(W, f'{p}.0.vn_lin', device, linear_only=True)
         t = lambda k: torch.as_tensor(W[k], dtype=torch.float32, device=device)
         self.w = [t(f'{p}.{i}.weight')[:, :, 0].contiguous() for i in (1, 3, 5)]
-        self.b = [t(f'{p}.{i}.bias') for i in (1, 3, 5)]
+        self.b = [t(f'{p}.{i}.bias').contiguous() for i in (1, 3, 5)]
         self.final = final
+        self.fused = not os.environ.get('BUF_SCORE_HEAD_UNFUSED')       # development switch: the 17-launch path
 
     @staticmethod
     def _inorm(h, seg=None):
@@ -25,6 +28,10 @@ class _ScoreHead:
         return ops.segment_instance_norm(h, [h.shape[0]] if seg is None else seg)
 
     def __call__(self, x, seg=None):
+        if self.fused and ops.score_head_supported(x.shape[1], self.vn1, self.vn2, self.lin, self.w):
+            # one launch up to the first InstanceNorm, its statistics in two, the normalisation folded into the next Conv1d
+            # (csrc/vn.hip buf_score_head: 7 launches instead of 17, bit-identical)
+            return ops.score_head(x, [x.shape[0]] if seg is None else seg, self.vn1, self.vn2, self.lin, self.w, self.b, self.final)
         z = ops.vn_pointwise(self.vn1, x)
         z = ops.vn_pointwise(self.vn2, z)
         z = ops.vn_pointwise(self.lin, z)                          # [N, 9]

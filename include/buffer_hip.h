@@ -235,6 +235,20 @@ int     buf_segment_instance_norm(const float* x, int n, int c, const int* lens_
                                   void* ws, size_t ws_bytes, void* stream);
 /* VNStdFeature tail (vn_layers.py:213-219): x f32[n,3c], z f32[n,9] -> f32[n,3c] invariant scalars. */
 int     buf_vn_std(const float* x, const float* z, int n, int c, float* out, void* stream);
+/* One whole score head of models/point_learner.py:128-136 (Ref.inv_layer -> eps) / :163-171 (Keypt.invar_layer -> saliency) in 7
+ * launches: VNStdFeature (vn1 -> vn2 -> vn_lin -> x . z, vn_layers.py:169-222) + Conv1d 30 -> 20 | InstanceNorm1d over the pair |
+ * Conv1d 20 -> c1 | InstanceNorm1d | Conv1d c1 -> 1 + activation (0 none, 1 sigmoid, 2 softplus).  x f32[n,30] -> out f32[n,1];
+ * lens_host: rows per pair (HOST int[nseg], sum = n).  vn*_wf / _wd: map_to_feat / map_to_dir [Cout,Cin]; _bsc / _bsh: folded VN
+ * batch-norm (null: none); lin: vn_lin's map_to_feat [3,5]; w* / b*: Conv1d weights [Cout,Cin] / bias.  Only the released
+ * widths (10 -> 10 -> 5 -> 3; 30 -> 20 -> c1 <= 10 -> 1); bit-identical to buf_vn_pointwise x 3, buf_vn_std, buf_row_linear and
+ * buf_segment_instance_norm called one after the other. */
+size_t  buf_score_head_ws_bytes(int n, int nseg);
+int     buf_score_head(const float* x, int n, const int* lens_host, int nseg,
+                       const float* vn1_wf, const float* vn1_wd, const float* vn1_bsc, const float* vn1_bsh, float vn1_slope,
+                       const float* vn2_wf, const float* vn2_wd, const float* vn2_bsc, const float* vn2_bsh, float vn2_slope,
+                       const float* lin, const float* w0, const float* b0, const float* w1, const float* b1, int c1,
+                       const float* w2, const float* b2, int final_activation, float eps, float* out,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A9+A10 (+ point MLP of A11) fused: axis alignment, normalisation, cylindrical voxelisation

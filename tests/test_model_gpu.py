@@ -248,6 +248,27 @@ def test_winograd_and_direct_forms_against_float64(W, dev):
     split.check_range()                                                      # no activation left the f16 range
 
 
+@pytest.mark.parametrize("head", ["eps_head", "key_head"])
+def test_fused_score_head_is_bit_identical_to_the_layer_by_layer_path(W, dev, head):
+    """buf_score_head (7 launches: VNStdFeature + first Conv1d in one kernel, InstanceNorm statistics in two, the normalisation
+    folded into the next Conv1d) against the 17-launch path (buf_vn_pointwise x 3, buf_vn_std, buf_row_linear,
+    buf_segment_instance_norm): the same bits, for one pair, for a stacked batch with uneven segments, an EMPTY segment and
+    300 segments shorter than a block's 256 rows (more than 8 segments inside one block of the fused Conv1d)."""
+    from buffer_amd.point_learner import PointLearner
+    pl = PointLearner(W, dev)
+    h = getattr(pl, head)
+    g = torch.Generator(device='cpu').manual_seed(4)
+    for n, seg in ((9000, None), (20011, [7000, 0, 9011, 4000]), (6000, [20] * 300), (1, None), (0, None)):
+        x = torch.randn((n, 30), generator=g).to(dev)
+        h.fused = True
+        got = h(x, seg)
+        h.fused = False
+        want = h(x, seg)
+        h.fused = True
+        assert got.shape == want.shape == (n, 1)
+        assert torch.equal(got, want), (head, n, float((got - want).abs().max()))
+
+
 def _stack64(x, layers, dev):
     h = x.double().reshape(-1, layers[0][0].shape[1], 7, 20)
     for w, b, relu in layers:                                                # circular azimuth, zero elevation, float64
