@@ -4,6 +4,7 @@ PyTorch is used for device memory and stream handles only; every operator below 
 gfx950 kernel behind the C ABI of include/buffer_hip.h.  Nothing here falls back to the CPU.
 """
 import ctypes as C
+import time
 import os
 import numpy as np
 import torch
@@ -97,6 +98,9 @@ def radius_neighbors(queries, supports, q_lengths, s_lengths, radius, k=None):
     return grid.query(queries, q_lengths, k)
 
 
+HOST_WAIT_S = [0.0]        # diagnostics: seconds callers spent blocked in calls that end with a host round trip (subsample row counts)
+
+
 def grid_subsample_batch(points, lengths, dl, max_p=0, max_cells=0, features=None):
     """subsample_batch on device -> (f32[M,3] device tensor, int32[nb] numpy lengths[, f32[M,fd] feature means]).
     Rows per element in ascending voxel-key order."""
@@ -119,9 +123,11 @@ def grid_subsample_batch(points, lengths, dl, max_p=0, max_cells=0, features=Non
     out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=points.device)
     out_b = np.zeros(nb, np.int32)
     m = C.c_int(0)
+    t0 = time.perf_counter()
     check(L.buf_grid_subsample_batch(_ptr(points), n, _hptr(lengths), nb, float(dl), int(max_p), _ptr(features), fd,
                                      _ptr(out), _ptr(out_f), _hptr(out_b), C.byref(m), max_cells, _ptr(ws), nbytes,
                                      _stream()), "buf_grid_subsample_batch")
+    HOST_WAIT_S[0] += time.perf_counter() - t0          # the call ends with a stream synchronise (rows per element go to the host)
     if features is not None:
         return out[:m.value], out_b, out_f[:m.value]
     return out[:m.value], out_b

@@ -155,7 +155,9 @@ class BufferPipeline:
         lens = np.concatenate([np.asarray(i['lengths'], np.int32) for i in inps])            # [2B]
         pts = torch.cat([i['points'] for i in inps]) if B > 1 else inps[0]['points']
         feats = torch.cat([i['features'] for i in inps]) if B > 1 else inps[0]['features']
+        w0 = ops.HOST_WAIT_S[0]
         pyr = pyramid.build_pyramid(pts, lens, self.limits, cfg)
+        self.host_wait_s += ops.HOST_WAIT_S[0] - w0                                         # the two subsample row-count round trips
         pair_rows = lens.reshape(B, 2).sum(1)
         seg = pair_rows.astype(np.int32) if B > 1 else None      # InstanceNorm segments of the score heads: one per pair
         axis, eps, bottle, skips, _ = self.point.efcnn(pyr, feats, seg)
@@ -164,9 +166,9 @@ class BufferPipeline:
         cloud_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
         cloud_id = torch.repeat_interleave(torch.arange(2 * B, device=dev), cloud_len)
         axis_o = orient_axes(axis, pts0)                                                    # BUFFER.py:244-249 (row-wise)
-        keep = ops.compact_greater(score[:, 0], cfg.keypts_th).long()                        # :255-259, ascending
-        t0 = time.perf_counter()
-        counts = torch.bincount(cloud_id[keep], minlength=2 * B).cpu().numpy()           # host round trip 1 (candidate counts for FPS)
+        t0 = time.perf_counter()                                                            # host round trip 1: the compaction sizes its
+        keep = ops.compact_greater(score[:, 0], cfg.keypts_th).long()                        # output (:255-259, ascending), then the
+        counts = torch.bincount(cloud_id[keep], minlength=2 * B).cpu().numpy()               # candidate counts per cloud for FPS
         self.host_wait_s += time.perf_counter() - t0
         st = dict(inps=inps, seeds=seeds, perms=perms, B=B)
         if (counts == 0).any():                             # rare: some cloud has no point above the threshold
@@ -221,11 +223,11 @@ class BufferPipeline:
         cfg, dev = self.cfg, self.device
         seeds, B, kp, emb, s_nn, P = st['seeds'], st['B'], st['kp'], st['emb'], st['s_nn'], self.cfg.num_keypts
         poses = [None] * B
-        mm = torch.nonzero(st['mutual'])                                                    # (pair, s) ascending
+        t0 = time.perf_counter()                                                            # host round trip 2: the mutual matches
+        mm = torch.nonzero(st['mutual'])                                                    # (pair, s) ascending; sizes its output
         pair_of, s_mid = mm[:, 0], mm[:, 1]
         t_mid = s_nn[pair_of, s_mid]
-        t0 = time.perf_counter()
-        m_counts = torch.bincount(pair_of, minlength=B).cpu().numpy()                     # host round trip 2 (match counts)
+        m_counts = torch.bincount(pair_of, minlength=B).cpu().numpy()                       # matches per pair
         self.host_wait_s += time.perf_counter() - t0
         src_row = (2 * pair_of) * P + s_mid
         tgt_row = (2 * pair_of + 1) * P + t_mid
