@@ -357,7 +357,7 @@ def make_kitti_fixture():
     sys.modules.pop('KITTI.config', None)
 
 
-def make_full_fixture(seed=4242, P=1500):
+def make_full_fixture(seed=4242, P=1500, dataset='3dmatch'):
     """F8 `full_1500.npz` (round 5): ONE synth.make_pair at the full 3DMatch shape through the reference's OWN
     buffer.forward (models/BUFFER.py:231-333, unmodified) at the reference's 1500 keypoints: the collate of
     ThreeDMatch/dataloader.py, Ref, Keypt, FPS, Desc x 2, mutual matching, Inlier, hypotheses, RANSAC, post_refinement.
@@ -370,10 +370,15 @@ def make_full_fixture(seed=4242, P=1500):
     torch.manual_seed(0)
     np.random.seed(0)
     from oracle import pipeline_ref
-    from ThreeDMatch import dataloader as dl
-    cfg, model, _ = load_reference_model()
+    if dataset == 'kitti':                                   # F9: the KITTI branch (KITTI/config.py, released KITTI snapshot, R = I alignment, no refinement)
+        cfg, model, _ = load_reference_model('KITTI', '06050001')
+        from KITTI import dataloader as dl
+        sample = synth.make_kitti_pair(seed)
+    else:
+        from ThreeDMatch import dataloader as dl
+        cfg, model, _ = load_reference_model()
+        sample = synth.make_pair(seed)
     assert cfg.point.num_keypts == P
-    sample = synth.make_pair(seed)
     limits = dl.calibrate_neighbors([sample], cfg, dl.collate_fn_descriptor)
     batch = dl.collate_fn_descriptor([sample], cfg, limits)
     rng = np.random.default_rng(seed)
@@ -504,11 +509,14 @@ def make_full_fixture(seed=4242, P=1500):
         out.update({f'{nm}_desc_rows': d['desc'][rows_p], f'{nm}_equi_rows': d['equi'][rows_e], f'{nm}_R_rows': d['R'][rows_p],
                     f'{nm}_rand_axis_rows': d['rand_axis'][rows_p], f'{nm}_desc_sum': f64(d['desc']), f'{nm}_equi_sum': f64(d['equi']),
                     f'{nm}_patches_sum': f64(d['patches']), f'{nm}_equi_rowsum': np.asarray(d['equi'], np.float64).sum((1, 2, 3))})
-    np.savez_compressed(os.path.join(GOLD, 'full_1500.npz'), **out)
+    name = 'kitti_full_1500.npz' if dataset == 'kitti' else 'full_1500.npz'
+    np.savez_compressed(os.path.join(GOLD, name), **out)
     err = np.abs(np.asarray(pose) - sample['relt_pose']).max()
-    print('F8: layers', out['layer_sizes'], 'limits', limits, 'candidates', out['n_candidates'], 'matches', len(s_mids),
+    print(name, ': layers', out['layer_sizes'], 'limits', limits, 'candidates', out['n_candidates'], 'matches', len(s_mids),
           'best inliers', int(inlier_num[best]), 'ransac', cap['ransac_info'], '|pose - gt|', float(err),
-          'size', os.path.getsize(os.path.join(GOLD, 'full_1500.npz')))
+          'size', os.path.getsize(os.path.join(GOLD, name)))
+    if dataset == 'kitti':
+        sys.modules.pop('KITTI.config', None)
 
 
 def make_rr_fixture():
@@ -576,10 +584,13 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'kitti':     
     make_kitti_fixture()
     sys.exit(0)
 
-if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'full':        # only F8 (leaves F1-F7 untouched)
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] in ('full', 'kitti_full'):     # only F8 / F9 (leaves F1-F7 untouched)
     cpu.build(ref=True)
     install_stubs()
-    make_full_fixture()
+    if sys.argv[1] == 'full':
+        make_full_fixture()
+    else:
+        make_full_fixture(seed=2003, dataset='kitti')
     sys.exit(0)
 
 if __name__ == '__main__':
