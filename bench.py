@@ -301,13 +301,13 @@ def compact(e, algo_key=None):
             'avg_us': round(e['avg_us'], 1), 'traffic_ratio': tr}
 
 
-def dgr_ok(poses, gts):
+def dgr_ok(poses, gts, rre_deg=15.0):
     ok = 0
     for pose, gt in zip(poses, gts):
         T = np.asarray(pose, np.float64)
         rte = np.linalg.norm(T[:3, 3] - gt[:3, 3])
         rre = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ gt[:3, :3]) - 1) / 2, -1, 1)))
-        ok += int(rte < 0.3 and rre < 15)
+        ok += int(rte < 0.3 and rre < rre_deg)
     return ok
 
 
@@ -552,6 +552,7 @@ def main():
                                         'per_step': med(lambda: pipe._keypoints([inputs[k % len(inputs)] for k in range(pps)], list(range(pps)), None), 3)}
     gts = [samples[(a.warmup * pps + n) % len(samples)]['relt_pose'] for n in range(len(all_poses))]    # step i, slot j -> pair (i*pps + j) mod distinct
     ok = dgr_ok(mine.cpu().numpy(), gts)
+    ok_ref = dgr_ok(mine.cpu().numpy(), gts, 1.0) if kitti else None      # KITTI/test.py:66-72 as coded: RTE < 0.3 m and RRE < 1 deg
 
     # second timed region: the SAME steps with the opt-in fp32-equivalent split-f16 CNN kernels (cnn_arith='split')
     split = None
@@ -605,6 +606,7 @@ def main():
                        'sds_points': [int(x) for x in inputs[0]['lengths']], 'neighbor_limits': limits,
                        'weights': ('KITTI 06050001' if kitti else '3DMatch 06132318') + ' (released)', 'parallelism': f'pair-sharded x{world}',
                        'registered_ok': f'{ok}/{len(all_poses)} (rank 0, RTE<0.3 m & RRE<15 deg)',
+                       **({'registered_ok_reference_criterion': f'{ok_ref}/{len(all_poses)} (KITTI/test.py:66-72: RTE<0.3 m & RRE<1 deg)'} if kitti else {}),
                        'gathered_poses': [int(g.shape[0]) for g in gathered] if gathered else None,
                        'setup_s': round(setup_s, 1), 'per_rank': per_rank_main},
         }
