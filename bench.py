@@ -98,11 +98,14 @@ def parse():
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(sample, cfg, limits, hip_register=None):
+def cpu_baseline(sample, cfg, limits, hip_register=None, hip_register_split=None):
     """The CPU path on THIS box's host cores, one pair, full size (no sampling of keypoints, nothing extrapolated):
     pyramid = the reference's cpp_wrappers cores (oracle/_ref, kind 'reference'; the plain-C port where that library was
     not built) on min(16, nproc) concurrent workers like the reference's DataLoader (ThreeDMatch/config.py:22), each
-    building the pyramid of one pair; model stages = torch-CPU restatement on all threads.  Baseline only."""
+    building the pyramid of one pair; model stages = torch-CPU restatement on all threads.  Baseline only.
+    hip_register / hip_register_split(perms, seed) -> (pose, detail): the product path (fp32 / split-f16 CNN kernels) on the SAME pair
+    with the SAME pinned permutations and seed -- the oracle's result is not thrown away but compared with them: `parity`,
+    `parity_split` (the checker role of oracle/, at the full BASELINE size)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import cpu, pipeline_ref, torch_ref
     from buffer_amd.weights import load_weights
@@ -125,9 +128,9 @@ def cpu_baseline(sample, cfg, limits, hip_register=None):
     t0 = time.perf_counter()
     want, wd = pipeline_ref.register_pair(sample, W, limits, cfg, 0, perms, use_ref=use_ref, timings=tm)
     t_model = sum(v for k, v in tm.items() if k != 'pyramid')
-    parity = None
-    if hip_register is not None:
-        got, gd = hip_register(perms, 0)
+
+    def compare(fn):
+        got, gd = fn(perms, 0)
         kp_equal = all(np.array_equal(gd['kpts'][i].cpu().numpy(), wd['kpts'][i].numpy()) for i in range(2))
         # descriptors row by row: a point of a patch that sits ON a voxel ball's surface can fall on either side when the aligned
         # patch coordinates differ in the last bit (torch's CPU matmul vs the kernel's Rodrigues product): a handful of rows in 10^4
@@ -135,7 +138,7 @@ def cpu_baseline(sample, cfg, limits, hip_register=None):
         ddesc = torch.cat([(gd['desc'][i]['desc'].cpu() - wd['desc'][i]['desc']).abs().amax(1) for i in range(2)]) if kp_equal else None
         mine = set(zip(gd['s_mids'].cpu().numpy().tolist(), gd['t_mids'].cpu().numpy().tolist()))
         ref = set(zip(np.asarray(wd['s_mids']).tolist(), np.asarray(wd['t_mids']).tolist()))
-        parity = dict(keypoints_equal=bool(kp_equal), matches=len(ref), matches_differing=len(mine ^ ref),
+        return dict(keypoints_equal=bool(kp_equal), matches=len(ref), matches_differing=len(mine ^ ref),
                       pose_max_abs_diff=float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max()),
                       desc_rows=None if ddesc is None else int(ddesc.numel()),
                       desc_rows_differing_over_1e_4=None if ddesc is None else int((ddesc > 1e-4).sum()),
@@ -143,6 +146,11 @@ def cpu_baseline(sample, cfg, limits, hip_register=None):
                       desc_max_abs_diff=None if ddesc is None else float(ddesc.max()),
                       what=f'HIP register() vs oracle/pipeline_ref.register_pair on this pair at {cfg.num_keypts} keypoints/fragment, '
                            'same permutations, seed 0')
+
+    parity = compare(hip_register) if hip_register is not None else None
+    parity_split = compare(hip_register_split) if hip_register_split is not None else None
+    if parity_split is not None:
+        parity_split['what'] = "the same comparison for cnn_arith='split' (the fp32-equivalent split-f16 CNN kernels)"
     # the reference overlaps its loader workers with the model process: steady-state rate = the slower of the two legs
     return dict(value=1.0 / max(t_pyr, t_model), unit='pairs/s', cores=torch.get_num_threads(), workers=workers,
                 kind='reference cores (pyramid) + restated model' if use_ref else 'port',
@@ -150,7 +158,8 @@ def cpu_baseline(sample, cfg, limits, hip_register=None):
                        f'{"reference cpp_wrappers cores" if use_ref else "plain-C port"} on {workers} workers ({t_pyr * 1e3:.1f} ms/pair), '
                        f'model stages = torch-CPU restatement, {torch.get_num_threads()} threads ({t_model:.1f} s/pair); '
                        f'value = 1 / max(loader leg, model leg)',
-                stages_s={k: round(v, 3) for k, v in tm.items()}, pyramid_s_per_pair_at_workers=round(t_pyr, 4), parity=parity)
+                stages_s={k: round(v, 3) for k, v in tm.items()}, pyramid_s_per_pair_at_workers=round(t_pyr, 4), parity=parity,
+                **({'parity_split': parity_split} if parity_split is not None else {}))
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -613,7 +622,11 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             def hip_register(perms, seed):
                 return pipe.register(inputs[0], seed=seed, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
-            out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits, hip_register)
+            hip_register_split = None
+            if split:
+                def hip_register_split(perms, seed):
+                    return pipe_s.register(inputs[0], seed=seed, perms=[torch.from_numpy(p).to(dev) for p in perms], detail=True)
+            out['cpu_baseline'] = cpu_baseline(samples[0], cfg, limits, hip_register, hip_register_split)
         out['roofline'] = main_roof
         detail = dict(out, roofline_other=other, timed_kernel_ms_per_step={k: v[1] / alone_steps for k, v in timed_alone.items() if v[0]})
         if split:
