@@ -33,8 +33,22 @@
 // [hi | lo'][lane][8], 4 KB per (tap, k-step) and wavefront, one step ahead in registers.
 #include "common.h"
 
+// Round 5 layout (H3_ROWTILES, default): the 16 positions of a tile follow the MAP'S ROWS -- tiles 0..6 = (y, x = 0..15), tile 7 =
+// (y = 0..3) x (x = 16..19), tile 8 = (y = 4..6) x (x = 16..19) + 4 idle slots -- rows of 512 B, and the 16-byte chunk of a row is
+// XOR-keyed: chunk' = chunk ^ key(y, x), key = (x == 19 ? 14 : 2 (x & 7)) ^ 8 (y & 1).  With 16 CONSECUTIVE positions per tile
+// (round 4, -DH3_ROWTILES=0: stride 544 B, no key) the one azimuth-wrapped lane of a tile cost an extra LDS cycle in each of the
+// four 16-lane groups of every ds_read_b128 of the dx = +-1 taps (+52 % read cycles; SQ_LDS_BANK_CONFLICT 45 % of
+// SQ_LDS_IDX_ACTIVE); here every group of every tap reads 16 distinct slots (tools/h3_lds_sim.py: +0 %), the image is 4.5 KB
+// smaller, and an address costs what it did (an XOR where there was an add).
+#ifndef H3_ROWTILES
+#define H3_ROWTILES 0
+#endif
 #ifndef H3_S
+#if H3_ROWTILES == 1
+#define H3_S 512u
+#else
 #define H3_S 544u                       // bytes per position (136 words = 8 mod 64 banks; 528 measured the same, 560 is 20 % slower)
+#endif
 #endif
 #define H3_LO 256u                      // offset of the lo' plane inside a position's row
 #define H3_NPOS 140
@@ -52,6 +66,36 @@ typedef float h3f4 __attribute__((ext_vector_type(4)));
 typedef unsigned h3u4 __attribute__((ext_vector_type(4)));
 typedef unsigned h3u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char* h3_lds_p;
+
+// tile slot (tile t, lane slot m) -> map position (y, x); false: an idle slot of tile 8 (y = 7 is returned: a virtual row)
+__device__ __forceinline__ bool h3_pos(int t, int m, int& y, int& x)
+{
+#if H3_ROWTILES == 1
+    if (t < 7) { y = t; x = m; return true; }
+    y = (t - 7) * 4 + (m >> 2); x = 16 + (m & 3);
+    return y <= 6;
+#elif H3_ROWTILES == 2
+    // rows shifted by one column: tiles 0..6 = (y, x = 1..16), tiles 7 / 8 = (y = 0..3 | 4..6) x (x = 17, 18, 19, 0).  No tap of a
+    // row tile wraps in azimuth (x - 1 .. x + 1 stays inside 0..17), the narrow tiles' four columns are cyclically consecutive, and
+    // with the 544-byte row stride 16 consecutive rows already sit on 16 distinct slots: no key, the round-4 addressing unchanged
+    if (t < 7) { y = t; x = m + 1; return true; }
+    y = (t - 7) * 4 + (m >> 2); x = 17 + (m & 3); x -= x >= 20 ? 20 : 0;
+    return y <= 6;
+#else
+    const int p = 16 * t + m;
+    y = p / 20; x = p - y * 20;
+    return p < H3_NPOS;
+#endif
+}
+// XOR key of the 16-byte chunk index inside a position's 256-byte plane
+__device__ __forceinline__ unsigned h3_key(int y, int x)
+{
+#if H3_ROWTILES == 1
+    return (unsigned)((x == 19 ? 14 : 2 * (x & 7)) ^ (8 * (y & 1)));
+#else
+    return 0u;
+#endif
+}
 
 struct CylH3Params {
     const void* wt[H3_LAYERS];          // buf_split_tile_filters
@@ -125,14 +169,26 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
 {
     constexpr int S = KS * PT;                                   // steps per tap
     constexpr int NDW = (PT + 1) / 2;
-    const unsigned kgo = lds0 + (lane >> 4) * 16u, lofs = lane * 16u;
+    const unsigned lofs = lane * 16u;
     const unsigned tadr = lds0 + H3_TAB + (lane & 15) * 32u + (unsigned)pt0 * 2u;
     unsigned rc[NDW], rn[NDW];
+#if H3_ROWTILES == 1
+    // table entry = row << 5 | key; the lane's k-group (lane >> 4) is XORed into both halves of a packed pair once per tap, the
+    // k-step into the chunk bits at the read: address = lds0 + ((entry ^ k-group ^ 4 k-step) << 4)
+    const unsigned kx = (lane >> 4) * 0x10001u;
+#pragma unroll
+    for (int j = 0; j < NDW; j++) rc[j] = h3_lds32(tadr + 4 * j) ^ kx;
+    auto row = [&](const unsigned (&r)[NDW], int t, int ks) __attribute__((always_inline)) {
+        return ((((t & 1) ? (r[t >> 1] >> 16) : (r[t >> 1] & 0xffffu)) ^ (unsigned)(ks << 2)) << 4) + lds0;
+    };
+#else
+    const unsigned kgo = lds0 + (lane >> 4) * 16u;
 #pragma unroll
     for (int j = 0; j < NDW; j++) rc[j] = h3_lds32(tadr + 4 * j);
-    auto row = [&](const unsigned (&r)[NDW], int t) __attribute__((always_inline)) {
-        return (((t & 1) ? (r[t >> 1] >> 16) : (r[t >> 1] & 0xffffu)) << 4) + kgo;
+    auto row = [&](const unsigned (&r)[NDW], int t, int ks) __attribute__((always_inline)) {
+        return (((t & 1) ? (r[t >> 1] >> 16) : (r[t >> 1] & 0xffffu)) << 4) + kgo + (unsigned)ks * 64u;
     };
+#endif
     // weights: the blocks (tap, k-step) of 4 KB, WD blocks ahead in registers.  A block feeds 6 PT matrix instructions (96 PT cycles).
     // Two blocks ahead for the 2..5-tile wavefronts measured +-0 (85.0 vs 86.0 ms per 320 000 patches): the partner workgroup of the
     // CU covers the fetch; the kernel sits at 73 % matrix-pipe busy at the ~1.8 GHz the chip holds under f16 MFMA load.
@@ -147,14 +203,19 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
     h3u4 X[3][2];
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-        const unsigned a = row(rc, g % PT) + (unsigned)((g / PT) % KS) * 64u;
+        const unsigned a = row(rc, g % PT, (g / PT) % KS);
         X[g][0] = h3_lds128(a); X[g][1] = h3_lds128(a + H3_LO);
     }
 #pragma unroll 1
     for (int tap = 0; tap < 9; tap++) {
         const unsigned tn = tadr + (unsigned)(tap < 8 ? tap + 1 : 8) * 512u;
 #pragma unroll
-        for (int j = 0; j < NDW; j++) rn[j] = h3_lds32(tn + 4 * j);
+        for (int j = 0; j < NDW; j++) {
+            rn[j] = h3_lds32(tn + 4 * j);
+#if H3_ROWTILES == 1
+            rn[j] ^= kx;
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < S; s++) {
@@ -166,7 +227,7 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
                 for (int q = 0; q < 4; q++) (WD == 2 ? Wnn : Wn)[q >> 1][q & 1] = h3_ldw(rs, wn + q * 1024u, lofs);
             }
             {
-                const unsigned a = g < S ? row(rc, g % PT) + (unsigned)(g / PT) * 64u : row(rn, (g - S) % PT) + (unsigned)(((g - S) / PT) % KS) * 64u;
+                const unsigned a = g < S ? row(rc, g % PT, g / PT) : row(rn, (g - S) % PT, ((g - S) / PT) % KS);
                 X[g % 3][0] = h3_lds128(a); X[g % 3][1] = h3_lds128(a + H3_LO);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -209,29 +270,32 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
     float k2048 = 2048.f;
     asm volatile("" : "+v"(k2048));                              // one register for the multiplier of v_fma_mixlo / mixhi_f16
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, 0x7fffffff, 0x00027000);
-    unsigned ybase = (unsigned)((32 * ct * H3_NPOS + 16 * pt0) * 4);
+    unsigned ybase = (unsigned)((32 * ct * H3_NPOS) * 4);
     asm volatile("" : "+s"(ybase));                              // (the per-store scalar offsets are formed here as well)
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int c = 32 * ct + 16 * n + 4 * lk;
+    for (int t = 0; t < PT; t++) {
+        int py, px;
+        const bool valid = h3_pos(pt0 + t, li, py, px);          // the lane's position in tile pt0 + t
+        const unsigned p = (unsigned)(py * 20 + px);
+        const unsigned key = h3_key(py, px);
 #pragma unroll
-        for (int t = 0; t < PT; t++) {
-            const int p = 16 * (pt0 + t) + li;
+        for (int n = 0; n < 2; n++) {
+            const int c = 32 * ct + 16 * n + 4 * lk;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = __builtin_fmaf(ac[n][t][r], 1.f / 2048.f, am[n][t][r]);     // the bias started the hi-sum
             if constexpr (LAST) {
                 if (to_lds) {                                    // fused head: the fp32 map [32][140] at the start of the (now free) image
-                    if (p < H3_NPOS) {
+                    if (valid) {
 #pragma unroll
                         for (int r = 0; r < 4; r++)
-                            *(__attribute__((address_space(3))) float*)(size_t)(lds0 + (unsigned)((c + r) * H3_NPOS + p) * 4u) = relu ? fmaxf(v[r], 0.f) : v[r];
+                            *(__attribute__((address_space(3))) float*)(size_t)(lds0 + ((unsigned)(c + r) * H3_NPOS + p) * 4u) = relu ? fmaxf(v[r], 0.f) : v[r];
                     }
-                } else if (p < H3_NPOS) {
+                } else if (valid) {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu ? fmaxf(v[r], 0.f) : v[r]), yrs,
-                                                              (unsigned)(4 * lk * H3_NPOS + li) * 4u, ybase + (unsigned)(((16 * n + r) * H3_NPOS + 16 * t) * 4), 0);
+                                                              ((unsigned)(4 * lk) * H3_NPOS + p) * 4u, ybase + (unsigned)(((16 * n + r) * H3_NPOS) * 4), 0);
                 }
             } else {
                 h3_watch2(amax, v[0], v[1]); h3_watch2(amax, v[2], v[3]);       // before the ReLU
@@ -243,8 +307,9 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
                 h3_split2(v[0], v[1], k2048, h0, l0);
                 h3_split2(v[2], v[3], k2048, h1, l1);
                 const h3u2 hi = { h0, h1 }, lo = { l0, l1 };
-                if (p < H3_NPOS) {
-                    const unsigned a = lds0 + (unsigned)p * H3_S + (unsigned)c * 2u;
+                if (valid) {
+                    // 4 channels = 8 bytes of the plane: chunk (c >> 3) keyed by the position, half (c & 4) inside it
+                    const unsigned a = lds0 + p * H3_S + ((((unsigned)c >> 3) ^ key) << 4) + ((unsigned)c & 4u) * 2u;
                     *(__attribute__((address_space(3))) h3u2*)(size_t)a = hi;
                     *(__attribute__((address_space(3))) h3u2*)(size_t)(a + H3_LO) = lo;
                 }
@@ -300,13 +365,24 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
     const unsigned lane = tid & (WAVE - 1);
     // address table: tab[tap][p] = row (in 16-byte units) that tap (dy, dx) reads for output position p
     for (int e = tid; e < 9 * 256; e += H3_THREADS) {
-        const int tap = e >> 8, p = ((e & 15) << 4) | ((e >> 4) & 15);        // e = (tap, lane m, tile slot t): p = 16 t + m
-        const int yy0 = p / 20, xx0 = p - yy0 * 20;
+        const int tap = e >> 8, t = e & 15, m = (e >> 4) & 15;               // e = (tap, lane m, tile slot t)
+        int yy0 = 7, xx0 = 0;
+        const bool ok = t < 9 && h3_pos(t, m, yy0, xx0);                      // idle slots read like the virtual row they stand for
         const int yy = yy0 + tap / 3 - 1;
         int xx = xx0 + tap % 3 - 1;
         xx += xx < 0 ? 20 : 0; xx -= xx >= 20 ? 20 : 0;
-        const unsigned row = (p >= H3_NPOS || yy < 0 || yy > 6) ? (unsigned)H3_NPOS : (unsigned)(yy * 20 + xx);
+#if H3_ROWTILES == 1
+        (void)ok;
+        const unsigned row = (t >= 9 || yy < 0 || yy > 6) ? (unsigned)H3_NPOS : (unsigned)(yy * 20 + xx);
+        *(__attribute__((address_space(3))) unsigned short*)(size_t)(lds0 + H3_TAB + 2u * e) = (unsigned short)((row << 5) | h3_key(yy, xx));
+#elif H3_ROWTILES == 2
+        (void)ok;                                                             // (idle slots read the row they would stand for, or zeros)
+        const unsigned row = (t >= 9 || yy < 0 || yy > 6) ? (unsigned)H3_NPOS : (unsigned)(yy * 20 + xx);
         *(__attribute__((address_space(3))) unsigned short*)(size_t)(lds0 + H3_TAB + 2u * e) = (unsigned short)(row * (H3_S / 16));
+#else
+        const unsigned row = (!ok || yy < 0 || yy > 6) ? (unsigned)H3_NPOS : (unsigned)(yy * 20 + xx);
+        *(__attribute__((address_space(3))) unsigned short*)(size_t)(lds0 + H3_TAB + 2u * e) = (unsigned short)(row * (H3_S / 16));
+#endif
     }
     for (int i = tid; i < (int)(H3_S / 16); i += H3_THREADS) *(__attribute__((address_space(3))) h3u4*)(size_t)(lds0 + H3_ZERO + 16u * i) = (h3u4){ 0, 0, 0, 0 };
     {   // input x[cin0][140] fp32 -> split rows; a work item = (4 positions, 2 channels), channel pairs fastest (one position's
@@ -325,7 +401,8 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
                 h3_split(a[j], h, l); hi[0] = h; lo[0] = l;
                 h3_split(b[j], h, l); hi[1] = h; lo[1] = l;
                 h3_watch(amax, a[j]); h3_watch(amax, b[j]);
-                const unsigned ad = lds0 + (unsigned)(4 * q + j) * H3_S + 4u * cp;
+                const int pp = 4 * q + j, py = pp / 20;
+                const unsigned ad = lds0 + (unsigned)pp * H3_S + ((((unsigned)cp >> 2) ^ h3_key(py, pp - 20 * py)) << 4) + 4u * ((unsigned)cp & 3u);
                 *(__attribute__((address_space(3))) unsigned*)(size_t)ad = __builtin_bit_cast(unsigned, hi);
                 *(__attribute__((address_space(3))) unsigned*)(size_t)(ad + H3_LO) = __builtin_bit_cast(unsigned, lo);
             }
@@ -333,8 +410,8 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         if (P.status && __builtin_amdgcn_ballot_w64(amax >= H3_F16_LIMIT_BITS) != 0 && lane == 0) atomicOr(P.status, 1);
         const int nz = (cpad - cin0) >> 1;                       // zero channel pairs up to the k-step boundary (48 -> 64)
         for (int i = tid; i < H3_NPOS * nz; i += H3_THREADS) {
-            const int p = i / nz, cp = (cin0 >> 1) + i - p * nz;
-            const unsigned ad = lds0 + (unsigned)p * H3_S + 4u * cp;
+            const int p = i / nz, cp = (cin0 >> 1) + i - p * nz, py = p / 20;
+            const unsigned ad = lds0 + (unsigned)p * H3_S + ((((unsigned)cp >> 2) ^ h3_key(py, p - 20 * py)) << 4) + 4u * ((unsigned)cp & 3u);
             *(__attribute__((address_space(3))) unsigned*)(size_t)ad = 0u;
             *(__attribute__((address_space(3))) unsigned*)(size_t)(ad + H3_LO) = 0u;
         }
