@@ -33,13 +33,14 @@
 // [hi | lo'][lane][8], 4 KB per (tap, k-step) and wavefront, one step ahead in registers.
 #include "common.h"
 
-// Round 5 layout (H3_ROWTILES, default): the 16 positions of a tile follow the MAP'S ROWS -- tiles 0..6 = (y, x = 0..15), tile 7 =
-// (y = 0..3) x (x = 16..19), tile 8 = (y = 4..6) x (x = 16..19) + 4 idle slots -- rows of 512 B, and the 16-byte chunk of a row is
-// XOR-keyed: chunk' = chunk ^ key(y, x), key = (x == 19 ? 14 : 2 (x & 7)) ^ 8 (y & 1).  With 16 CONSECUTIVE positions per tile
-// (round 4, -DH3_ROWTILES=0: stride 544 B, no key) the one azimuth-wrapped lane of a tile cost an extra LDS cycle in each of the
-// four 16-lane groups of every ds_read_b128 of the dx = +-1 taps (+52 % read cycles; SQ_LDS_BANK_CONFLICT 45 % of
-// SQ_LDS_IDX_ACTIVE); here every group of every tap reads 16 distinct slots (tools/h3_lds_sim.py: +0 %), the image is 4.5 KB
-// smaller, and an address costs what it did (an XOR where there was an add).
+// Activation-image layouts (round 5; profiles/r05_h3_lds_layouts.txt).  0 (default, round 4): a tile = 16 CONSECUTIVE positions, rows of
+// 544 B.  One azimuth-wrapped lane per tile then costs an extra LDS cycle in each of the four 16-lane groups of every ds_read_b128 of
+// the dx = +-1 taps (+52 % read cycles; SQ_LDS_BANK_CONFLICT 45 % of SQ_LDS_IDX_ACTIVE).  1: tiles follow the MAP'S ROWS -- tiles
+// 0..6 = (y, x = 0..15), tile 7 = (y = 0..3) x (x = 16..19), tile 8 = (y = 4..6) x (x = 16..19) + 4 idle slots --, rows of 512 B, the
+// 16-byte chunk XOR-keyed: chunk' = chunk ^ key(y, x), key = (x == 19 ? 14 : 2 (x & 7)) ^ 8 (y & 1): every group of every tap reads
+// 16 distinct slots.  2: tiles = (y, x = 1..16) + narrow tiles (x = 17, 18, 19, 0), 544-byte rows, no key, round-4 addressing.
+// 1 and 2 remove the read conflicts (conflict cycles -56 %) with bit-identical outputs and do NOT make the kernel faster (LDS 43 %
+// busy, matrix pipe 73-76 %): kept as switches, 0 stays the default.
 #ifndef H3_ROWTILES
 #define H3_ROWTILES 0
 #endif
