@@ -401,3 +401,44 @@ def test_split_gemm_tiling_general_form():
         assert not t[:, cout:].any() and not t[:, :, cin:].any()
     w = (rng.standard_normal((64, 48, 3, 3)) * 0.1).astype(np.float32)
     assert np.array_equal(ops.split_tile_filters(w), ops.split_tile_gemm(w.reshape(64, 48, 9), 2))
+
+
+def test_traffic_summary_keeps_full_step_launches_only(tmp_path):
+    """tools/make_traffic.py on a synthetic counter file: a 64-patch probe launch of k_cyl_net_wg beside five full-step launches
+    (round 4 averaged it in and under-reported the kernel's traffic by 1/6) must be dropped, and counted as dropped."""
+    import csv
+    hdr = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id", "Kernel_Name",
+           "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value",
+           "Start_Timestamp", "End_Timestamp"]
+    patches, pairs = 2 * 100 * 4, 4
+
+    def write(path, counter, per_patch_kb):
+        with open(path, 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(hdr)
+            d = 0
+            for k in range(5):                                  # full-step launches: grid = patches x 256 threads
+                d += 1
+                w.writerow([d, d, "Agent 2", 1, 1, 1, patches * 256, 8, "k_cyl_net_wg(float const*, CylWgParams, float*)", 256, 0, 0, 128, 128, 32,
+                            counter, per_patch_kb * patches, 0, 1])
+            d += 1                                              # the 64-patch probe launch
+            w.writerow([d, d, "Agent 2", 1, 1, 1, 64 * 256, 8, "k_cyl_net_wg(float const*, CylWgParams, float*)", 256, 0, 0, 128, 128, 32,
+                        counter, per_patch_kb * 64, 0, 1])
+            for k in range(3):                                  # a kernel whose launches legitimately differ in size: all kept
+                d += 1
+                w.writerow([d, d, "Agent 2", 1, 1, 1, (k + 1) * 1024, 9, "k_cost_net(float const*, float const*, CostNetParams, float*)", 256, 0, 0, 128,
+                            128, 32, counter, 10.0 * (k + 1), 0, 1])
+    write(tmp_path / 'fetch.csv', 'FETCH_SIZE', 14.0)          # KB per patch (the raw counter; doubled by the tool)
+    write(tmp_path / 'write.csv', 'WRITE_SIZE', 17.5)
+    bench = {'value': 1.0, 'config': {'pairs_per_step_per_gpu': pairs, 'keypoints_per_fragment': 100},
+             'roofline_other': [{'kernel': 'k_cost_net (A13)', 'avg_algorithmic_flops': 51905536.0 * 100}]}
+    (tmp_path / 'bench.json').write_text(__import__('json').dumps(bench))
+    out = tmp_path / 'traffic.json'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'make_traffic.py'), str(tmp_path / 'fetch.csv'), str(tmp_path / 'write.csv'),
+                        str(tmp_path / 'bench.json'), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    t = __import__('json').load(open(out))['kernels']
+    k = t['k_cyl_net_wg']
+    assert k['launches_profiled'] == 5 and k['launches_dropped'] == 1
+    assert abs(k['hbm_bytes_per_unit'] - (2 * 14.0 + 17.5) * 1024) < 1e-6          # not diluted by the probe launch
+    assert t['k_cost_net']['launches_profiled'] == 3 and t['k_cost_net']['launches_dropped'] == 0
