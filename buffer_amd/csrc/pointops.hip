@@ -859,7 +859,8 @@ __global__ void __launch_bounds__(256) k_nn1f_norm(const float* __restrict__ ref
 #pragma unroll
     for (int c4 = 0; c4 < 8; c4++) {
         const float4 v = src[c4];
-        nn += (double)v.x * (double)v.x; nn += (double)v.y * (double)v.y; nn += (double)v.z * (double)v.z; nn += (double)v.w * (double)v.w;
+        nn = fma((double)v.x, (double)v.x, nn); nn = fma((double)v.y, (double)v.y, nn);      // (exact products: rounds like mul + add)
+        nn = fma((double)v.z, (double)v.z, nn); nn = fma((double)v.w, (double)v.w, nn);
     }
     const float nf = (float)nn;
     const bool isbad = !(nf <= 1e30f);                           // also catches NaN / infinity
@@ -900,7 +901,7 @@ __global__ void __launch_bounds__(256) k_nn1f_prep(const float* __restrict__ x, 
             const float a[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                nn += (double)a[j] * (double)a[j];
+                nn = fma((double)a[j], (double)a[j], nn);
                 const float sv = a[j] * s2;                      // (power of two: exact unless the product leaves the fp32 range -- `bad` rows)
                 h[4 * c4 + j] = (_Float16)sv;
                 l[4 * c4 + j] = (_Float16)(sv - (float)h[4 * c4 + j]);

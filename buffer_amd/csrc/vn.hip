@@ -65,6 +65,9 @@ __global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_p
     float bsc = has_bn ? P.bn_scale[o] : 0.f, bsh = has_bn ? P.bn_shift[o] : 0.f;
     float qx = q_pts[3 * (size_t)i], qy = q_pts[3 * (size_t)i + 1], qz = q_pts[3 * (size_t)i + 2];
     const int* row = idx + (size_t)i * K;
+    // (Round 5: the fp64 multiply-adds are written as fma(): the product of two fp32 values is EXACT in fp64 (48 <= 53 bits), so
+    // a * f + P rounds once either way -- bit-identical to the separate multiply and add of -ffp-contract=off, half the fp64
+    // instructions.)
     // Dot products over the input channels and the sums over the K slots run in fp64 and are rounded once (round 3): an fp32
     // sum is one summation order among many, and on the KITTI branch (80 m coordinates, features near zero behind VN-BN) this
     // kernel's order put the HIP path at twice the reference's own distance from the float64 network (eps 9.0e-4 vs 4.3e-4 of
@@ -111,10 +114,10 @@ __global__ void __launch_bounds__(256) k_vn_gather(const float* __restrict__ q_p
                 for (int c = 0; c < cin; c++) {
                     double a = wfo[c], b = wdo[c];
                     double fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
-                    Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
+                    Px = fma(a, fx, Px); Py = fma(a, fy, Py); Pz = fma(a, fz, Pz); Dx = fma(b, fx, Dx); Dy = fma(b, fy, Dy); Dz = fma(b, fz, Dz);
                 }
                 { double a = wfo[cin], b = wdo[cin];
-                  Px += a * ex; Py += a * ey; Pz += a * ez; Dx += b * ex; Dy += b * ey; Dz += b * ez; }
+                  Px = fma(a, ex, Px); Py = fma(a, ey, Py); Pz = fma(a, ez, Pz); Dx = fma(b, ex, Dx); Dy = fma(b, ey, Dy); Dz = fma(b, ez, Dz); }
                 px = (float)Px; py = (float)Py; pz = (float)Pz; dx = (float)Dx; dy = (float)Dy; dz = (float)Dz;
             }
         }
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(256) k_vn_linear_pre(const float* __restrict__
     double x = 0.0, y = 0.0, z = 0.0;
     for (int c = 0; c < cin; c++) {
         const double a = w[c];
-        x += a * (double)f[3 * c]; y += a * (double)f[3 * c + 1]; z += a * (double)f[3 * c + 2];
+        x = fma(a, (double)f[3 * c], x); y = fma(a, (double)f[3 * c + 1], y); z = fma(a, (double)f[3 * c + 2], z);
     }
     float* d = pf + (size_t)t * 3;
     d[0] = (float)x; d[1] = (float)y; d[2] = (float)z;
@@ -264,8 +267,8 @@ __global__ void __launch_bounds__(256) k_vn_gather_pre(const float* __restrict__
             if (j >= 0) {                                    // shadow: delta = 0, features = 0 (:329-349)
                 const float* a = pf + ((size_t)j * 2 * cout + o) * 3;
                 const float* b = a + (size_t)cout * 3;
-                px = (float)((double)a[0] + wfe * (double)e.x); py = (float)((double)a[1] + wfe * (double)e.y); pz = (float)((double)a[2] + wfe * (double)e.z);
-                dx = (float)((double)b[0] + wde * (double)e.x); dy = (float)((double)b[1] + wde * (double)e.y); dz = (float)((double)b[2] + wde * (double)e.z);
+                px = (float)fma(wfe, (double)e.x, (double)a[0]); py = (float)fma(wfe, (double)e.y, (double)a[1]); pz = (float)fma(wfe, (double)e.z, (double)a[2]);
+                dx = (float)fma(wde, (double)e.x, (double)b[0]); dy = (float)fma(wde, (double)e.y, (double)b[1]); dz = (float)fma(wde, (double)e.z, (double)b[2]);
             }
             vn_epilogue(px, py, pz, dx, dy, dz, has_bn, bsc, bsh, P.slope);
             ax += (double)px; ay += (double)py; az += (double)pz;
@@ -303,7 +306,7 @@ __global__ void __launch_bounds__(256) k_vn_pointwise(const float* __restrict__ 
         for (int c = 0; c < ca; c++) {
             double a = wfo[c], b = has_dir ? wdo[c] : 0.f;
             double fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
-            Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
+            Px = fma(a, fx, Px); Py = fma(a, fy, Py); Pz = fma(a, fz, Pz); Dx = fma(b, fx, Dx); Dy = fma(b, fy, Dy); Dz = fma(b, fz, Dz);
         }
     }
     if (cb > 0) {
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(256) k_vn_pointwise(const float* __restrict__ 
         for (int c = 0; c < cb; c++) {
             double a = wfo[ca + c], b = has_dir ? wdo[ca + c] : 0.f;
             double fx = f[3 * c], fy = f[3 * c + 1], fz = f[3 * c + 2];
-            Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
+            Px = fma(a, fx, Px); Py = fma(a, fy, Py); Pz = fma(a, fz, Pz); Dx = fma(b, fx, Dx); Dy = fma(b, fy, Dy); Dz = fma(b, fz, Dz);
         }
     }
     float px = (float)Px, py = (float)Py, pz = (float)Pz, dx = (float)Dx, dy = (float)Dy, dz = (float)Dz;
@@ -482,7 +485,7 @@ __global__ void __launch_bounds__(256) k_seg_partial(const float* __restrict__ x
     double acc = 0.0;                                        // fp64 sums (tens of thousands of rows per segment), rounded once in k_seg_final
     for (int r = r0 + rr; r < r1; r += rpi) {
         float v = x[(size_t)r * c + ch] - mu;
-        acc += SQ ? (double)v * (double)v : (double)v;
+        acc = SQ ? fma((double)v, (double)v, acc) : acc + (double)v;       // (fp32 x fp32 is exact in fp64: the fma rounds like mul + add)
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -622,7 +625,7 @@ __device__ __forceinline__ void sh_vn_layer(const float (&in)[CIN * 3], const fl
         for (int c = 0; c < CIN; c++) {
             double a = wf[o * CIN + c], b = wd[o * CIN + c];
             double fx = in[3 * c], fy = in[3 * c + 1], fz = in[3 * c + 2];
-            Px += a * fx; Py += a * fy; Pz += a * fz; Dx += b * fx; Dy += b * fy; Dz += b * fz;
+            Px = fma(a, fx, Px); Py = fma(a, fy, Py); Pz = fma(a, fz, Pz); Dx = fma(b, fx, Dx); Dy = fma(b, fy, Dy); Dz = fma(b, fz, Dz);
         }
         float px = (float)Px, py = (float)Py, pz = (float)Pz, dx = (float)Dx, dy = (float)Dy, dz = (float)Dz;
         vn_epilogue(px, py, pz, dx, dy, dz, has_bn, has_bn ? bsc[o] : 0.f, has_bn ? bsh[o] : 0.f, slope);
@@ -656,7 +659,7 @@ __global__ void __launch_bounds__(128) k_score_head_a(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < SH_C2; c++) {
             double a = wl[o * SH_C2 + c];
-            Px += a * (double)y2[3 * c]; Py += a * (double)y2[3 * c + 1]; Pz += a * (double)y2[3 * c + 2];
+            Px = fma(a, (double)y2[3 * c], Px); Py = fma(a, (double)y2[3 * c + 1], Py); Pz = fma(a, (double)y2[3 * c + 2], Pz);
         }
         z[3 * o] = (float)Px; z[3 * o + 1] = (float)Py; z[3 * o + 2] = (float)Pz;
     }
@@ -698,7 +701,7 @@ __global__ void __launch_bounds__(256) k_seg_sq(const float* __restrict__ x, con
     double acc = 0.0;
     for (int r = r0 + rr; r < r1; r += rpi) {
         float v = x[(size_t)r * c + ch] - mu;
-        acc += (double)v * (double)v;
+        acc = fma((double)v, (double)v, acc);
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
