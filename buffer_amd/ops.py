@@ -53,6 +53,10 @@ class CellGrid:
         self.radius = float(radius)
         if cells_per_elem <= 0:
             cells_per_elem = L.buf_grid_default_cells(self.ns, self.nb)
+            f = int(os.environ.get('BUF_GRID_CELLS_PER_POINT', 0))          # development switch: table cells per support point (library default 16)
+            if f > 0:
+                per = (self.ns + self.nb - 1) // max(self.nb, 1)
+                cells_per_elem = min(cells_per_elem, f * per + 65536)
         nbytes = L.buf_grid_ws_bytes(self.ns, self.nb, cells_per_elem)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.supports.device)
         self.g = buf_grid_t()
@@ -111,7 +115,9 @@ def grid_subsample_batch(points, lengths, dl, max_p=0, max_cells=0, features=Non
     lengths = _host_i32(lengths)
     n, nb = int(points.shape[0]), int(lengths.shape[0])
     if max_cells <= 0:
-        max_cells = max(1 << 22, 64 * n)
+        # bucket table of the counting sort: the result does not depend on it (a bucket holds consecutive voxel keys, ranked by key),
+        # the memset + two scan passes over it do cost (64 n cells were 180 MB per call at 32 pairs: most of A1's time)
+        max_cells = max(1 << 16, int(os.environ.get('BUF_VOX_CELLS_PER_POINT', 4)) * n, 2 * nb)
     fd = 0
     out_f = None
     if features is not None:
