@@ -18,6 +18,9 @@ the SAME pair at the SAME keypoint count (no extrapolation).
 Other workloads (each prints its own line with the same metric; they are not the headline):
   --workload stream   BASELINE configs[2]: 1623 synthetic pairs from RAW clouds, pre-processing included, with DGR recall + RR
   --workload kitti    BASELINE configs[3]: KITTI-shape ring scans (~120k returns, 0.05 / 0.30 m voxels), KITTI constants
+  --workload surface  the DROP-IN mode: one 3DMatch-shape pair at 1500 keypoints, every operator of the reference's import surface
+                      called THROUGH THE SHIM PACKAGES in the reference's own call order, shapes and host conventions (numpy in / out
+                      for cpp_wrappers, batch 1, un-fused ball_query + grouping_operation), beside the same call on the host cores
 """
 import argparse
 import ctypes as C
@@ -72,7 +75,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', choices=['pair', 'stream', 'kitti'], default='pair')
+    ap.add_argument('--workload', choices=['pair', 'stream', 'kitti', 'surface'], default='pair')
     ap.add_argument('--keypts', type=int, default=None,
                     help='keypoints per fragment (pair: 5000 = BASELINE; stream / kitti: 1500 = the reference configs)')
     ap.add_argument('--pairs-per-step', type=int, default=None, help='pairs registered per GPU and step (pair: 32, kitti: 16)')
@@ -400,7 +403,7 @@ def main():
         pps = a.pairs_per_step or (16 if kitti else 32)
         job_pairs_per_step = world * pps
     samples = None
-    if a.workload != 'stream':                        # host-side synthetic data first: forked workers, no GPU state yet
+    if a.workload not in ('stream', 'surface'):                        # host-side synthetic data first: forked workers, no GPU state yet
         n_distinct = max(a.distinct_pairs or pps, 1)
         seeds = [1000] + [2000 + rank * 1000 + i for i in range(n_distinct)]
         made = make_samples('kitti' if kitti else 'pair', seeds)
@@ -426,6 +429,10 @@ def main():
     L = _lib.lib()
     if a.workload == 'stream':
         return run_stream(a, rank, world, dev, cdev, dist, L)
+    if a.workload == 'surface':
+        if world != 1:
+            raise SystemExit('--workload surface measures one caller on one GPU: run it with --gpus 1')
+        return run_surface(a, dev, L)
     cfg = replace(KITTI if kitti else THREEDMATCH, num_keypts=keypts, cnn_arith=a.arith)
     pipe = BufferPipeline(cfg, dev)
     limits = pipe.calibrate([calib])                  # same calibration pair on every rank -> identical limits
@@ -559,6 +566,15 @@ def main():
         latency['single_pair_latency_ms'] = med(lambda: pipe.register_batch([inputs[0]], seeds=[0]))
         latency['keypoint_stage_ms'] = {'one_pair': med(lambda: pipe._keypoints([inputs[0]], [0], None)),
                                         'per_step': med(lambda: pipe._keypoints([inputs[k % len(inputs)] for k in range(pps)], list(range(pps)), None), 3)}
+        if not kitti:
+            # the same single caller at the REFERENCE's operating point (ThreeDMatch/config.py:48: 1500 keypoints per fragment), both arithmetics
+            lat15 = {}
+            for ar in ('f32', 'split'):
+                p15 = BufferPipeline(replace(cfg, num_keypts=1500, cnn_arith=ar), dev, limits=limits)
+                p15.register_batch([inputs[0]], seeds=[0])
+                lat15[ar] = round(med(lambda: p15.register_batch([inputs[0]], seeds=[0])), 3)
+                del p15
+            latency['single_pair_latency_ms_1500'] = lat15
     gts = [samples[(a.warmup * pps + n) % len(samples)]['relt_pose'] for n in range(len(all_poses))]    # step i, slot j -> pair (i*pps + j) mod distinct
     ok = dgr_ok(mine.cpu().numpy(), gts)
     ok_ref = dgr_ok(mine.cpu().numpy(), gts, 1.0) if kitti else None      # KITTI/test.py:66-72 as coded: RTE < 0.3 m and RRE < 1 deg
@@ -650,6 +666,271 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ drop-in surface
+def surface_cpu_leg(calls):
+    """The CPU leg of --workload surface (baseline only; the one place of this workload that touches oracle/): every recorded call
+    again on the host cores -- the reference's own cpp_wrappers cores (oracle/_ref, compiled from /root/reference in the build
+    container) for batch_query / subsample_batch, the plain-C restatements of the third-party CUDA operators for the rest (kind
+    'port'; scalar, one thread), numpy for the two gathers and the SVD.  Also the checker: each CPU result is compared with the shim's."""
+    from oracle import cpu
+    cpu.build(ref=True)
+    use_ref = cpu.have_ref()
+    rq = cpu.ref_radius_neighbors if use_ref else cpu.radius_neighbors
+    rs = cpu.ref_grid_subsample_batch if use_ref else cpu.grid_subsample_batch
+
+    def rows_sorted(x):
+        return x[np.lexsort(x.T[::-1])]
+
+    impl = {
+        'batch_query': lambda q, s, qb, sb, radius: rq(q, s, qb, sb, radius),
+        'subsample_batch': lambda p, b, sampleDl: rs(p, b, sampleDl),
+        'furthest_point_sample': lambda xyz, m: cpu.fps(xyz, m),
+        'gather_operation': cpu.gather_operation,
+        'ball_query': lambda r, ns, xyz, new: cpu.ball_query(r, ns, xyz, new),
+        'grouping_operation': cpu.grouping_operation,
+        'KNN': lambda ref, query: cpu.knn(ref, query, 1),
+        'svd': lambda m: np.linalg.svd(m.astype(np.float32)),
+    }
+    for c in calls:
+        fn = impl[c['fn']]
+        t0 = time.perf_counter()
+        want = fn(*c['host_args'])
+        c['ms_cpu'] = (time.perf_counter() - t0) * 1e3
+        got = c['host_out']
+        if c['fn'] == 'batch_query':              # index for index except inside groups of exactly equidistant neighbours (INTEGRATION.md caveat 1)
+            w = min(got.shape[1], want.shape[1])
+            c['agree'] = float((got[:, :w] == want[:, :w]).mean()) if got.shape[0] == want.shape[0] else 0.0
+            c['equal'] = bool(got.shape == want.shape and c['agree'] > 0.995)
+        elif c['fn'] == 'subsample_batch':        # same multiset of rows bit for bit; the reference's row order is its unordered_map's
+            c['equal'] = bool(np.array_equal(got[1], want[1]) and got[0].shape == want[0].shape
+                              and all(np.array_equal(rows_sorted(got[0][lo:hi]), rows_sorted(want[0][lo:hi]))
+                                      for lo, hi in zip(np.cumsum(got[1]) - got[1], np.cumsum(got[1]))))
+        elif c['fn'] == 'KNN':
+            c['equal'] = bool(np.array_equal(got[1], want[1]) and np.allclose(got[0], want[0], rtol=1e-6, atol=1e-7))
+        elif c['fn'] == 'svd':                    # signs are free: singular values, and U S V^T = A
+            u, sv, v = got
+            rec = np.einsum('bij,bj,bkj->bik', u, sv, v)
+            sc = max(float(np.abs(c['host_args'][0]).max()), 1e-30)
+            c['equal'] = bool(np.abs(sv - want[1]).max() < 2e-5 * sc and np.abs(rec - c['host_args'][0]).max() < 2e-5 * sc)
+        else:
+            c['equal'] = bool(np.array_equal(got, want))
+    return 'reference cores (cpp_wrappers) + plain-C port (third-party operators)' if use_ref else 'port'
+
+
+def run_surface(a, dev, L):
+    """--workload surface: what a maintainer gets who ONLY swaps the imports.  One 3DMatch-shape pair at the
+    reference's own operating point (ThreeDMatch/config.py:48: 1500 keypoints); every call the reference's inference makes into a
+    replaced package, in its order, shapes and host conventions, through buffer_amd/shims:
+      ThreeDMatch/dataloader.py:155-224   7 x cpp_neighbors.batch_query + 2 x cpp_subsampling.subsample_batch, numpy in / numpy out
+      models/BUFFER.py:266-271            2 x furthest_point_sample ([1,N',3] -> 1500) + 4 x gather_operation
+      models/patch_embedder.py:100-104    per cloud ball_query(0.3, 512) + grouping_operation over the shuffled 2 cm cloud
+      utils/common.py:442-455             per cloud ball_query(delta / rad_n, 10) + grouping_operation, batch = the 1500 patches, 420 centres
+      models/BUFFER.py:347,352            2 x KNN(k=1, transpose_mode=True) on [1,1500,32]
+      utils/common.py:715                 svd of [1500,3,3] covariances (cal_Z_axis: only when no reference axis is passed -- off the inference path)
+    Inputs of every call are the real intermediates of this pair (BufferPipeline.register(detail=True), untimed).  Each call is timed
+    as its caller sees it: host clock around the call, device synchronised on both sides, median of `--steps` repetitions.  Beside
+    each: the same call on the host cores (surface_cpu_leg) and, per stage, the fused device form BufferPipeline uses instead."""
+    from buffer_amd import ops, pyramid, shims
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.pipeline import BufferPipeline
+    from buffer_amd.point_learner import orient_axes
+    shims.install()
+    import cpp_wrappers.cpp_neighbors.radius_neighbors as cpp_neighbors
+    import cpp_wrappers.cpp_subsampling.grid_subsampling as cpp_subsampling
+    import pointnet2_ops.pointnet2_utils as pnt2
+    from knn_cuda import KNN
+    from torch_batch_svd import svd
+
+    reps = max(a.steps, 3)
+    keypts = a.keypts or 1500
+    cfg = replace(THREEDMATCH, num_keypts=keypts, cnn_arith=a.arith)
+    calib, sample = _make_sample(('pair', 1000)), _make_sample(('pair', 2000))
+    pipe = BufferPipeline(cfg, dev)
+    limits = pipe.calibrate([calib])
+    inp = pipe.upload(sample)
+    rng = np.random.default_rng(0)
+    perms = [torch.from_numpy(rng.permutation(int(r.shape[0]))).to(dev) for r in (inp['src_raw'], inp['tgt_raw'])]
+    _, d = pipe.register(inp, seed=0, perms=perms, detail=True)
+    torch.cuda.synchronize()
+
+    calls = []
+
+    def host(x):
+        if isinstance(x, torch.Tensor):
+            return x.detach().cpu().numpy()
+        if isinstance(x, (tuple, list)):
+            return tuple(host(y) for y in x)
+        return x
+
+    def call(op, fn_name, site, shape, fn, *args, **kw):
+        """one call of the surface: warm once, then the median of `reps` synchronised repetitions on the host clock"""
+        out = fn(*args, **kw)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn(*args, **kw)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        calls.append(dict(op=op, fn=fn_name, site=site, shape=shape, ms_gpu=float(np.median(ts)),
+                          host_args=tuple(host(x) for x in args) + tuple(host(v) for v in kw.values()), host_out=host(out)))
+        return out
+
+    # ---- collate (ThreeDMatch/dataloader.py:155-224): numpy in, numpy out, as the DataLoader worker calls it
+    pts = np.concatenate([sample['src_sds_pts'][:, :3], sample['tgt_sds_pts'][:, :3]]).astype(np.float32)
+    lens = np.array([len(sample['src_sds_pts']), len(sample['tgt_sds_pts'])], np.int32)
+    r = cfg.voxel_size_0 * cfg.conv_radius
+    bq, sb = 'cpp_neighbors.batch_query', 'cpp_subsampling.subsample_batch'
+    for layer in range(3):
+        call(bq, 'batch_query', 'ThreeDMatch/dataloader.py:172', f'conv l{layer}: {len(pts)} x {len(pts)}, r={r:.2f}',
+             cpp_neighbors.batch_query, pts, pts, lens, lens, radius=r)
+        if layer == 2:
+            break
+        dl = 2 * r / cfg.conv_radius
+        pool_p, pool_b = call(sb, 'subsample_batch', 'ThreeDMatch/dataloader.py:190', f'l{layer}: {len(pts)} pts, dl={dl:.3f}',
+                              cpp_subsampling.subsample_batch, pts, lens, sampleDl=dl)
+        call(bq, 'batch_query', 'ThreeDMatch/dataloader.py:196', f'pool l{layer}: {len(pool_p)} x {len(pts)}, r={r:.2f}',
+             cpp_neighbors.batch_query, pool_p, pts, pool_b, lens, radius=r)
+        call(bq, 'batch_query', 'ThreeDMatch/dataloader.py:200', f'up l{layer}: {len(pts)} x {len(pool_p)}, r={2 * r:.2f}',
+             cpp_neighbors.batch_query, pts, pool_p, lens, pool_b, radius=2 * r)
+        pts, lens, r = pool_p, pool_b, 2 * r
+
+    # ---- keypoints (models/BUFFER.py:255-271)
+    n_src = int(inp['lengths'][0])
+    pts0, score = d['pyr']['points'][0], d['score'][:, 0]
+    kp, ka, cand = [], [], []
+    for lo, hi in ((0, n_src), (n_src, int(pts0.shape[0]))):
+        keep = torch.where(score[lo:hi] > cfg.keypts_th)[0]
+        p = pts0[lo:hi][keep].contiguous()
+        ax = orient_axes(d['axis'][lo:hi], pts0[lo:hi])[keep].contiguous()
+        cand.append(int(p.shape[0]))
+        p_f, a_f = p[None].transpose(1, 2).contiguous(), ax[None].transpose(1, 2).contiguous()
+        idx = call('pnt2.furthest_point_sample', 'furthest_point_sample', 'models/BUFFER.py:266-267', f'[1,{p.shape[0]},3] -> {keypts}',
+                   pnt2.furthest_point_sample, p[None], keypts)
+        k1 = call('pnt2.gather_operation', 'gather_operation', 'models/BUFFER.py:268-271', f'[1,3,{p.shape[0]}] by [1,{keypts}]',
+                  pnt2.gather_operation, p_f, idx)
+        a1 = call('pnt2.gather_operation', 'gather_operation', 'models/BUFFER.py:268-271', f'[1,3,{p.shape[0]}] by [1,{keypts}]',
+                  pnt2.gather_operation, a_f, idx)
+        kp.append(k1.transpose(1, 2).contiguous())
+        ka.append(a1.transpose(1, 2).contiguous())
+    assert all(torch.equal(kp[i][0], d['kpts'][i]) for i in range(2)), 'shim keypoints differ from BufferPipeline.register()'
+
+    # ---- patches (models/patch_embedder.py:93-104) and the SPT ball queries (utils/common.py:431-455)
+    raws = (inp['src_raw'], inp['tgt_raw'])
+    voxel_r = cfg.delta / cfg.rad_n
+    centres = pipe.desc.centres[None].repeat(keypts, 1, 1).contiguous()
+    covs = []
+    for i in range(2):
+        cloud = raws[i][perms[i]][None].contiguous()
+        nf = int(cloud.shape[1])
+        gi = call(f'pnt2.ball_query({cfg.des_r}, {cfg.num_points_per_patch})', 'ball_query', 'models/patch_embedder.py:100',
+                  f'[1,{nf},3] x [1,{keypts},3]', pnt2.ball_query, cfg.des_r, cfg.num_points_per_patch, cloud, kp[i])
+        call('pnt2.grouping_operation (patches)', 'grouping_operation', 'models/patch_embedder.py:102-104',
+             f'[1,3,{nf}] by [1,{keypts},{cfg.num_points_per_patch}]', pnt2.grouping_operation, cloud.transpose(1, 2).contiguous(), gi)
+        patches = d['desc'][i]['patches'].contiguous()                      # aligned + normalised [P,512,3]: what SPT receives
+        vi = call(f'pnt2.ball_query({voxel_r:.3f}, {cfg.voxel_sample})', 'ball_query', 'utils/common.py:442',
+                  f'[{keypts},{patches.shape[1]},3] x [{keypts},{centres.shape[1]},3]', pnt2.ball_query, voxel_r, cfg.voxel_sample, patches, centres)
+        call('pnt2.grouping_operation (voxels)', 'grouping_operation', 'utils/common.py:452-455',
+             f'[{keypts},3,{patches.shape[1]}] by [{keypts},{centres.shape[1]},{cfg.voxel_sample}]', pnt2.grouping_operation,
+             patches.transpose(1, 2).contiguous(), vi)
+        covs.append(torch.matmul(patches.transpose(-1, -2), patches))
+
+    # ---- mutual matching (models/BUFFER.py:347,352)
+    des = [d['desc'][i]['desc'].contiguous() for i in range(2)]
+    knn = KNN(k=1, transpose_mode=True)
+    call('knn_cuda.KNN(k=1)', 'KNN', 'models/BUFFER.py:347', f'ref [1,{keypts},32], query [1,{keypts},32]', knn, des[1][None], des[0][None])
+    call('knn_cuda.KNN(k=1)', 'KNN', 'models/BUFFER.py:352', f'ref [1,{keypts},32], query [1,{keypts},32]', knn, des[0][None], des[1][None])
+    for i in range(2):
+        call('torch_batch_svd.svd', 'svd', 'utils/common.py:715 (cal_Z_axis: off the inference path, z_axis is given)', f'[{keypts},3,3]', svd, covs[i])
+
+    # ---- the fused device forms BufferPipeline runs in place of those calls (same pair, same inputs already in HBM)
+    def med(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+
+    cp = [pts0[lo:hi][torch.where(score[lo:hi] > cfg.keypts_th)[0]] for lo, hi in ((0, n_src), (n_src, int(pts0.shape[0])))]
+    cat_cand, kp_cat, ka_cat = torch.cat(cp).contiguous(), torch.cat([k[0] for k in kp]).contiguous(), torch.cat([k[0] for k in ka]).contiguous()
+    sup = torch.cat([raws[i][perms[i]] for i in range(2)]).contiguous()
+    sup_len = [int(raws[0].shape[0]), int(raws[1].shape[0])]
+    init_patches = ops.select_patches_batched(sup, sup_len, kp_cat, keypts, cfg.des_r, cfg.num_points_per_patch)
+    dd = torch.stack(des)
+    fused = [
+        dict(stage='pyramid.build_pyramid (3 cell grids, 7 queries, 2 subsamplings; device in, device out)',
+             replaces=[bq, sb], ms=med(lambda: pyramid.build_pyramid(inp['points'], inp['lengths'], limits, cfg))),
+        dict(stage='ops.furthest_point_sample_ragged (both clouds, one launch) + row gathers',
+             replaces=['pnt2.furthest_point_sample', 'pnt2.gather_operation'],
+             ms=med(lambda: (lambda f: [cp[i][f[i]] for i in range(2)])(ops.furthest_point_sample_ragged(cat_cand, cand, keypts).long()))),
+        dict(stage='ops.select_patches_batched (ball query + grouping + keypoint substitution, both clouds, no index tensor)',
+             replaces=[c['op'] for c in calls if c['site'].startswith('models/patch_embedder.py')][:2],
+             ms=med(lambda: ops.select_patches_batched(sup, sup_len, kp_cat, keypts, cfg.des_r, cfg.num_points_per_patch))),
+        dict(stage='ops.patch_voxelize (axis align + 420 ball queries + var_to_invar + point MLP + max-pool per patch, both clouds)',
+             replaces=[c['op'] for c in calls if c['site'].startswith('utils/common.py:4')][:2],
+             ms=med(lambda: ops.patch_voxelize(init_patches, ka_cat, cfg.des_r, pipe.desc.centres, pipe.desc.azi_cs, voxel_r, cfg.voxel_sample,
+                                               pipe.desc.mlp_w, pipe.desc.mlp_b, pipe.desc.mlp_s, pipe.desc.mlp_t, cfg.azi_n, False))),
+        dict(stage='ops.knn x 2 (matrix-pipe ranking, fp32 decision)', replaces=['knn_cuda.KNN(k=1)'],
+             ms=med(lambda: (ops.knn(dd[1:2], dd[0:1], 1), ops.knn(dd[0:1], dd[1:2], 1)))),
+    ]
+    whole = med(lambda: pipe.register_batch([inp], seeds=[0]))
+
+    kind = None
+    if not a.no_cpu_baseline:
+        kind = surface_cpu_leg(calls)
+    table, order = {}, []
+    for c in calls:
+        if c['op'] not in table:
+            order.append(c['op'])
+            table[c['op']] = dict(op=c['op'], site=c['site'], calls=0, ms_gpu=0.0, ms_cpu=0.0 if kind else None,
+                                  equal_to_cpu=True if kind else None, shapes=[])
+        t = table[c['op']]
+        t['calls'] += 1
+        t['ms_gpu'] += c['ms_gpu']
+        t['shapes'].append(c['shape'])
+        if kind:
+            t['ms_cpu'] += c['ms_cpu']
+            t['equal_to_cpu'] = bool(t['equal_to_cpu'] and c['equal'])
+    rows = [table[k] for k in order]
+    for t in rows:
+        t['ms_gpu'] = round(t['ms_gpu'], 3)
+        t['ms_cpu'] = None if t['ms_cpu'] is None else round(t['ms_cpu'], 2)
+    on_path = [t for t in rows if 'svd' not in t['op']]
+    sum_gpu = sum(t['ms_gpu'] for t in on_path)
+    sum_cpu = sum(t['ms_cpu'] for t in on_path) if kind else None
+    sum_fused = sum(f['ms'] for f in fused)
+    out = {
+        'metric': 'registration pairs/sec', 'value': 1e3 / sum_gpu, 'unit': 'pairs/s', 'n_gpus': 1, 'steps': reps, 'warmup': 1,
+        'ms_per_step': sum_gpu, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'operator surface of one 3DMatch-shape pair through the shim packages (drop-in mode): the calls the reference '
+                               'makes into cpp_wrappers / pointnet2_ops / knn_cuda / torch_batch_svd, in its order, shapes and host conventions; '
+                               'value = 1 / (sum of those calls): the surface alone, NOT a registration rate -- the reference\'s torch layers '
+                               'between the calls are not part of it',
+                   'keypoints_per_fragment': keypts, 'fds_points': sup_len, 'sds_points': [int(x) for x in inp['lengths']],
+                   'candidates_above_threshold': cand, 'neighbor_limits': limits, 'repetitions_per_call': reps,
+                   'timing': 'host clock around each call, device synchronised on both sides, median; cpp_wrappers calls include their numpy <-> device copies'},
+        'surface': {'ops': rows, 'sum_ms_gpu': round(sum_gpu, 3), 'sum_ms_cpu': None if sum_cpu is None else round(sum_cpu, 1),
+                    'sum_excludes': 'torch_batch_svd.svd (no call on the inference path)',
+                    'fused': [dict(f, ms=round(f['ms'], 3)) for f in fused], 'sum_ms_fused': round(sum_fused, 3),
+                    'buffer_pipeline_whole_pair_ms': round(whole, 3),
+                    'buffer_pipeline_note': 'BufferPipeline.register_batch([pair]): the WHOLE inference of this pair (operators + both CNNs + pose recovery), '
+                                            'un-batched, host clock'},
+    }
+    if kind:
+        out['cpu_baseline'] = {'value': 1e3 / sum_cpu, 'unit': 'pairs/s', 'cores': 1, 'kind': kind,
+                               'sample': 'the same calls with the same inputs, once each, one host thread'}
+    if a.detail_json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.detail_json)), exist_ok=True)
+        with open(a.detail_json, 'w') as f:
+            json.dump(dict(out, calls=[{k: v for k, v in c.items() if k not in ('host_args', 'host_out')} for c in calls]), f)
+    print(json.dumps(out), flush=True)
 
 
 def run_stream(a, rank, world, dev, cdev, dist, L):

@@ -50,6 +50,8 @@ def test_bench_json_line(dev, tmp_path):
         assert set(o) == {'kernel', 'bound', 'frac', 'avg_us', 'traffic_ratio'}
         assert o['avg_us'] > 0 and (o['frac'] is None or 0 < o['frac'] < 1.0), o
     assert d['single_pair_latency_ms'] > 0 and d['keypoint_stage_ms']['one_pair'] > 0 and d['keypoint_stage_ms']['per_step'] > 0
+    l15 = d['single_pair_latency_ms_1500']               # one caller at the reference's operating point (1500 keypoints), both arithmetics
+    assert set(l15) == {'f32', 'split'} and 0 < l15['split'] and 0 < l15['f32'] < 200
     c = d['cpu_baseline']
     assert c['kind'] in ('reference cores (pyramid) + restated model', 'port') and c['cores'] >= 1 and c['workers'] >= 1 and c['value'] > 0 and c['unit'] == 'pairs/s'
     assert 'nothing scaled' in c['sample'] and c['stages_s']['descriptors'] > 0
@@ -63,13 +65,40 @@ def test_bench_json_line(dev, tmp_path):
     # the driver keeps the last 2000 characters of the line: the four round-4 keys and every compact entry must be inside them
     line = json.dumps(d)
     tail = line[-2000:]
-    for k in ('"single_pair_latency_ms"', '"keypoint_stage_ms"', '"roofline_other"', 'k_grid_query', 'k_fps'):
+    for k in ('"single_pair_latency_ms"', '"single_pair_latency_ms_1500"', '"keypoint_stage_ms"', '"roofline_other"', 'k_grid_query', 'k_fps'):
         assert k in tail, k
     full = json.load(open(detail))
     assert full['roofline_other'][0]['launches'] > 0 and 'timed_kernel_ms_per_step' in full
     # instruction counts the vector-issue roofline is priced with come from profiles/instr.json, measured on THIS library version
     vox = [o for o in full['roofline_other'] if o['kernel'].startswith('k_patch_voxelize')][0]
     assert vox['bound'] == 'valu' and vox['instr_current'] is True, 'profiles/instr.json is stale: re-run tools/profile_round.sh (make_instr.py)'
+
+
+def test_bench_surface_workload_line(dev, tmp_path):
+    """--workload surface: the drop-in mode measured -- every operator of the reference's import surface through the shim packages in
+    the reference's call order (7 batch_query + 2 subsample_batch with numpy in / out, 2 FPS + 4 gathers, ball_query + grouping for the
+    patches and for the 420 voxel centres, 2 KNN, svd), the same calls on the host beside them, and each shim result equal to the CPU's."""
+    detail = str(tmp_path / 'surface.json')
+    d = _run(['--workload', 'surface', '--keypts', '300', '--steps', '3', '--detail-json', detail])
+    assert d['metric'] == 'registration pairs/sec' and d['unit'] == 'pairs/s' and d['n_gpus'] == 1 and d['vs_baseline'] is None
+    assert 'drop-in mode' in d['config']['workload'] and 'NOT a registration rate' in d['config']['workload']
+    s = d['surface']
+    by = {o['op']: o for o in s['ops']}
+    want = {'cpp_neighbors.batch_query': 7, 'cpp_subsampling.subsample_batch': 2, 'pnt2.furthest_point_sample': 2, 'pnt2.gather_operation': 4,
+            'pnt2.ball_query(0.3, 512)': 2, 'pnt2.grouping_operation (patches)': 2, 'pnt2.ball_query(0.267, 10)': 2,
+            'pnt2.grouping_operation (voxels)': 2, 'knn_cuda.KNN(k=1)': 2, 'torch_batch_svd.svd': 2}
+    assert {k: v['calls'] for k, v in by.items()} == want
+    for o in s['ops']:
+        assert set(o) == {'op', 'site', 'calls', 'ms_gpu', 'ms_cpu', 'equal_to_cpu', 'shapes'}
+        assert o['ms_gpu'] > 0 and o['ms_cpu'] > 0 and o['equal_to_cpu'] is True, o
+    on_path = [o for o in s['ops'] if 'svd' not in o['op']]
+    assert abs(s['sum_ms_gpu'] - sum(o['ms_gpu'] for o in on_path)) < 0.01 and abs(d['value'] - 1e3 / s['sum_ms_gpu']) < 1e-3 * d['value']
+    assert abs(s['sum_ms_cpu'] - sum(o['ms_cpu'] for o in on_path)) < 0.5
+    assert len(s['fused']) == 5 and all(f['ms'] > 0 and f['replaces'] for f in s['fused']) and s['buffer_pipeline_whole_pair_ms'] > 0
+    c = d['cpu_baseline']
+    assert c['cores'] == 1 and c['unit'] == 'pairs/s' and abs(c['value'] - 1e3 / s['sum_ms_cpu']) < 1e-2 * c['value']
+    full = json.load(open(detail))
+    assert len(full['calls']) == 27 and all(x['equal'] for x in full['calls'])
 
 
 def test_bench_strong_scaling_mode_two_ranks_over_gloo(dev):
