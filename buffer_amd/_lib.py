@@ -77,6 +77,9 @@ _SIGNATURES = {
     "buf_patch_voxelize": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _sz, _vp]),
     "buf_cylindrical_net_wg": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_cylindrical_net_wg_supports": (_i, [_vp, _vp]),
+    "buf_cylindrical_net_split_safe": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "buf_cost_volume_net_split_safe": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_cylindrical_net_split": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_cylindrical_net_split_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "buf_split_gemm_count": (C.c_longlong, [_i, _i, _i, _i]),

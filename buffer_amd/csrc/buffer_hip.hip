@@ -20,3 +20,4 @@
 // two fp32-MFMA CNN kernels, whose Winograd transforms the compiler had built on v_pk_add_f32, measured 0.9 % FASTER without them.
 #include "convnet_wg.hip"
 #include "costnet.hip"
+#include "split_safe.hip"

@@ -92,6 +92,21 @@ __global__ void __launch_bounds__(DH_THREADS) k_desc_head(const float* __restric
     dh_body((dh_lds*)ys, (dh_lds*)wgt, (dh_lds*)nrm, (dh_lds*)fs, (dh_lds*)hp, params, desc, equi, patch, tid);
 }
 
+// The head for the patches with only_if[p] != 0 only; y may BE equi (the map is in LDS before the first store): no __restrict__ here.
+__global__ void __launch_bounds__(DH_THREADS) k_desc_head_masked(const float* y, const float* __restrict__ params, float* __restrict__ desc,
+                                                              float* equi, const int* __restrict__ only_if)
+{
+    __shared__ __attribute__((aligned(16))) float ys[DH_C * CN_POS];
+    __shared__ __attribute__((aligned(16))) float wgt[CN_POS], nrm[CN_POS], fs[DH_C];
+    __shared__ __attribute__((aligned(16))) float hp[DH_NPARAM + 3];
+    const int patch = blockIdx.x, tid = threadIdx.x;
+    if (only_if[patch] == 0) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(y + (size_t)patch * DH_C * CN_POS);
+    for (int i = tid; i < DH_C * CN_POS / 4; i += DH_THREADS) reinterpret_cast<f32x4*>(ys)[i] = src[i];
+    __syncthreads();
+    dh_body((dh_lds*)ys, (dh_lds*)wgt, (dh_lds*)nrm, (dh_lds*)fs, (dh_lds*)hp, params, desc, equi, patch, tid);
+}
+
 // y f32[np,32,140] -> desc f32[np,32], equi f32[np,32,140].  params: DEVICE f32[545] = w0 [16][32], b0 [16], w3 [16], b3 (BN folded).
 extern "C" int buf_descriptor_head(const float* y, int npatch, const float* params, float* desc, float* equi, void* stream)
 {

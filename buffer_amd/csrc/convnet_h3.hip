@@ -103,6 +103,7 @@ struct CylH3Params {
     const float* bias[H3_LAYERS];
     int cin[H3_LAYERS], cout[H3_LAYERS], relu[H3_LAYERS];
     int* status;                        // nullable: bit 0 set when an activation left the f16 range (|v| >= 65504)
+    int* flags;                         // nullable: int32[np], flags[p] = 1 when patch p did (caller zero-fills; buf_cylindrical_net_split_safe)
     const float* head;                  // nullable: parameters of the attention-pooling head (csrc/convnet.hip dh_body) -> fused behind the last layer
     float* desc;                        // with head: desc f32[np,32], equi f32[np,32,140] instead of y
     float* equi;
@@ -264,7 +265,7 @@ __device__ __forceinline__ void h3_gemm(unsigned lds0, __amdgpu_buffer_rsrc_t rs
 // C/D layout gives a lane 4 consecutive output channels of one position: one ds_write_b64 per plane) or y[32][140] in fp32.
 template <int PT, bool LAST>
 __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT], const h3f4 (&ac)[2][PT], int relu, int ct, int pt0, unsigned lane,
-                                         float* __restrict__ y, int* status, bool to_lds = false)
+                                         float* __restrict__ y, int* status, int* flag, bool to_lds = false)
 {
     const int li = lane & 15, lk = lane >> 4;
     float amax = 0.f;
@@ -317,12 +318,15 @@ __device__ __forceinline__ void h3_store(unsigned lds0, const h3f4 (&am)[2][PT],
             }
         }
     }
-    if (!LAST && status && __builtin_amdgcn_ballot_w64(!(amax < 65504.f)) != 0 && lane == 0) atomicOr(status, 1);
+    if (!LAST && (status || flag) && __builtin_amdgcn_ballot_w64(!(amax < 65504.f)) != 0 && lane == 0) {
+        if (status) atomicOr(status, 1);
+        if (flag) *flag = 1;                                     // this patch goes through the fp32 kernel again (buf_cylindrical_net_split_safe)
+    }
 }
 
 template <int PT, int KS>
 __device__ __forceinline__ void h3_layer(unsigned lds0, const void* wt, const float* bias, int relu, int ct, int pt0, unsigned lane, bool last,
-                                         float* y, int* status, bool to_lds)
+                                         float* y, int* status, int* flag, bool to_lds)
 {
     h3f4 am[2][PT], ac[2][PT];
 #pragma unroll
@@ -339,21 +343,21 @@ __device__ __forceinline__ void h3_layer(unsigned lds0, const void* wt, const fl
     H3_STAMP_AT(31)
     unsigned lane_s = lane;
     asm volatile("" : "+v"(lane_s));                             // the store addresses are formed here, not hoisted out of the layer loop (and spilled)
-    if (last) h3_store<PT, true>(lds0, am, ac, relu, ct, pt0, lane_s, y, status, to_lds);
-    else h3_store<PT, false>(lds0, am, ac, relu, ct, pt0, lane_s, y, status);
+    if (last) h3_store<PT, true>(lds0, am, ac, relu, ct, pt0, lane_s, y, status, flag, to_lds);
+    else h3_store<PT, false>(lds0, am, ac, relu, ct, pt0, lane_s, y, status, flag);
 }
 
 template <int KS>
 __device__ __forceinline__ void h3_dispatch(unsigned lds0, const void* wt, const float* bias, int relu, int cout, int w, unsigned lane, bool last,
-                                            float* y, int* status, bool to_lds)
+                                            float* y, int* status, int* flag, bool to_lds)
 {
-    if (cout == 128) h3_layer<9, KS>(lds0, wt, bias, relu, w, 0, lane, last, y, status, to_lds);
+    if (cout == 128) h3_layer<9, KS>(lds0, wt, bias, relu, w, 0, lane, last, y, status, flag, to_lds);
     else if (cout == 64) {
-        if (w < 2) h3_layer<4, KS>(lds0, wt, bias, relu, w & 1, 0, lane, last, y, status, to_lds);
-        else h3_layer<5, KS>(lds0, wt, bias, relu, w & 1, 4, lane, last, y, status, to_lds);
+        if (w < 2) h3_layer<4, KS>(lds0, wt, bias, relu, w & 1, 0, lane, last, y, status, flag, to_lds);
+        else h3_layer<5, KS>(lds0, wt, bias, relu, w & 1, 4, lane, last, y, status, flag, to_lds);
     } else {
-        if (w == 3) h3_layer<3, KS>(lds0, wt, bias, relu, 0, 6, lane, last, y, status, to_lds);
-        else h3_layer<2, KS>(lds0, wt, bias, relu, 0, 2 * w, lane, last, y, status, to_lds);
+        if (w == 3) h3_layer<3, KS>(lds0, wt, bias, relu, 0, 6, lane, last, y, status, flag, to_lds);
+        else h3_layer<2, KS>(lds0, wt, bias, relu, 0, 2 * w, lane, last, y, status, flag, to_lds);
     }
 }
 
@@ -364,6 +368,7 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
     const int patch = blockIdx.x, tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid / WAVE);
     const unsigned lane = tid & (WAVE - 1);
+    int* const flag = P.flags ? P.flags + patch : nullptr;
     // address table: tab[tap][p] = row (in 16-byte units) that tap (dy, dx) reads for output position p
     for (int e = tid; e < 9 * 256; e += H3_THREADS) {
         const int tap = e >> 8, t = e & 15, m = (e >> 4) & 15;               // e = (tap, lane m, tile slot t)
@@ -408,7 +413,10 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
                 *(__attribute__((address_space(3))) unsigned*)(size_t)(ad + H3_LO) = __builtin_bit_cast(unsigned, lo);
             }
         }
-        if (P.status && __builtin_amdgcn_ballot_w64(amax >= H3_F16_LIMIT_BITS) != 0 && lane == 0) atomicOr(P.status, 1);
+        if ((P.status || flag) && __builtin_amdgcn_ballot_w64(amax >= H3_F16_LIMIT_BITS) != 0 && lane == 0) {
+            if (P.status) atomicOr(P.status, 1);
+            if (flag) *flag = 1;
+        }
         const int nz = (cpad - cin0) >> 1;                       // zero channel pairs up to the k-step boundary (48 -> 64)
         for (int i = tid; i < H3_NPOS * nz; i += H3_THREADS) {
             const int p = i / nz, cp = (cin0 >> 1) + i - p * nz, py = p / 20;
@@ -424,9 +432,9 @@ __global__ void __launch_bounds__(H3_THREADS, 2) k_cyl_net_h3(const float* __res
         const int ks = (P.cin[l] + 31) >> 5, cout = P.cout[l];
         const bool last = l == H3_LAYERS - 1;
         float* yo = y + (size_t)patch * cout * H3_NPOS;
-        if (ks == 4) h3_dispatch<4>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, last && P.head != nullptr);
-        else if (ks == 2) h3_dispatch<2>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, last && P.head != nullptr);
-        else h3_dispatch<1>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, last && P.head != nullptr);
+        if (ks == 4) h3_dispatch<4>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, flag, last && P.head != nullptr);
+        else if (ks == 2) h3_dispatch<2>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, flag, last && P.head != nullptr);
+        else h3_dispatch<1>(lds0, P.wt[l], P.bias[l], P.relu[l], cout, w, lane, last, yo, P.status, flag, last && P.head != nullptr);
 #ifdef H3_STAMP
         if ((threadIdx.x & 63) == 0) {      // gemm end / barrier end of this layer (slots 30, 31) -> per-layer slots
             long long* q = h3_stamp_ptr + ((size_t)blockIdx.x * 4 + threadIdx.x / 64) * 32;
@@ -506,7 +514,8 @@ extern "C" int buf_split_tile_filters(const float* w_host, int cout, int cin, un
 
 // x f32[np,Cin0,140] -> y f32[np,32,140] with fp32-equivalent arithmetic on the f16 matrix pipe (header: buf_cylindrical_net_split).
 static int h3_launch(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host, const int* cin_host,
-                     const int* cout_host, const int* relu_host, float* y, const float* head, float* desc, float* equi, int* status_dev, void* stream);
+                     const int* cout_host, const int* relu_host, float* y, const float* head, float* desc, float* equi, int* status_dev, void* stream,
+                     int* flags_dev = nullptr);
 
 extern "C" int buf_cylindrical_net_split(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host,
                                          const int* cin_host, const int* cout_host, const int* relu_host, float* y, int* status_dev, void* stream)
@@ -526,7 +535,8 @@ extern "C" int buf_cylindrical_net_split_head(const float* x, int npatch, const 
 }
 
 static int h3_launch(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host, const int* cin_host,
-                     const int* cout_host, const int* relu_host, float* y, const float* head, float* desc, float* equi, int* status_dev, void* stream)
+                     const int* cout_host, const int* relu_host, float* y, const float* head, float* desc, float* equi, int* status_dev, void* stream,
+                     int* flags_dev)
 {
     BUF_REQUIRE(npatch >= 0, BUF_EINVAL, "buf_cylindrical_net_split: npatch=%d", npatch);
     if (npatch == 0) return BUF_OK;
@@ -544,6 +554,7 @@ static int h3_launch(const float* x, int npatch, const void* const* wt_host, con
     }
     BUF_REQUIRE(P.cout[H3_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_split: the last layer must have 32 channels");
     P.status = status_dev;
+    P.flags = flags_dev;
     P.head = head; P.desc = desc; P.equi = equi;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cyl_net_h3, H3_LDS, grant)) return rc;

@@ -67,6 +67,7 @@ struct CylWgParams {
     const float* wt[WG_LAYERS];     // Winograd-domain weights, [i][k-step][N-tile][lane][j] (ops.winograd_tile_weights)
     const float* bias[WG_LAYERS];   // [Cout]
     int cin[WG_LAYERS], cout[WG_LAYERS], relu[WG_LAYERS];
+    const int* only_if;             // nullable: workgroup p runs only if only_if[p] != 0 (the fp32 re-run of buf_cylindrical_net_split_safe)
 #ifdef WG_STAMP
     long long* stamps;              // development build (-DWG_STAMP): [workgroup][wave][20] s_memtime at the layer boundaries
 #endif
@@ -655,6 +656,7 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
     extern __shared__ float lds[];                   // [128][160]
     float* act = lds;
     const int patch = blockIdx.x;
+    if (P.only_if && P.only_if[patch] == 0) return;      // masked re-run: the patches the split-f16 kernel flagged, nothing else
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     WG_STAMP_AT(17)
 #ifdef WG_STAMP
@@ -753,8 +755,31 @@ extern "C" int buf_winograd_tile_weights(const float* w_host, int cout, int cin,
 extern "C" int buf_winograd_group(int cin, int cout) { return wg_group(cin, cout); }
 
 // x f32[np,48,140] -> y f32[np,32,140]; weights in the Winograd-domain tiling (see CylWgParams).
+static int wg_launch(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host, const int* cin_host,
+                     const int* cout_host, const int* relu_host, float* y, const int* only_if, void* stream);
+
 extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                       const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream)
+{
+    return wg_launch(x, npatch, wt_host, bias_host, cin_host, cout_host, relu_host, y, nullptr, stream);
+}
+
+// 0 when the Winograd fp32 kernel is built for this stack of widths (what buf_cylindrical_net_wg would accept), else BUF_EINVAL with the reason
+extern "C" int buf_cylindrical_net_wg_supports(const int* cin_host, const int* cout_host)
+{
+    BUF_REQUIRE(cin_host && cout_host, BUF_EINVAL, "buf_cylindrical_net_wg_supports: null argument");
+    for (int l = 0; l < WG_LAYERS; l++) {
+        const int ci = cin_host[l], co = cout_host[l];
+        const bool ok = ci > 0 && ci % 16 == 0 && ci <= WG_MAXC && (co == 32 || co == 64 || co == 128) && (co != 128 || ci % 32 == 0) &&
+                        (co != 32 || (ci % 32 == 0 && ci <= 64)) && (l == 0 || ci == cout_host[l - 1]) && (l == 0 || cout_host[l - 1] != 32 || co == 32);
+        BUF_REQUIRE(ok, BUF_EINVAL, "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d", l, ci, co);
+    }
+    BUF_REQUIRE(cout_host[WG_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_wg: the last layer must have 32 channels");
+    return BUF_OK;
+}
+
+static int wg_launch(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host, const int* cin_host,
+                     const int* cout_host, const int* relu_host, float* y, const int* only_if, void* stream)
 {
     BUF_REQUIRE(npatch >= 0, BUF_EINVAL, "buf_cylindrical_net_wg: npatch=%d", npatch);
     if (npatch == 0) return BUF_OK;
@@ -777,13 +802,14 @@ extern "C" int buf_cylindrical_net_wg(const float* x, int npatch, const float* c
                     "buf_cylindrical_net_wg: layer %d has unsupported widths %d -> %d (only 32-output layers may follow a 32-output layer)", l, P.cin[l], P.cout[l]);
     }
     BUF_REQUIRE(P.cout[WG_LAYERS - 1] == 32, BUF_EINVAL, "buf_cylindrical_net_wg: the last layer must have 32 channels");
+    P.only_if = only_if;
     size_t lds = sizeof(float) * WG_BUF;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cyl_net_wg, lds, grant)) return rc;
     double macs = 0;
     for (int l = 0; l < WG_LAYERS; l++) macs += 9.0 * P.cin[l] * P.cout[l];
     TimedSpan span;
-    bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * 140 * macs * npatch, BUF_TIMED_CYL_NET);
+    bool timed = !only_if && timing_begin((hipStream_t)stream, &span, 2.0 * 140 * macs * npatch, BUF_TIMED_CYL_NET);   // (a masked re-run is not a full launch)
 #ifdef WG_STAMP
     BUF_CHECK_HIP(hipMalloc(&P.stamps, (size_t)npatch * (4 * 20 + 4) * sizeof(long long)));
     BUF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(wg_stamp_ptr), &P.stamps, sizeof(P.stamps)));

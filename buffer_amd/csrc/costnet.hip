@@ -57,6 +57,7 @@ struct CostNetParams {
     const long long* s_rows;
     const long long* t_rows;
     int row_floats, chan_floats, skip_floats;
+    const int* only_if;            // nullable: workgroup i runs only if only_if[i] != 0 (the fp32 re-run of buf_cost_volume_net_split_safe)
 };
 
 // ---- tile GEMM: acc[t][u] += sum over groups of 4 k-steps ---------------------------------------------------------
@@ -420,6 +421,7 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
     float* SM = bufB + CVA_SM;
     float* TB = bufB + CVA_TB;
     const int match = blockIdx.x;
+    if (P.only_if && P.only_if[match] == 0) return;       // masked re-run: the matches the split-f16 kernel flagged, nothing else
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), li = lane & 15, lk = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid / WAVE);        // wavefront-uniform for the compiler too (scalar weight offsets)
     {   // both maps, transposed on the way in: global [c][k][l] -> LDS [k][l][c]; S with its two wrap-around columns per side
@@ -675,7 +677,8 @@ extern "C" int buf_cost_winograd_group(int layer)
 }
 
 static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const float* const* wt_host, const float* const* bias_host,
-                           const long long* s_rows, const long long* t_rows, int ele_n, float* ind_out, void* stream, const char* who)
+                           const long long* s_rows, const long long* t_rows, int ele_n, float* ind_out, void* stream, const char* who,
+                           const int* only_if = nullptr)
 {
     CostNetParams P;
     for (int l = 0; l < CV_LAYERS; l++) {
@@ -686,6 +689,7 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
     P.chan_floats = s_rows ? ele_n * 20 : 100;
     P.row_floats = 32 * P.chan_floats;
     P.skip_floats = s_rows ? 20 : 0;                         // elevation row 0 of every channel is not part of the cost volume
+    P.only_if = only_if;
     size_t lds = sizeof(float) * CV_BUF;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
@@ -698,7 +702,7 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
         16.0 * (49.0 * 64 * 64 + 36.0 * 64 * 128 + 25.0 * 128 * 128 + 16.0 * 128 * 64) +        // layers 2..5: 16 components per 2 x 2 tile
         36.0 * 576 * 64 + 16.0 * 576 * 32 + 4.0 * 288 * 32 + 1.0 * 128 * 20;
     TimedSpan span;
-    bool timed = timing_begin((hipStream_t)stream, &span, 2.0 * macs_per_match * m, BUF_TIMED_COST_NET);
+    bool timed = !only_if && timing_begin((hipStream_t)stream, &span, 2.0 * macs_per_match * m, BUF_TIMED_COST_NET);   // (a masked re-run is not a full launch)
 #ifdef CV_STAMP
     long long* stamps = nullptr;
     BUF_CHECK_HIP(hipMalloc(&stamps, (size_t)m * 16 * sizeof(long long)));

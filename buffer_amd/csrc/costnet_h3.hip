@@ -43,6 +43,7 @@ struct CostH3Params {
     const long long* t_rows;
     int row_floats, chan_floats, skip_floats;
     int* status;
+    int* flags;                    // nullable: int32[m], flags[i] = 1 when a value of match i left the f16 range (caller zero-fills)
 };
 
 #ifdef CH_STAMP
@@ -443,7 +444,10 @@ __global__ void __launch_bounds__(CH_THREADS, 2) k_cost_net_h3(const float* __re
         if (lane == 0) ind_out[match] = sw / se;
     }
     CH_STAMP_AT(9)
-    if (P.status && __builtin_amdgcn_ballot_w64(amax_in >= H3_F16_LIMIT_BITS || !(amax < 65504.f)) != 0 && lane == 0) atomicOr(P.status, 1);
+    if ((P.status || P.flags) && __builtin_amdgcn_ballot_w64(amax_in >= H3_F16_LIMIT_BITS || !(amax < 65504.f)) != 0 && lane == 0) {
+        if (P.status) atomicOr(P.status, 1);
+        if (P.flags) P.flags[match] = 1;                      // this match goes through the fp32 kernel again (buf_cost_volume_net_split_safe)
+    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -479,7 +483,7 @@ extern "C" int buf_split_tile_gemm(const float* w_host, int cout, int cin, int n
 
 static int cost_net_h3_launch(const float* s_eq, const float* t_eq, int m, const void* const* wt_host, const float* const* bias_host,
                               const long long* s_rows, const long long* t_rows, int ele_n, float* ind_out, int* status_dev, void* stream,
-                              const char* who)
+                              const char* who, int* flags_dev = nullptr)
 {
     CostH3Params P;
     for (int l = 0; l < CH_NW; l++) {
@@ -495,6 +499,7 @@ static int cost_net_h3_launch(const float* s_eq, const float* t_eq, int m, const
     P.row_floats = 32 * P.chan_floats;
     P.skip_floats = s_rows ? 20 : 0;
     P.status = status_dev;
+    P.flags = flags_dev;
     static LdsGrant grant;
     if (int rc = grant_dynamic_lds((const void*)k_cost_net_h3, CH_LDS, grant)) return rc;
     // work = the dense algorithmic count of SURVEY 8d per match (as id 2 counts the fp32 kernel's executed flops, bench.py

@@ -613,8 +613,13 @@ def split_tile_filters(w):
 
 class CylindricalNetSplit:
     """Cylindrical_Net on the f16 matrix pipe with fp32-equivalent arithmetic (csrc/convnet_h3.hip, "split-f16"): opt-in next to
-    CylindricalNet.  Same call, same [P,32,7,20] fp32 result to fp32 round-off; `check_range()` raises if an activation ever
-    left the f16 range (the kernel sets a device flag; reading it synchronises)."""
+    CylindricalNet.  Same call, same [P,32,7,20] fp32 result to fp32 round-off.
+
+    Safe by construction (round 6, csrc/split_safe.hip): the kernel flags every patch whose input or hidden activation leaves the f16
+    range (|v| >= 65504, NaN included) and the fp32 kernel of CylindricalNet re-runs exactly those patches in the same stream, masked by
+    the flags -- no host round trip, no exception; `last_flags` (int32[P], device) marks the patches of the last call that took the fp32
+    kernel.  For widths the fp32 kernel is not built for (the released network's are) the old contract stays: `check_range()` raises if
+    the status word was set."""
 
     def __init__(self, layers, device):
         self.wt, self.bias, self.cin, self.cout, self.relu = [], [], [], [], []
@@ -631,9 +636,29 @@ class CylindricalNetSplit:
         self._ci = (C.c_int * n)(*self.cin)
         self._co = (C.c_int * n)(*self.cout)
         self._re = (C.c_int * n)(*self.relu)
+        self.last_flags = None
+        # the fp32 re-run needs the Winograd tiling of the same filters; widths it is not built for keep the raising contract
+        self.safe = n == 8 and _lib.lib().buf_cylindrical_net_wg_supports(self._ci, self._co) == 0 and not os.environ.get('BUF_SPLIT_UNSAFE')
+        if self.safe:
+            self.wt_wg = [torch.from_numpy(winograd_tile_weights(w)).to(device) for w, _, _ in layers]
+            self._wwp = (C.c_void_p * n)(*[t.data_ptr() for t in self.wt_wg])
+
+    def _safe_call(self, x, head):
+        L = _lib.lib()
+        x = x.contiguous()
+        P = x.shape[0]
+        out = torch.empty((P, self.cout[-1], 7, 20), dtype=torch.float32, device=x.device)
+        desc = torch.empty((P, 32), dtype=torch.float32, device=x.device) if head is not None else None
+        self.last_flags = torch.empty((max(P, 1),), dtype=torch.int32, device=x.device)
+        check(L.buf_cylindrical_net_split_safe(_ptr(x), P, self._wp, self._wwp, self._bp, self._ci, self._co, self._re,
+                                               _ptr(head.params) if head is not None else None, _ptr(out), _ptr(desc), _ptr(self.status),
+                                               _ptr(self.last_flags), _stream()), "buf_cylindrical_net_split_safe")
+        return (desc, out) if head is not None else out
 
     def __call__(self, x):
         """x f32[P,16,420] (or [P,48,140]) -> f32[P,32,7,20]"""
+        if self.safe:
+            return self._safe_call(x, None)
         L = _lib.lib()
         x = x.contiguous()
         P = x.shape[0]
@@ -645,6 +670,8 @@ class CylindricalNetSplit:
     def with_head(self, x, head):
         """x f32[P,16,420] -> (desc f32[P,32], equi f32[P,32,7,20]) with DescriptorHead `head` fused behind the last layer: the
         [32][140] map never leaves LDS; bit-identical to head(self(x))."""
+        if self.safe:
+            return self._safe_call(x, head)
         L = _lib.lib()
         x = x.contiguous()
         P = x.shape[0]
@@ -654,10 +681,17 @@ class CylindricalNetSplit:
                                                _ptr(desc), _ptr(equi), _ptr(self.status), _stream()), "buf_cylindrical_net_split_head")
         return desc, equi
 
+    def range_fallbacks(self):
+        """patches of the last call that left the f16 range and were recomputed by the fp32 kernel (reads the flags: synchronises)"""
+        return 0 if self.last_flags is None else int((self.last_flags != 0).sum().item())
+
     def check_range(self):
+        """Safe form: nothing to raise (flagged patches were recomputed in fp32); clears the informational status word.  Otherwise
+        (widths without an fp32 kernel): raises FloatingPointError if an activation left the f16 range."""
         if int(self.status.item()) != 0:
             self.status.zero_()
-            raise FloatingPointError("buf_cylindrical_net_split: an activation left the f16 range (|v| >= 65504); use the fp32 kernel")
+            if not self.safe:
+                raise FloatingPointError("buf_cylindrical_net_split: an activation left the f16 range (|v| >= 65504); use the fp32 kernel")
 
 
 class DescriptorHead:
@@ -805,12 +839,27 @@ class CostVolumeNetSplit:
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self._wp = (C.c_void_p * 11)(*[t.data_ptr() for t in self.wt])
         self._bp = (C.c_void_p * 10)(*[t.data_ptr() for t in self.bias])
+        # safe by construction (csrc/split_safe.hip): the fp32 kernel's weights ride along and re-run the matches the split kernel flags
+        self.safe = not os.environ.get('BUF_SPLIT_UNSAFE')
+        self.f32 = CostVolumeNet(layers, device) if self.safe else None
+        self.last_flags = None
+
+    def _safe(self, s_eq, t_eq, s_rows, t_rows, m, dev):
+        L = _lib.lib()
+        out = torch.empty((m,), dtype=torch.float32, device=dev)
+        self.last_flags = torch.empty((max(m, 1),), dtype=torch.int32, device=dev)
+        check(L.buf_cost_volume_net_split_safe(_ptr(s_eq), _ptr(t_eq), 7, _ptr(s_rows), _ptr(t_rows), m, self._wp, self._bp, self.f32._wp,
+                                               self.f32._bp, _ptr(out), _ptr(self.status), _ptr(self.last_flags), _stream()),
+              "buf_cost_volume_net_split_safe")
+        return out
 
     def __call__(self, s_eq, t_eq):
         """s_eq, t_eq f32[M,32,5,20] -> f32[M]"""
         L = _lib.lib()
         s_eq, t_eq = s_eq.contiguous(), t_eq.contiguous()
         m = s_eq.shape[0]
+        if self.safe:
+            return self._safe(s_eq, t_eq, None, None, m, s_eq.device)
         out = torch.empty((m,), dtype=torch.float32, device=s_eq.device)
         check(L.buf_cost_volume_net_split(_ptr(s_eq), _ptr(t_eq), m, self._wp, self._bp, _ptr(out), _ptr(self.status), _stream()),
               "buf_cost_volume_net_split")
@@ -823,12 +872,20 @@ class CostVolumeNetSplit:
             raise _lib.BufferHipError(f"CostVolumeNetSplit.gathered: expected [rows,32,7,20] maps, got {tuple(equi.shape)}")
         s_rows, t_rows = _dev(s_rows, torch.int64, "s_rows"), _dev(t_rows, torch.int64, "t_rows")
         m = int(s_rows.shape[0])
+        if self.safe:
+            return self._safe(equi, equi, s_rows, t_rows, m, equi.device)
         out = torch.empty((m,), dtype=torch.float32, device=equi.device)
         check(L.buf_cost_volume_net_split_gather(_ptr(equi), 7, _ptr(s_rows), _ptr(t_rows), m, self._wp, self._bp, _ptr(out),
                                                  _ptr(self.status), _stream()), "buf_cost_volume_net_split_gather")
         return out
 
+    def range_fallbacks(self):
+        """matches of the last call that left the f16 range and were recomputed by the fp32 kernel (synchronises)"""
+        return 0 if self.last_flags is None else int((self.last_flags != 0).sum().item())
+
     def check_range(self):
+        """Safe form: nothing to raise (flagged matches were recomputed in fp32); clears the informational status word."""
         if int(self.status.item()) != 0:
             self.status.zero_()
-            raise FloatingPointError("buf_cost_volume_net_split: a value left the f16 range (|v| >= 65504); use the fp32 kernel")
+            if not self.safe:
+                raise FloatingPointError("buf_cost_volume_net_split: a value left the f16 range (|v| >= 65504); use the fp32 kernel")

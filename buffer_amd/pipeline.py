@@ -27,12 +27,17 @@ class BufferPipeline:
         self.host_wait_s = 0.0        # seconds the enqueueing thread spent blocked in the path's host round trips (diagnostics)
 
     def check_range(self):
-        """cnn_arith='split': raise FloatingPointError if an activation of either CNN ever left the f16 range (the kernels set a device
-        flag; reading it synchronises).  No-op on the fp32 kernels.  register() / register_batch() / register_batches() call it
-        before they return, so no driver reports poses computed behind an overflow."""
+        """cnn_arith='split': the kernels are safe by construction (csrc/split_safe.hip: every patch / match whose values leave the f16
+        range is recomputed by the fp32 kernel in the same stream), so there is nothing to check and no synchronisation here.  Only a
+        split network without an fp32 kernel for its widths (never the released ones) keeps the round-5 contract: FloatingPointError
+        if its status word was set."""
         for m in (self.desc.fused, self.inlier.fused):
-            if hasattr(m, 'check_range'):
+            if hasattr(m, 'check_range') and not getattr(m, 'safe', False):
                 m.check_range()
+
+    def range_fallbacks(self):
+        """(patches, matches) of the LAST launches that left the f16 range and took the fp32 kernels (cnn_arith='split'; synchronises)"""
+        return tuple(m.range_fallbacks() if hasattr(m, 'range_fallbacks') else 0 for m in (self.desc.fused, self.inlier.fused))
 
     def calibrate(self, samples):
         self.limits = [int(x) for x in pyramid.calibrate_limits(samples, self.cfg, self.device)]

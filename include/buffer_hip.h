@@ -285,6 +285,7 @@ int     buf_winograd_tile_filters(const float* w_host, int cout, int cin, int ng
                                                    /* host only: the same tiling with N-groups of ng and nblk = 4 | 5 blocks -> 4*nblk*Cout*Cin floats */
 int     buf_cylindrical_net_wg(const float* x, int npatch, const float* const* wt_host, const float* const* bias_host,
                                const int* cin_host, const int* cout_host, const int* relu_host, float* y, void* stream);
+int     buf_cylindrical_net_wg_supports(const int* cin_host, const int* cout_host);   /* host only: 0 if the kernel is built for these 8 widths */
 
 /* A11 (dense), split-f16 form -- the same stack with fp32-EQUIVALENT arithmetic on the f16 matrix pipe (csrc/convnet_h3.hip; opt-in,
  * the all-fp32 kernel above stays the default): every fp32 operand is split once into hi = f16(x) and lo' = f16((x - hi) 2^11)
@@ -307,6 +308,18 @@ int     buf_cylindrical_net_split(const float* x, int npatch, const void* const*
 int     buf_cylindrical_net_split_head(const float* x, int npatch, const void* const* wt_host, const float* const* bias_host,
                                        const int* cin_host, const int* cout_host, const int* relu_host, const float* head_params,
                                        float* desc, float* equi, int* status_dev, void* stream);
+
+/* The split form made SAFE BY CONSTRUCTION (csrc/split_safe.hip; what buffer_amd.ops.CylindricalNetSplit calls): flags_ws (DEVICE
+ * int32[np], scratch) is cleared, the split kernel sets flags_ws[p] for every patch whose input or hidden activation left the f16 range
+ * (NaN included), then buf_cylindrical_net_wg's kernel runs over the same grid with the flags as a mask -- workgroups of clear patches
+ * return at once, flagged patches are recomputed in fp32 and overwrite their result (bit-identical to buf_cylindrical_net_wg [+
+ * buf_descriptor_head] for those patches).  Same stream, no host round trip; nothing is returned from behind an overflow.
+ * head_params null: y_or_equi = y f32[np,32,140]; else desc f32[np,32] and y_or_equi = equi f32[np,32,140].
+ * wt_split_host as buf_cylindrical_net_split, wt_wg_host as buf_cylindrical_net_wg, bias_host shared.  Replaces the model's
+ * torch layers of models/patchnet.py:15-85 exactly like the two entry points it combines. */
+int     buf_cylindrical_net_split_safe(const float* x, int npatch, const void* const* wt_split_host, const float* const* wt_wg_host,
+                                       const float* const* bias_host, const int* cin_host, const int* cout_host, const int* relu_host,
+                                       const float* head_params, float* y_or_equi, float* desc, int* status_dev, int* flags_ws, void* stream);
 
 /* A11 (head)  attention pooling + normalisation (models/patch_embedder.py:66-72,81-84): pool_layer
  * (Conv2d 1x1 32->16 + BN + ReLU, Conv2d 1x1 16->1 + BN + ReLU), desc = normalize(mean(y * w)),
@@ -352,6 +365,14 @@ int     buf_cost_volume_net_split(const float* s_eq, const float* t_eq, int m, c
 int     buf_cost_volume_net_split_gather(const float* equi, int ele_n, const long long* s_rows, const long long* t_rows, int m,
                                          const void* const* wt_host, const float* const* bias_host, float* ind_out,
                                          int* status_dev, void* stream);
+/* Safe by construction, as buf_cylindrical_net_split_safe (models/patchnet.py:88-147): per-match flags in flags_ws (DEVICE int32[m]),
+ * the fp32 kernel of buf_cost_volume_net[_gather] re-runs the flagged matches in the same stream.  s_rows null: dense s_eq / t_eq
+ * f32[m,32,5,20]; else s_eq = t_eq = equi f32[rows,32,7,20] with DEVICE int64 row ids.  wt_split_host / bias_split_host as
+ * buf_cost_volume_net_split, wt_f32_host / bias_f32_host as buf_cost_volume_net. */
+int     buf_cost_volume_net_split_safe(const float* s_eq, const float* t_eq, int ele_n, const long long* s_rows, const long long* t_rows,
+                                       int m, const void* const* wt_split_host, const float* const* bias_split_host,
+                                       const float* const* wt_f32_host, const float* const* bias_f32_host, float* ind_out,
+                                       int* status_dev, int* flags_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A14  hypotheses + all-vs-all scoring (models/BUFFER.py:295-311): ind f32[m] -> R f32[m,3,3], t f32[m,3],

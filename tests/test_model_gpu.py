@@ -1,6 +1,7 @@
 """A4-A16 on the GPU: HIP stages vs the golden vectors produced by the reference and vs the torch
 fp32 oracle.  Tolerances: 1e-4 relative on descriptors / poses (BASELINE.json north_star)."""
 import os
+from dataclasses import replace
 
 import numpy as np
 import pytest
@@ -129,6 +130,108 @@ def test_split_kernel_flags_activations_outside_the_f16_range(W, dev):
     bad[1] = ((rng.standard_normal((128, 64, 3, 3))).astype(np.float32), layers[1][1], True)
     with pytest.raises(_lib.BufferHipError):
         ops.CylindricalNetSplit(bad, dev)(torch.zeros(1, 80, 140, device=dev))
+
+
+def test_split_kernels_are_safe_by_construction(W, dev):
+    """cnn_arith='split' never returns a value from behind an f16 overflow (csrc/split_safe.hip): patches / matches whose input or
+    hidden activations leave the f16 range -- inputs x 1e6 (the input watch), x 3e3 (hidden activations only), NaN, inf -- are flagged on
+    the device and recomputed by the fp32 kernel in the same stream: their rows equal the fp32 kernels' BIT FOR BIT, every other row
+    equals the split kernel's own result, the flags say exactly which is which, and nothing raises.  With the fused head and without."""
+    from buffer_amd import registration
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.patch_embedder import PatchEmbedder
+    pe32 = PatchEmbedder(W, dev, THREEDMATCH)
+    pes = PatchEmbedder(W, dev, replace(THREEDMATCH, cnn_arith='split'))
+    assert pes.fused.safe
+    g = torch.Generator(device='cpu').manual_seed(9)
+    x = torch.rand((41, 16, 420), generator=g).to(dev)
+    clean = pes.fused(x)
+    assert pes.fused.range_fallbacks() == 0
+    dclean, eclean = pes.fused.with_head(x, pes.fused_head)
+    bad = x.clone()
+    bad[3] *= 1e6                      # input beyond the f16 range
+    bad[17] *= 5e4                     # input inside the range, hidden activations possibly beyond
+    bad[18, 5, 77] = float('nan')
+    bad[40, 0, 0] = float('inf')
+    y32 = pe32.fused(bad)
+    d32, e32 = pe32.head(y32)
+    y = pes.fused(bad)
+    rows = sorted(np.nonzero(pes.fused.last_flags.cpu().numpy())[0].tolist())
+    assert set(rows) >= {3, 18, 40} and set(rows) <= {3, 17, 18, 40} and pes.fused.range_fallbacks() == len(rows)
+    keep = torch.tensor([i for i in range(41) if i not in rows], device=dev)
+    rr = torch.tensor(rows, device=dev)
+    assert torch.equal(y[keep], clean[keep])
+    assert torch.equal(y[rr].view(torch.int32), y32[rr].view(torch.int32))           # bitwise, NaN patterns included
+    assert float(y32[3].abs().max()) > 65504.0 and bool(torch.isfinite(y[3]).all())   # a real overflow case, a finite fp32 result
+    d, e = pes.fused.with_head(bad, pes.fused_head)
+    assert sorted(np.nonzero(pes.fused.last_flags.cpu().numpy())[0].tolist()) == rows
+    assert torch.equal(d[keep], dclean[keep]) and torch.equal(e[keep], eclean[keep])
+    assert torch.equal(d[rr].view(torch.int32), d32[rr].view(torch.int32)) and torch.equal(e[rr].view(torch.int32), e32[rr].view(torch.int32))
+    pes.fused.check_range()                                                           # nothing to raise
+    assert int(pes.fused.status.item()) == 0
+    # hidden activations only: inputs in [0, 1), layer-0 filters x 3e4 (still f16 numbers) -> the watch of the layer epilogues trips
+    from buffer_amd import ops
+    big = [(w * np.float32(3e4) if i == 0 else w, b, r) for i, (w, b, r) in enumerate(pe32.layers)]
+    ns, n32 = ops.CylindricalNetSplit(big, dev), ops.CylindricalNet(big, dev)
+    assert ns.safe
+    ys, y3 = ns(x), n32(x)
+    hit = torch.nonzero(ns.last_flags[:41]).flatten()
+    assert hit.numel() > 0 and torch.equal(ys[hit].view(torch.int32), y3[hit].view(torch.int32))
+    assert (ys - y3).abs().max().item() <= 1e-5 * y3.abs().max().item()
+    # the cost net: dense and gathered forms
+    cv32 = registration.CostVolume(W, dev)
+    cvs = registration.CostVolume(W, dev, arith='split')
+    assert cvs.fused.safe
+    a = torch.nn.functional.normalize(torch.rand((37, 32, 5, 20), generator=g), dim=1).to(dev)
+    b = torch.nn.functional.normalize(torch.rand((37, 32, 5, 20), generator=g), dim=1).to(dev)
+    ind_clean = cvs(a, b)
+    assert cvs.fused.range_fallbacks() == 0
+    a2, b2 = a.clone(), b.clone()
+    a2[5] *= 1e6
+    b2[20] *= 3e4
+    a2[36, 1, 2, 3] = float('nan')
+    want = cv32(a2, b2)
+    got = cvs(a2, b2)
+    fl = sorted(np.nonzero(cvs.fused.last_flags.cpu().numpy())[0].tolist())
+    assert set(fl) >= {5, 36} and set(fl) <= {5, 20, 36}
+    keep = torch.tensor([i for i in range(37) if i not in fl], device=dev)
+    ff = torch.tensor(fl, device=dev)
+    assert torch.equal(got[keep], ind_clean[keep]) and torch.equal(got[ff].view(torch.int32), want[ff].view(torch.int32))
+    equi = torch.nn.functional.normalize(torch.rand((50, 32, 7, 20), generator=g), dim=1).to(dev)
+    equi[7] *= 1e6
+    s_rows = torch.arange(0, 40, device=dev)
+    t_rows = torch.arange(10, 50, device=dev)
+    got = cvs.gathered(equi, s_rows, t_rows)
+    want = cv32.gathered(equi, s_rows, t_rows)
+    fl = np.nonzero(cvs.fused.last_flags.cpu().numpy())[0].tolist()
+    assert fl == [7] and torch.equal(got[7].view(torch.int32), want[7].view(torch.int32))
+    assert (got - want).abs().max().item() < 2e-4
+    cvs.fused.check_range()
+
+
+def test_split_pipeline_survives_an_overflowing_pair(W, dev):
+    """BufferPipeline(cnn_arith='split') on a pair whose descriptor CNN overflows the f16 range in some patches (the point MLP's folded
+    BatchNorm scaled so that a third of the voxel features exceed 65504): no exception, the pose is the fp32 pipeline's to round-off,
+    and range_fallbacks() reports the re-run patches."""
+    from buffer_amd import synth
+    from buffer_amd.config import THREEDMATCH
+    from buffer_amd.pipeline import BufferPipeline
+    sample = synth.make_pair(11, n_raw=40_000, size=(1.0, 1.0, 0.9), n_boxes=3)
+    cfg = replace(THREEDMATCH, num_keypts=256)
+    p32 = BufferPipeline(cfg, dev)
+    ps = BufferPipeline(replace(cfg, cnn_arith='split'), dev, limits=p32.calibrate([sample]))
+    inp = ps.upload(sample)
+    pose32 = p32.register(inp, seed=0)
+    pose_s = ps.register(inp, seed=0)
+    assert ps.range_fallbacks() == (0, 0)
+    assert (pose32 - pose_s).abs().max().item() < 1e-4
+    for pipe in (p32, ps):                                   # the same (absurd) point-MLP scale in both pipelines
+        pipe.desc.mlp_s = pipe.desc.mlp_s * np.float32(3e5)
+        pipe.desc.mlp_t = pipe.desc.mlp_t * np.float32(3e5)
+    pose32b = p32.register(inp, seed=0)
+    pose_sb = ps.register(inp, seed=0)                       # rounds 4-5 raised FloatingPointError here
+    assert ps.range_fallbacks()[0] > 0
+    assert torch.isfinite(pose_sb).all() and (pose32b - pose_sb).abs().max().item() < 1e-4
 
 
 def test_voxelize_vs_oracle_spt(W, dev):
