@@ -139,12 +139,32 @@ def cpu_baseline(sample, cfg, limits, hip_register=None, hip_register_split=None
         # patch coordinates differ in the last bit (torch's CPU matmul vs the kernel's Rodrigues product): a handful of rows in 10^4
         # see another sample there (tools/desc_diff_probe.py); every other row agrees to fp32 round-off
         ddesc = torch.cat([(gd['desc'][i]['desc'].cpu() - wd['desc'][i]['desc']).abs().amax(1) for i in range(2)]) if kp_equal else None
+        # ... and the cause is SHOWN for every such row (round 6, buffer_amd/diagnose.py): the two aligned patches differ in their last
+        # bits only, the fp32 hit masks of the 420 x 512 (centre, point) pairs differ in at least one pair, and every differing pair
+        # lies on a voxel ball's surface within the alignment's last-bit uncertainty.  A row over tolerance WITHOUT that is counted as
+        # unexplained (the bench-contract test requires 0).
+        over, unexplained, shown = [], 0, []
+        if kp_equal:
+            from buffer_amd import diagnose
+            from buffer_amd.patch_embedder import voxel_centres
+            centres = voxel_centres(cfg.rad_n, cfg.azi_n, cfg.ele_n)
+            P = cfg.num_keypts
+            for row in torch.nonzero(ddesc > 1e-4).flatten().tolist():
+                c, k = divmod(row, P)
+                e = diagnose.explain_row(gd['desc'][c]['patches'][k].cpu().numpy(), centres, cfg.delta / cfg.rad_n,
+                                         theirs=wd['desc'][c]['patches'][k].numpy())
+                over.append(row)
+                unexplained += 0 if e['explained'] else 1
+                if len(shown) < 3:
+                    shown.append(dict(cloud=c, keypoint=k, desc_abs_diff=float(ddesc[row]), **e))
         mine = set(zip(gd['s_mids'].cpu().numpy().tolist(), gd['t_mids'].cpu().numpy().tolist()))
         ref = set(zip(np.asarray(wd['s_mids']).tolist(), np.asarray(wd['t_mids']).tolist()))
         return dict(keypoints_equal=bool(kp_equal), matches=len(ref), matches_differing=len(mine ^ ref),
                       pose_max_abs_diff=float(np.abs(got.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max()),
                       desc_rows=None if ddesc is None else int(ddesc.numel()),
                       desc_rows_differing_over_1e_4=None if ddesc is None else int((ddesc > 1e-4).sum()),
+                      desc_rows_over_1e_4_not_explained_by_a_ball_surface_flip=None if ddesc is None else int(unexplained),
+                      desc_rows_over_1e_4_examples=shown,
                       desc_max_abs_diff_other_rows=None if ddesc is None else float(ddesc[ddesc <= 1e-4].max()),
                       desc_max_abs_diff=None if ddesc is None else float(ddesc.max()),
                       what=f'HIP register() vs oracle/pipeline_ref.register_pair on this pair at {cfg.num_keypts} keypoints/fragment, '

@@ -357,6 +357,10 @@ def make_kitti_fixture():
     sys.modules.pop('KITTI.config', None)
 
 
+def name_of(dataset):
+    return 'kitti_full_1500.npz' if dataset == 'kitti' else 'full_1500.npz'
+
+
 def make_full_fixture(seed=4242, P=1500, dataset='3dmatch'):
     """F8 `full_1500.npz` (round 5): ONE synth.make_pair at the full 3DMatch shape through the reference's OWN
     buffer.forward (models/BUFFER.py:231-333, unmodified) at the reference's 1500 keypoints: the collate of
@@ -383,7 +387,7 @@ def make_full_fixture(seed=4242, P=1500, dataset='3dmatch'):
     batch = dl.collate_fn_descriptor([sample], cfg, limits)
     rng = np.random.default_rng(seed)
     perms = [rng.permutation(len(sample['src_fds_pts'])), rng.permutation(len(sample['tgt_fds_pts']))]
-    cap = dict(fps=[], desc=[], perm_calls=0)
+    cap = dict(fps=[], desc=[], desc_kpts=[], perm_calls=0)
 
     # --- open3d surface of models/BUFFER.py:314-326 and utils/common.py:569-578 (third-party: stubbed) ---
     class _PC:
@@ -434,6 +438,7 @@ def make_full_fixture(seed=4242, P=1500, dataset='3dmatch'):
 
     def spy_desc(*a, **k):
         out = orig_desc(*a, **k)
+        cap['desc_kpts'].append(a[1][0].numpy().copy())                     # the keypoints Desc actually received ([1,P,3])
         cap['desc'].append({kk: v.numpy().copy() for kk, v in out.items() if isinstance(v, torch.Tensor)})
         return out
 
@@ -468,7 +473,9 @@ def make_full_fixture(seed=4242, P=1500, dataset='3dmatch'):
     kp_idx = [det[i][cap['fps'][i][1].astype(np.int64)] for i in range(2)]            # rows of the src / tgt halves of points[0]
     pts0 = batch['points'][0].numpy()
     for i, off in enumerate((0, n_src)):
-        assert np.array_equal(pts0[off + kp_idx[i]], cap['desc'][i]['patches'][:, -1] * 0 + pts0[off + kp_idx[i]])
+        # the reconstructed indices (det[fps idx]) ARE the keypoints the reference's Desc received (this used to compare a
+        # value with itself)
+        assert np.array_equal(pts0[off + kp_idx[i]], cap['desc_kpts'][i]), f'reconstructed keypoints of cloud {i} differ from those Desc received'
     # hypotheses / scoring as the forward computed them (recomputed here from the captured pieces: forward keeps them local)
     s_mids, t_mids, ind = cap['s_mids'], cap['t_mids'], cap['ind']
     kp = [torch.from_numpy(pts0[kp_idx[0]]), torch.from_numpy(pts0[n_src + kp_idx[1]])]
@@ -509,8 +516,22 @@ def make_full_fixture(seed=4242, P=1500, dataset='3dmatch'):
         out.update({f'{nm}_desc_rows': d['desc'][rows_p], f'{nm}_equi_rows': d['equi'][rows_e], f'{nm}_R_rows': d['R'][rows_p],
                     f'{nm}_rand_axis_rows': d['rand_axis'][rows_p], f'{nm}_desc_sum': f64(d['desc']), f'{nm}_equi_sum': f64(d['equi']),
                     f'{nm}_patches_sum': f64(d['patches']), f'{nm}_equi_rowsum': np.asarray(d['equi'], np.float64).sum((1, 2, 3))})
-    name = 'kitti_full_1500.npz' if dataset == 'kitti' else 'full_1500.npz'
-    np.savez_compressed(os.path.join(GOLD, name), **out)
+    # Rows whose voxel ball queries hinge on the last bits of the aligned coordinates (buffer_amd/diagnose.py: a point of the patch
+    # within the alignment's last-bit uncertainty of a ball surface): the ONLY rows of another correct fp32 implementation that may
+    # legitimately differ from these by more than round-off.  Their aligned patches and full outputs ride along, so the test can show
+    # the cause row by row (round 6).
+    from buffer_amd import diagnose
+    from oracle import torch_ref as T_
+    centres = T_.voxel_centres(cfg.patch.rad_n, cfg.patch.azi_n, cfg.patch.ele_n).numpy()
+    voxel_r = cfg.patch.delta / cfg.patch.rad_n
+    for i, nm in enumerate(('src', 'tgt')):
+        d = cap['desc'][i]
+        rows = np.array([r for r in range(P) if diagnose.explain_row(d['patches'][r], centres, voxel_r)['near_surface_pairs'] > 0], np.int64)
+        out.update({f'{nm}_surface_rows': rows, f'{nm}_surface_patches': d['patches'][rows], f'{nm}_surface_desc': d['desc'][rows],
+                    f'{nm}_surface_equi_rowsum': np.asarray(d['equi'][rows], np.float64).sum((1, 2, 3))})
+        print(f'{name_of(dataset)} {nm}: {len(rows)} of {P} patches have a point on a voxel ball surface (to the last bits of the alignment)')
+    name = name_of(dataset)
+    np.savez_compressed(os.path.join(os.environ.get('BUF_GOLDEN_OUT', GOLD), name), **out)
     err = np.abs(np.asarray(pose) - sample['relt_pose']).max()
     print(name, ': layers', out['layer_sizes'], 'limits', limits, 'candidates', out['n_candidates'], 'matches', len(s_mids),
           'best inliers', int(inlier_num[best]), 'ransac', cap['ransac_info'], '|pose - gt|', float(err),

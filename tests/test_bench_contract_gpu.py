@@ -59,8 +59,12 @@ def test_bench_json_line(dev, tmp_path):
     par = c['parity']
     assert set(par) >= {'keypoints_equal', 'matches_differing', 'pose_max_abs_diff'}
     assert par['keypoints_equal'] is True and par['matches_differing'] <= max(2, par['matches'] // 200) and par['pose_max_abs_diff'] < 1e-4
+    # descriptor rows beyond 1e-4 are allowed only with their cause shown: a patch point on a voxel ball surface whose fp32 decision flips
+    # with the last bits of the aligned coordinates (buffer_amd/diagnose.py); every other row within round-off
+    assert par['desc_rows_over_1e_4_not_explained_by_a_ball_surface_flip'] == 0 and par['desc_max_abs_diff_other_rows'] < 1e-4
     ps = c['parity_split']                                # the same pair on the split-f16 CNN kernels against the same oracle run
     assert ps['keypoints_equal'] is True and ps['matches_differing'] <= max(2, ps['matches'] // 200) and ps['pose_max_abs_diff'] < 1e-4
+    assert ps['desc_rows_over_1e_4_not_explained_by_a_ball_surface_flip'] == 0
     assert d['config']['registered_ok'].startswith('8/8') and d['config']['distinct_pairs_per_gpu'] == 4      # = pairs per step
     # the driver keeps the last 2000 characters of the line: the four round-4 keys and every compact entry must be inside them
     line = json.dumps(d)
