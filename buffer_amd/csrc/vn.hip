@@ -181,6 +181,9 @@ __global__ void __launch_bounds__(256) k_vn_gather6_lds(const float* __restrict_
         double ax = 0.0, ay = 0.0, az = 0.0;
         for (int k = 0; k < K; k++) {
             const float4 a = e4[2 * k], b = e4[2 * k + 1];
+#ifdef VG6_PROBE_NOP     // development builds of tools/pk_bisect.sh only: drain the LDS reads and idle VG6_PROBE_NOP + 1 cycles before the arithmetic
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop %0" :: "n"(VG6_PROBE_NOP) : "memory");
+#endif
             const float ex = a.x, ey = a.y, ez = a.z, fx = b.x, fy = b.y, fz = b.z;
             const float cx = fy * ez - fz * ey, cy = fz * ex - fx * ez, cz = fx * ey - fy * ex;
             float px = wfo[0] * fx + wfo[1] * ex + wfo[2] * cx + wfo[3] * mx;
