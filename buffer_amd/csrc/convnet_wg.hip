@@ -442,6 +442,31 @@ __device__ __forceinline__ void wg_addresses(const float* act, int k0, int li, i
         for (int a = 0; a < 4; a++) RA[t][a] = wg_row_addr(act_addr, t, a, li, lk);
 }
 
+// The 12 window-row addresses depend on the lane only (the map's geometry is the same in every layer): formed ONCE per kernel and parked in
+// accumulation registers (round 6, WG_ADDR_PARK); a layer reads them back (one v_accvgpr_read each, plus one add where its K range does not
+// start at channel 0) instead of re-deriving tile coordinates and padding selects -- ~110 vector instructions per layer and wavefront.
+#ifndef WG_ADDR_PARK
+#define WG_ADDR_PARK 1
+#endif
+struct WgAddrPark { float a[3][4]; };
+__device__ __forceinline__ void wg_park_addresses(const float* act, int li, int lk, WgAddrPark& pk)
+{
+    const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)act;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const unsigned v = wg_row_addr(act_addr, t, a, li, lk);
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(pk.a[t][a]) : "v"(v));
+        }
+}
+__device__ __forceinline__ unsigned wg_parked(const WgAddrPark& pk, int t, int a)
+{
+    unsigned v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(pk.a[t][a]));
+    return v;
+}
+
 template <int NN, int K0, int K1, int KN>
 __device__ __forceinline__ void wg_first_weights(__amdgpu_buffer_rsrc_t rs, unsigned wp, unsigned lofs, int wstride, wgf4 (&W)[NN][KN])
 {
@@ -459,7 +484,7 @@ __device__ __forceinline__ void wg_first_weights(__amdgpu_buffer_rsrc_t rs, unsi
 #define WG_XCH_C 64
 template <bool GLB>
 __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
-                                                const float* __restrict__ bias, int cin, int cout, int relu, int w)
+                                                const float* __restrict__ bias, int cin, int cout, int relu, int w, const WgAddrPark& pk)
 {
     int lane = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane));
@@ -467,7 +492,14 @@ __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* 
     const int nt = w & 1, half = w >> 1;
     const int k4 = cin >> 2, kn = k4 >> 1, k0 = half * kn, wstride = 256;
     unsigned RA[3][4];
+#if WG_ADDR_PARK
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) RA[t][a] = wg_parked(pk, t, a) + (unsigned)k0 * WG_KSTEP;
+#else
     wg_addresses(act, k0, li, lk, RA);
+#endif
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
     const unsigned wp = (unsigned)nt * (WG_BLOCKS * cin * 16) + (unsigned)k0 * wstride;
     const unsigned lofs = lane * 16;
@@ -496,7 +528,7 @@ __device__ __forceinline__ void wg_layer_ksplit(float* __restrict__ act, float* 
 // ten quads of partial sums to hand over.
 template <bool GLB>
 __device__ __forceinline__ void wg_layer_mksplit(float* __restrict__ act, float* __restrict__ out_glb, const float* __restrict__ wt,
-                                                 const float* __restrict__ bias, int cin, int cout, int relu, int w)
+                                                 const float* __restrict__ bias, int cin, int cout, int relu, int w, const WgAddrPark& pk)
 {
     int lane = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane));
@@ -504,11 +536,19 @@ __device__ __forceinline__ void wg_layer_mksplit(float* __restrict__ act, float*
     const int h = w & 1, half = w >> 1;
     const int k4 = cin >> 2, kn = k4 >> 1, k0 = half * kn, wstride = 512;
     unsigned RA[3][4];
+#if WG_ADDR_PARK
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const unsigned r0 = wg_parked(pk, 0, a), r1 = wg_parked(pk, 1, a);
+        RA[0][a] = (h ? r1 : r0) + (unsigned)k0 * WG_KSTEP; RA[1][a] = RA[0][a]; RA[2][a] = wg_parked(pk, 2, a) + (unsigned)k0 * WG_KSTEP;
+    }
+#else
     {
         const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)act + (unsigned)k0 * WG_KSTEP;
 #pragma unroll
         for (int a = 0; a < 4; a++) { RA[0][a] = wg_row_addr(act_addr, h, a, li, lk); RA[1][a] = RA[0][a]; RA[2][a] = wg_row_addr(act_addr, 2, a, li, lk); }
     }
+#endif
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
     const unsigned wp = (unsigned)k0 * wstride;                            // [pair 0][i][k-step][n2][lane][j]
     const unsigned wpb = wp + (unsigned)h * 256;
@@ -543,7 +583,7 @@ __device__ __forceinline__ void wg_layer_mksplit(float* __restrict__ act, float*
 // ONE N-tile of its pair: 32 + 8 = 40 matrix instructions per k-step for every wavefront, no partial sums to exchange.
 // (One N-tile per wavefront over all M-tiles, the round-2 form, pays 1.8 transform instructions per MFMA instead of 1.0.)
 __device__ __forceinline__ void wg_layer_msplit(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                int cin, int cout, int relu, int w)
+                                                int cin, int cout, int relu, int w, const WgAddrPark& pk)
 {
     int lane = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane));
@@ -551,11 +591,19 @@ __device__ __forceinline__ void wg_layer_msplit(float* __restrict__ act, const f
     const int pair = w & 1, h = w >> 1;
     const int k4 = cin >> 2, wstride = 512;
     unsigned RA[3][4];
+#if WG_ADDR_PARK
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const unsigned r0 = wg_parked(pk, 0, a), r1 = wg_parked(pk, 1, a);
+        RA[0][a] = h ? r1 : r0; RA[1][a] = RA[0][a]; RA[2][a] = wg_parked(pk, 2, a);
+    }
+#else
     {
         const unsigned act_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)act;
 #pragma unroll
         for (int a = 0; a < 4; a++) { RA[0][a] = wg_row_addr(act_addr, h, a, li, lk); RA[1][a] = RA[0][a]; RA[2][a] = wg_row_addr(act_addr, 2, a, li, lk); }
     }
+#endif
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
     const unsigned wp = (unsigned)pair * (WG_BLOCKS * cin * 32);           // [pair][i][k-step][n2][lane][j]
     const unsigned wpb = wp + (unsigned)h * 256;                           // the N-tile of the pair whose bottom row is this wavefront's
@@ -601,7 +649,7 @@ __device__ __forceinline__ void wg_park(const wgf4 (&Y)[2][3][2][2], float (&par
 // (64 accumulators; a round per M-tile -- more passes, the pair's filters streamed a third time -- measured 0.9 % slower), the
 // bottom row is the second.
 __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const float* __restrict__ wt, const float* __restrict__ bias,
-                                              int cin, int cout, int relu, int pair)
+                                              int cin, int cout, int relu, int pair, const WgAddrPark& pk)
 {
     int lane = threadIdx.x & (WAVE - 1);
     asm volatile("" : "+v"(lane));
@@ -612,7 +660,14 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
     const int k4 = cin >> 2, wstride = 512;
 #endif
     unsigned RA[3][4];
+#if WG_ADDR_PARK
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) RA[t][a] = wg_parked(pk, t, a);
+#else
     wg_addresses(act, 0, li, lk, RA);
+#endif
     const __amdgpu_buffer_rsrc_t rs = wg_weights(wt);
     const unsigned wp = (unsigned)pair * (WG_BLOCKS * cin * 32);           // [pair][i][k-step][n2][lane][j]
     const unsigned lofs = lane * 16;
@@ -690,19 +745,27 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_cyl_net_wg(const float* __res
     for (int i = threadIdx.x; i < WG_MAXC * 4; i += WG_THREADS) act[(i >> 2) * WG_CS + WG_ZERO + (i & 3)] = 0.f;
     __syncthreads();
     WG_STAMP_AT(0)
+    WgAddrPark pk;
+#if WG_ADDR_PARK
+    {
+        int lane0 = threadIdx.x & (WAVE - 1);
+        asm volatile("" : "+v"(lane0));
+        wg_park_addresses(act, lane0 & 15, lane0 >> 4, pk);
+    }
+#endif
 #pragma unroll 1
     for (int l = 0; l < WG_LAYERS; l++) {
         const int cin = P.cin[l], cout = P.cout[l];
-        if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        if (cout == 128) wg_layer_pair(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w, pk);
         else if (cout == 64) {
-            wg_layer_msplit(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+            wg_layer_msplit(act, P.wt[l], P.bias[l], cin, cout, P.relu[l], w, pk);
         }
 #if WG_KSPLIT_PAIRS
-        else if (l < WG_LAYERS - 1) wg_layer_mksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-        else wg_layer_mksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        else if (l < WG_LAYERS - 1) wg_layer_mksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w, pk);
+        else wg_layer_mksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w, pk);
 #else
-        else if (l < WG_LAYERS - 1) wg_layer_ksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
-        else wg_layer_ksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w);
+        else if (l < WG_LAYERS - 1) wg_layer_ksplit<false>(act, nullptr, P.wt[l], P.bias[l], cin, cout, P.relu[l], w, pk);
+        else wg_layer_ksplit<true>(act, y + (size_t)patch * cout * 140, P.wt[l], P.bias[l], cin, cout, P.relu[l], w, pk);
 #endif
         WG_STAMP_AT(2 * l + 1)
         WG_SYNC();
