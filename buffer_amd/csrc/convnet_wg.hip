@@ -661,6 +661,7 @@ __device__ __forceinline__ void wg_layer_pair(float* __restrict__ act, const flo
 #endif
     unsigned RA[3][4];
 #if WG_ADDR_PARK
+    (void)li;
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll

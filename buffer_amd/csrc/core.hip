@@ -98,6 +98,9 @@ extern "C" int buf_device_count(void)
 // Exclusive scan: <=SCAN_BLOCKS workgroups each own a contiguous chunk; pass 1 reduces the
 // chunks, one workgroup scans the chunk sums, pass 2 rescans each chunk with its offset.
 // Reads the data twice and writes it once (12 B per element of HBM traffic).
+// (Round 6 tried the single-launch chained form with decoupled look-back: on this chip every block's ticket is a same-address
+// device-scope atomic, ~170 ns apiece behind eight L2s -- 1024 tickets cost more than the two launches they save (measured: 3 ms per
+// scan with a CAS ticket); without tickets the form leans on in-order workgroup dispatch, a hang if that ever fails.  Three launches stay.)
 #define SCAN_BLOCKS 1024
 #define SCAN_THREADS 256
 

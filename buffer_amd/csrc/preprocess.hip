@@ -174,15 +174,14 @@ static int voxel_downsample_impl(const T* pts, const T* normals, int n, const in
     BUF_CHECK_HIP(hipMemsetAsync(v.table, 0, sizeof(int) * (size_t)max_cells, s));
     k_o3d_bbox_partial<T><<<dim3(O3D_BBOX_BLOCKS, nb), 256, 0, s>>>(pts, v.off, part);
     k_o3d_bbox<<<nb, O3D_BBOX_BLOCKS, 0, s>>>(part, v.off, voxel, v.grids, og);
-    k_vox_offsets<<<1, 1, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
+    k_vox_offsets<<<1, 1024, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
     int blocks = cdiv(n, 256);
     k_o3d_count<T><<<blocks, 256, 0, s>>>(pts, n, v.off, nb, v.grids, og, v.st, v.table, v.cell_of, v.keys);
     rc = exclusive_scan_i32(v.table, (long long)max_cells, v.scan_tmp, nullptr, s);
     if (rc) return rc;
     // only the input index (.w) of the scattered rows is used afterwards: the coordinates are re-read in fp64
     k_cell_scatter<<<blocks, 256, 0, s>>>((const float*)pts, n, v.cell_of, &v.st->error, v.table, v.sorted_tmp);
-    k_vox_rank<<<blocks, 256, 0, s>>>(v.cell_of, v.keys, v.table, v.sorted_tmp, n, v.st, v.sorted, v.key_sorted, v.cell_sorted);
-    k_vox_heads<<<blocks, 256, 0, s>>>(v.key_sorted, v.cell_sorted, n, v.st, v.head);
+    k_vox_rank<<<blocks, 256, 0, s>>>(v.cell_of, v.keys, v.table, v.sorted_tmp, n, v.st, v.sorted, v.key_sorted, v.cell_sorted, v.head);   // + head flags
     rc = exclusive_scan_i32(v.head, n, v.scan_tmp, v.total, s);
     if (rc) return rc;
     k_o3d_emit<T><<<blocks, 256, 0, s>>>(pts, normals, v.sorted, v.key_sorted, v.cell_sorted, v.head, n, v.st, out_pts, out_normals);

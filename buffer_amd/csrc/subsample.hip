@@ -22,7 +22,56 @@ struct VoxGrid {
     int lo, hi;                    // point range
 };
 
-struct VoxStatus { int error; unsigned long long B; };
+struct VoxStatus { int error; unsigned pad; unsigned long long B; };
+
+// Bucket width and table offsets of every element (round 6: one workgroup of 1024 threads; rounds 1-5: a kernel of ONE thread that walked
+// the nb descriptors up to 200 times through global memory, 35 us per call at 64 elements -- a quarter of the whole operator.  Run by the last
+// workgroup of k_vox_bbox instead, it needed a device-scope fence per element's workgroup: each one writes an XCD's whole L2 back).  Smallest power-of-two bucket width B with sum_b (floor(cells_b / B) + 2) <= max_cells.
+__device__ void vox_offsets(VoxGrid* __restrict__ grids, int nb, long long max_cells, VoxStatus* __restrict__ st)
+{
+    __shared__ double red[16];
+    __shared__ long long scan_s[16];
+    __shared__ double s_B;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid / WAVE;
+    const int per = (nb + 1023) / 1024;
+    const int b0 = tid * per, b1 = min(b0 + per, nb);
+    double Bd = 1.0;
+    for (int it = 0; it < 200; it++) {
+        double need = 0.0;
+        for (int b = b0; b < b1; b++) need += grids[b].hi > grids[b].lo ? floor(grids[b].cells / Bd) + 2.0 : 1.0;
+        for (int d = WAVE / 2; d > 0; d >>= 1) need += __shfl_xor(need, d, WAVE);
+        __syncthreads();
+        if (lane == 0) red[w] = need;
+        __syncthreads();
+        double tot = 0.0;
+        for (int i = 0; i < 16; i++) tot += red[i];
+        if (tot <= (double)max_cells) break;                  // (uniform: every thread sees the same sum)
+        Bd *= 2.0;
+    }
+    // exclusive prefix of the bucket counts in element order: thread chunks, then the 16 wave sums
+    long long mine = 0;
+    for (int b = b0; b < b1; b++) mine += grids[b].hi > grids[b].lo ? (long long)(floor(grids[b].cells / Bd) + 2.0) : 1;
+    long long inc = mine;
+    for (int d = 1; d < WAVE; d <<= 1) { const long long t = __shfl_up(inc, d, WAVE); if (lane >= d) inc += t; }
+    __syncthreads();
+    if (lane == WAVE - 1) scan_s[w] = inc;
+    __syncthreads();
+    long long run = inc - mine, total = 0;
+    for (int i = 0; i < 16; i++) { if (i < w) run += scan_s[i]; total += scan_s[i]; }
+    for (int b = b0; b < b1; b++) {
+        const long long nbk = grids[b].hi > grids[b].lo ? (long long)(floor(grids[b].cells / Bd) + 2.0) : 1;
+        grids[b].nbuckets = nbk;
+        grids[b].table_off = run;
+        run += nbk;
+    }
+    if (tid == 0) { st->error = total > max_cells ? 1 : 0; st->B = (unsigned long long)Bd; }
+    (void)s_B;
+}
+
+__global__ void __launch_bounds__(1024) k_vox_offsets(VoxGrid* __restrict__ grids, int nb, long long max_cells, VoxStatus* __restrict__ st)
+{
+    vox_offsets(grids, nb, max_cells, st);
+}
 
 __global__ void __launch_bounds__(1024) k_vox_bbox(const float* __restrict__ pts, const int* __restrict__ off,
                                                  VoxGrid* __restrict__ grids, float dl)
@@ -71,27 +120,6 @@ __global__ void __launch_bounds__(1024) k_vox_bbox(const float* __restrict__ pts
     }
 }
 
-__global__ void k_vox_offsets(VoxGrid* __restrict__ grids, int nb, long long max_cells, VoxStatus* __restrict__ st)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double Bd = 1.0;
-    for (int it = 0; it < 200; it++) {             // smallest power-of-two bucket width that fits the table
-        double need = 0.0;
-        for (int b = 0; b < nb; b++) need += grids[b].hi > grids[b].lo ? floor(grids[b].cells / Bd) + 2.0 : 1.0;
-        if (need <= (double)max_cells) break;
-        Bd *= 2.0;
-    }
-    long long run = 0;
-    for (int b = 0; b < nb; b++) {
-        long long nbk = grids[b].hi > grids[b].lo ? (long long)(floor(grids[b].cells / Bd) + 2.0) : 1;
-        grids[b].nbuckets = nbk;
-        grids[b].table_off = run;
-        run += nbk;
-    }
-    st->error = run > max_cells ? 1 : 0;
-    st->B = (unsigned long long)Bd;
-}
-
 __global__ void __launch_bounds__(256) k_vox_count(const float* __restrict__ pts, int n, const int* __restrict__ off, int nb,
                                                  const VoxGrid* __restrict__ grids, const VoxStatus* __restrict__ st,
                                                  int* __restrict__ table, int* __restrict__ cell_of,
@@ -118,24 +146,27 @@ __global__ void __launch_bounds__(256) k_vox_count(const float* __restrict__ pts
 __global__ void __launch_bounds__(256) k_vox_rank(const int* __restrict__ cell_of, const unsigned long long* __restrict__ keys,
                                                 const int* __restrict__ table, const float4* __restrict__ sorted_in, int n,
                                                 const VoxStatus* __restrict__ st, float4* __restrict__ sorted_out,
-                                                unsigned long long* __restrict__ key_sorted, int* __restrict__ cell_sorted)
+                                                unsigned long long* __restrict__ key_sorted, int* __restrict__ cell_sorted, int* __restrict__ head)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n || st->error) return;
+    if (p >= n) return;
+    if (st->error) { head[p] = 0; return; }
     float4 me = sorted_in[p];
     int i = __float_as_int(me.w);
     int c = cell_of[i];
     unsigned long long k = keys[i];
     int s = c == 0 ? 0 : table[c - 1], e = table[c];
-    int rank = 0;
+    int rank = 0, same_before = 0;
     for (int t = s; t < e; t++) {
         int j = __float_as_int(sorted_in[t].w);
         unsigned long long kj = keys[j];
         rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+        same_before += (kj == k && j < i) ? 1 : 0;
     }
     sorted_out[s + rank] = me;
     key_sorted[s + rank] = k;
     cell_sorted[s + rank] = c;
+    head[s + rank] = same_before == 0 ? 1 : 0;                  // the first point of its voxel in input order = the head of the voxel's run (round 6: was k_vox_heads)
 }
 
 __device__ __forceinline__ bool vox_is_head(const unsigned long long* __restrict__ key_sorted, const int* __restrict__ cell_sorted, int p)
@@ -143,19 +174,20 @@ __device__ __forceinline__ bool vox_is_head(const unsigned long long* __restrict
     return p == 0 || cell_sorted[p] != cell_sorted[p - 1] || key_sorted[p] != key_sorted[p - 1];
 }
 
-__global__ void __launch_bounds__(256) k_vox_heads(const unsigned long long* __restrict__ key_sorted, const int* __restrict__ cell_sorted,
-                                                 int n, const VoxStatus* __restrict__ st, int* __restrict__ head)
-{
-    int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    head[p] = (!st->error && vox_is_head(key_sorted, cell_sorted, p)) ? 1 : 0;
-}
-
 __global__ void __launch_bounds__(256) k_vox_emit(const float4* __restrict__ sorted, const unsigned long long* __restrict__ key_sorted,
                                                 const int* __restrict__ cell_sorted, const int* __restrict__ rowidx,
                                                 int n, const VoxStatus* __restrict__ st, float* __restrict__ out,
-                                                const float* __restrict__ feats, int fdim, float* __restrict__ out_feats)
+                                                const float* __restrict__ feats, int fdim, float* __restrict__ out_feats,
+                                                const int* __restrict__ off, int nb, const int* __restrict__ total_dev, int* __restrict__ counts)
 {
+    if (blockIdx.x == gridDim.x - 1) {                           // rows per element from the exclusive head scan; counts[nb] = status, [nb + 1] = total (was k_vox_counts)
+        const int tot = *total_dev;
+        for (int b = threadIdx.x; b <= nb; b += 256) {
+            if (b == nb) { counts[nb] = st->error; counts[nb + 1] = tot; continue; }
+            const int lo = off[b], hi = off[b + 1];
+            counts[b] = (hi < n ? rowidx[hi] : tot) - (lo < n ? rowidx[lo] : tot);
+        }
+    }
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n || st->error) return;
     if (!vox_is_head(key_sorted, cell_sorted, p)) return;
@@ -183,6 +215,7 @@ __global__ void __launch_bounds__(256) k_vox_emit(const float4* __restrict__ sor
     }
 }
 
+// stand-alone form for callers with their own emit kernel (csrc/preprocess.hip)
 // per-element row counts from the exclusive head scan; counts[nb] = status word
 __global__ void k_vox_counts(const int* __restrict__ rowidx, const int* __restrict__ off, int nb, int n, int total,
                              const int* __restrict__ total_dev, VoxStatus* __restrict__ st, int* __restrict__ counts)
@@ -208,8 +241,8 @@ static VoxWs carve_vox(WsCarver& w, int n, int nb, int64_t max_cells, int fdim)
     VoxWs v;
     size_t nn = (size_t)(n > 0 ? n : 1);
     v.grids = w.take<VoxGrid>((size_t)nb);
-    v.st = w.take<VoxStatus>(1);
     v.off = w.take<int>((size_t)nb + 1);
+    v.st = w.take<VoxStatus>(1);
     v.table = w.take<int>((size_t)max_cells);
     v.cell_of = w.take<int>(nn);
     v.sorted_tmp = w.take<float4>(nn);
@@ -261,20 +294,19 @@ extern "C" int buf_grid_subsample_batch(const float* pts, int n, const int* batc
     bool timed = timing_begin(s, &span, 24.0 * n + 4.0 * nb, BUF_TIMED_GRID_SUBSAMPLE);
     BUF_CHECK_HIP(hipMemsetAsync(v.table, 0, sizeof(int) * (size_t)max_cells, s));
     k_vox_bbox<<<nb, 1024, 0, s>>>(pts, v.off, v.grids, dl);
-    k_vox_offsets<<<1, 1, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
+    k_vox_offsets<<<1, 1024, 0, s>>>(v.grids, nb, (long long)max_cells, v.st);
     int blocks = cdiv(n, 256);
     k_vox_count<<<blocks, 256, 0, s>>>(pts, n, v.off, nb, v.grids, v.st, v.table, v.cell_of, v.keys);
     rc = exclusive_scan_i32(v.table, (long long)max_cells, v.scan_tmp, nullptr, s);
     if (rc) return rc;
     k_cell_scatter<<<blocks, 256, 0, s>>>(pts, n, v.cell_of, &v.st->error, v.table, v.sorted_tmp);
-    k_vox_rank<<<blocks, 256, 0, s>>>(v.cell_of, v.keys, v.table, v.sorted_tmp, n, v.st, v.sorted, v.key_sorted, v.cell_sorted);
-    k_vox_heads<<<blocks, 256, 0, s>>>(v.key_sorted, v.cell_sorted, n, v.st, v.head);
+    k_vox_rank<<<blocks, 256, 0, s>>>(v.cell_of, v.keys, v.table, v.sorted_tmp, n, v.st, v.sorted, v.key_sorted, v.cell_sorted, v.head);   // + head flags
     rc = exclusive_scan_i32(v.head, n, v.scan_tmp, v.total, s);
     if (rc) return rc;
     float* dst = max_p > 0 ? v.out_tmp : out_pts;
     float* fdst = max_p > 0 ? v.feat_tmp : out_feats;
-    k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.key_sorted, v.cell_sorted, v.head, n, v.st, dst, fdim > 0 ? feats : nullptr, fdim, fdst);
-    k_vox_counts<<<cdiv(nb + 1, 64), 64, 0, s>>>(v.head, v.off, nb, n, 0, v.total, v.st, v.counts);
+    k_vox_emit<<<blocks, 256, 0, s>>>(v.sorted, v.key_sorted, v.cell_sorted, v.head, n, v.st, dst, fdim > 0 ? feats : nullptr, fdim, fdst,
+                                      v.off, nb, v.total, v.counts);                                  // + rows per element
     if (timed) timing_end(s, &span);
     BUF_LAUNCH_CHECK();
     int stackc[66];
