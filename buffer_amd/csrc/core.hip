@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) k_cell_rank(const int* __restrict__ cell_
                                                  const float4* __restrict__ sorted_in, int n, const int* __restrict__ err,
                                                  float4* __restrict__ sorted_out, int* __restrict__ order_out,
                                                  int* __restrict__ scell_out = nullptr, const int* __restrict__ dims = nullptr,
-                                                 long long cells_per_elem = 0, int dims_stride = 0)
+                                                 long long cells_per_elem = 0, int dims_stride = 0, int* __restrict__ cruns = nullptr)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n || (err && *err)) return;
@@ -241,13 +241,35 @@ __global__ void __launch_bounds__(256) k_cell_rank(const int* __restrict__ cell_
     sorted_out[s + rank] = me;
     order_out[s + rank] = i;
     if (scell_out) {
-        // the cell of every row of the cell-ordered stream, as PACKED coordinates x | y << 10 | z << 20 (one division chain per
-        // point here instead of one per cell change in k_grid_query_cell); a grid with a dimension above 1024 stores the linear
-        // cell number with the sign bit set and the query kernel divides
-        const int b = (int)(c / cells_per_elem), cl = (int)(c - (long long)b * cells_per_elem);
-        const int dx = dims[b * dims_stride], dy = dims[b * dims_stride + 1], dz = dims[b * dims_stride + 2];
-        const int x = cl % dx, t2 = cl / dx, y = t2 % dy, z = t2 / dy;
-        scell_out[s + rank] = (dx <= 1024 && dy <= 1024 && dz <= 1024) ? (x | (y << 10) | (z << 20)) : (int)(0x80000000u | (unsigned)cl);
+        // the cell of every row of the cell-ordered stream, named by the FIRST ROW of the cell's run (round 6; rounds 4-5: packed cell
+        // coordinates, from which k_grid_query_cell derived 18 scattered reads of the dense table at every cell change -- most of the
+        // operator's HBM traffic).  The row that opens the run writes the cell's 27-cell neighbourhood ONCE as a record of 9 run starts |
+        // 0 | 9 run lengths | 0 at cruns[20 * first row]: the query kernel stages a cell from one contiguous 80-byte read.
+        scell_out[s + rank] = s;
+        if (rank == 0) {
+            const int b = (int)(c / cells_per_elem), cl = (int)(c - (long long)b * cells_per_elem);
+            const int dx = dims[b * dims_stride], dy = dims[b * dims_stride + 1], dz = dims[b * dims_stride + 2];
+            const int cx = cl % dx, t2 = cl / dx, cy = t2 % dy, cz = t2 / dy;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, dx - 1);
+            const long long toff = (long long)b * cells_per_elem;
+            int rs[9], len[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int y = cy + (j % 3) - 1, z = cz + (j / 3) - 1;
+                rs[j] = 0; len[j] = 0;
+                if (y >= 0 && y < dy && z >= 0 && z < dz) {
+                    const long long g0 = toff + x0 + (long long)dx * (y + (long long)dy * z);
+                    rs[j] = g0 == 0 ? 0 : table[g0 - 1];
+                    len[j] = table[g0 + (x1 - x0)] - rs[j];
+                }
+            }
+            int4* rec = reinterpret_cast<int4*>(cruns + 20 * (size_t)s);
+            rec[0] = make_int4(rs[0], rs[1], rs[2], rs[3]);
+            rec[1] = make_int4(rs[4], rs[5], rs[6], rs[7]);
+            rec[2] = make_int4(rs[8], 0, len[0], len[1]);
+            rec[3] = make_int4(len[2], len[3], len[4], len[5]);
+            rec[4] = make_int4(len[6], len[7], len[8], 0);
+        }
     }
 }
 

@@ -452,6 +452,7 @@ __device__ __forceinline__ void qc_pass(const float4* __restrict__ cd_lds, int t
 template <int CAP, int CAPC>
 __global__ void __launch_bounds__(QC_WAVES * WAVE) k_grid_query_cell(const CellGrid* __restrict__ grids, const int* __restrict__ table,
                                                                   const float4* __restrict__ sorted, const int* __restrict__ scell,
+                                                                  const int* __restrict__ cruns,
                                                                   const int* __restrict__ q_off, float r2, float bin_scale, int k_out, int shadow,
                                                                   int* __restrict__ nbr_out, int* __restrict__ counts_out,
                                                                   int* __restrict__ max_count_out, int* __restrict__ todo,
@@ -470,28 +471,19 @@ __global__ void __launch_bounds__(QC_WAVES * WAVE) k_grid_query_cell(const CellG
     const int base = (blockIdx.x * QC_WAVES + w) * QC_QPW;
     if (base >= e_n) return;
     const int nq_w = min(QC_QPW, e_n - base);
-    const CellGrid g = grids[b];
+    (void)grids; (void)table;            // (round 6: the neighbourhood of a cell comes from its record, not from the dense table)
     // lanes 0..15 (and their copies in the other rows) hold the wavefront's 16 queries
     const bool have = l16 < nq_w;
     const float4 me = have ? sorted[e_lo + base + l16] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int mycell = have ? scell[e_lo + base + l16] : -1;
     int staged = -2, total = 0;
 
-    // the 27-cell candidate set of cell `c` (packed coordinates, or sign bit + linear number) -> cand[w][0 .. total)
+    // the 27-cell candidate set of the cell whose run starts at row `c` -> cand[w][0 .. total): its record (k_cell_rank) is ONE 80-byte read
     auto stage = [&](int c) __attribute__((always_inline)) {
-        int cx, cy, cz;
-        if (c >= 0) { cx = c & 1023; cy = (c >> 10) & 1023; cz = c >> 20; }
-        else { const int cl = c & 0x7fffffff; cx = cl % g.dim[0]; const int t2 = cl / g.dim[0]; cy = t2 % g.dim[1]; cz = t2 / g.dim[1]; }
-        int rs = 0, len = 0;
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-        const int y = cy + (l16 % 3) - 1, z = cz + (l16 / 3) - 1;
-        if (l16 < 9 && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
-            const int g0 = g.table_off + x0 + g.dim[0] * (y + g.dim[1] * z);
-            rs = g0 == 0 ? 0 : table[g0 - 1];
-            len = table[g0 + (x1 - x0)] - rs;
-        }
+        int rec = 0;
+        if (lane < 20) rec = cruns[20 * (size_t)c + lane];
         wave_sync();                         // the previous cell's candidates and runs have been read
-        if (lane < 10) { runs[w][lane] = rs; runs[w][10 + lane] = len; }
+        if (lane < 20) runs[w][lane] = rec;
         wave_sync();
         int st[9], pre[9];
         int tot = 0;
@@ -662,7 +654,7 @@ static void carve_grid(buf_grid_t* g, WsCarver& w, int ns, int nb, int64_t cells
     g->scan_tmp = w.take<int>(scan_tmp_ints());
 }
 
-struct GridExtra { float4* sorted_tmp; int* cell_of; int* q_off; int* todo_n; int* scell; };
+struct GridExtra { float4* sorted_tmp; int* cell_of; int* q_off; int* todo_n; int* scell; int* cruns; };
 
 static GridExtra carve_extra(WsCarver& w, int ns, int nb)
 {
@@ -671,7 +663,8 @@ static GridExtra carve_extra(WsCarver& w, int ns, int nb)
     e.cell_of = w.take<int>((size_t)(ns > 0 ? ns : 1));
     e.q_off = w.take<int>((size_t)nb + 1);
     e.todo_n = w.take<int>(64);
-    e.scell = w.take<int>((size_t)(ns > 0 ? ns : 1));          // cell of every row of the cell-ordered stream
+    e.scell = w.take<int>((size_t)(ns > 0 ? ns : 1));          // cell of every row of the cell-ordered stream (= first row of the cell's run)
+    e.cruns = w.take<int>(20 * (size_t)(ns > 0 ? ns : 1));     // 27-cell neighbourhood records, one per occupied cell at 20 * its first row (80 B, written by k_cell_rank)
     return e;
 }
 
@@ -714,7 +707,7 @@ extern "C" int buf_grid_build(buf_grid_t* g, const float* supports, int ns, cons
         if (rc) return rc;
         k_cell_scatter<<<cdiv(ns, 256), 256, 0, s>>>(supports, ns, ex.cell_of, nullptr, g->table, ex.sorted_tmp);
         k_cell_rank<<<cdiv(ns, 256), 256, 0, s>>>(ex.cell_of, g->table, ex.sorted_tmp, ns, nullptr, (float4*)g->sorted, g->order, ex.scell,
-                                                  ((const CellGrid*)g->desc)->dim, (long long)cells_per_elem, (int)(sizeof(CellGrid) / sizeof(int)));
+                                                  ((const CellGrid*)g->desc)->dim, (long long)cells_per_elem, (int)(sizeof(CellGrid) / sizeof(int)), ex.cruns);
     }
     BUF_LAUNCH_CHECK();
     return BUF_OK;
@@ -767,11 +760,11 @@ extern "C" int buf_grid_query(const buf_grid_t* g, const float* queries, int nq,
             dim3 gridc(cdiv(qmax, QC_WAVES * QC_QPW), g->nb);
             if (k_out > 32)
                 k_grid_query_cell<2 * QW_CAP, 512><<<gridc, QC_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, ex.scell,
-                                                                                 g->s_off, r2, bin_scale, k_out, g->ns, nbr_out, counts_out,
+                                                                                 ex.cruns, g->s_off, r2, bin_scale, k_out, g->ns, nbr_out, counts_out,
                                                                                  max_count_out, todo, ex.todo_n);
             else
                 k_grid_query_cell<QW_CAP, QC_CAPC><<<gridc, QC_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted, ex.scell,
-                                                                             g->s_off, r2, bin_scale, k_out, g->ns, nbr_out, counts_out,
+                                                                             ex.cruns, g->s_off, r2, bin_scale, k_out, g->ns, nbr_out, counts_out,
                                                                              max_count_out, todo, ex.todo_n);
         } else if (k_out > 32)
             k_grid_query_wave<2 * QW_CAP><<<grid2, QW_WAVES * WAVE, 0, s>>>((const CellGrid*)g->desc, g->table, (const float4*)g->sorted,
