@@ -229,7 +229,12 @@ def voxelize_entry(timed, traffic, patches, lib_version=None):
     e['frac'] = e['achieved'] / e['peak']
     e['source'] = 'SQ_INSTS_VALU / patches, profiles/instr.json (tools/make_instr.py)'
     e['instr_lib_version'] = instr.get('lib_version')
-    e['instr_current'] = None if lib_version is None else bool(instr.get('lib_version') == lib_version)
+    # current = counted on THIS library version AND on this very voxelize.hip (kernels changed without a version bump)
+    import hashlib
+    src = os.path.join(ROOT, 'buffer_amd', 'csrc', 'voxelize.hip')
+    sha = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16] if os.path.exists(src) else None
+    same_src = instr.get('csrc_sha256_16', {}).get('voxelize.hip') == sha
+    e['instr_current'] = None if lib_version is None else bool(instr.get('lib_version') == lib_version and same_src)
     return e
 
 

@@ -45,7 +45,36 @@ def build(force=False, verbose=False, out=None):
         print(err, file=sys.stderr)
     if r.returncode != 0:
         raise subprocess.CalledProcessError(r.returncode, cmd)
+    if "+packed-fp32-ops" not in os.environ.get("BUF_EXTRA_HIPCC_FLAGS", ""):     # (tools/pk_bisect.sh builds packed variants on purpose)
+        verify_no_packed_fp32(out)
     return out
+
+
+def verify_no_packed_fp32(so):
+    """The warning filter above would also hide a toolchain that IGNORES -packed-fp32-ops on the device side: the built code
+    object itself is checked.  Any v_pk_{mul,add,fma}_f32 in it fails the build (profiles/r06_pk_hazard.txt: such kernels return wrong values
+    beside the library's f16-MFMA kernels).  Skipped only where the image has no llvm-objdump."""
+    import glob
+    import re
+    import tempfile
+    objdump = os.path.join(os.path.dirname(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), "..", "lib", "llvm", "bin", "llvm-objdump")
+    if not os.path.exists(objdump):
+        objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        print("buffer_amd.build: no llvm-objdump, the packed-fp32 check of the code object was skipped", file=sys.stderr)
+        return
+    with tempfile.TemporaryDirectory() as tmp:
+        link = os.path.join(tmp, "lib.so")
+        os.symlink(os.path.abspath(so), link)
+        subprocess.run([objdump, "--offloading", link], capture_output=True, cwd=tmp, check=True)
+        cos = [f for f in glob.glob(os.path.join(tmp, "*")) if "gfx950" in os.path.basename(f)]
+        if not cos:
+            raise RuntimeError(f"{so}: no gfx950 code object found")
+        asm = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True, check=True).stdout
+    hits = re.findall(r"v_pk_(?:mul|add|fma)_f32", asm)
+    if hits:
+        raise RuntimeError(f"{so}: {len(hits)} packed-fp32 instructions in the gfx950 code object: the toolchain ignored "
+                           "-target-feature -packed-fp32-ops (see profiles/r06_pk_hazard.txt)")
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ void buf_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* buf_last_error(void) { return g_err; }
-extern "C" int buf_version(void) { return 500; }   // 500: round 5 (no packed-fp32 instructions, per-element scaled 1-NN planes); 200: round 2 (batched entry points, Winograd descriptor CNN); 300: round 3 (filter tilings: N-tile
+extern "C" int buf_version(void) { return 600; }   // 600: round 6 (split-f16 kernels safe by construction, cell records of the A2 self query, A1 with 13 launches); 500: round 5 (no packed-fp32 instructions, per-element scaled 1-NN planes); 200: round 2 (batched entry points, Winograd descriptor CNN); 300: round 3 (filter tilings: N-tile
                                                    // groups for 32 / 64 channels, Winograd layers 1-5 of the cost net, compact voxel lookup table)
 
 // ------------------------------------------------------------------------------------------

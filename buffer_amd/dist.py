@@ -46,7 +46,8 @@ def _gpu_numa_nodes(sys_root='/sys'):
             try:
                 if open(os.path.join(d, 'vendor')).read().strip() != '0x1002':
                     continue
-                if not open(os.path.join(d, 'class')).read().strip().startswith(('0x0302', '0x0380', '0x0300', '0x1200')):
+                # 3D / display / processing accelerators (not 0x0300: a board's VGA function is no compute device)
+                if not open(os.path.join(d, 'class')).read().strip().startswith(('0x0302', '0x0380', '0x1200')):
                     continue
                 nodes.append(int(open(os.path.join(d, 'numa_node')).read().strip()))
             except (OSError, ValueError):
@@ -64,7 +65,10 @@ def rank_cpus(local_rank, local_world, allowed=None, sys_root='/sys'):
     allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
     local_world = max(int(local_world), 1)
     local_rank = int(local_rank) % local_world
-    nodes = _gpu_numa_nodes(sys_root)
+    # a *_VISIBLE_DEVICES mask may drop or reorder devices: sysfs order is then no longer HIP's order and LOCAL_RANK no device index --
+    # no NUMA guess in that case, contiguous shares of the allowed cores instead
+    masked = any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+    nodes = [] if masked else _gpu_numa_nodes(sys_root)
     if len(nodes) >= local_world and all(n >= 0 for n in nodes[:local_world]):
         node = nodes[local_rank]
         try:
@@ -96,6 +100,12 @@ def pin_rank(local_rank=None, local_world=None):
         os.sched_setaffinity(0, cpus)
     except OSError:
         return {}
+    try:                                      # a process that already imported torch keeps the whole machine's thread count otherwise: the
+        import sys                            # intra-op pool would oversubscribe this rank's share
+        if 'torch' in sys.modules:
+            sys.modules['torch'].set_num_threads(max(1, len(cpus)))
+    except Exception:
+        pass
     return dict(cpus=len(cpus), first=cpus[0], last=cpus[-1], numa_node=node)
 
 
