@@ -237,6 +237,25 @@ __device__ __forceinline__ int row16_excl_scan(int v)
     return inc - v;
 }
 
+// XCD-aware (chunk, element) of a workgroup of the 2-D query launches (grid = chunks x elements).  The hardware deals workgroups to the
+// 8 XCDs round-robin in launch order (x fastest): with the plain blockIdx mapping the chunks of ONE element land on all eight XCDs in turn and
+// every L2 fetches that element's whole cell-ordered array and table (measured, round 6: FETCH_SIZE of the self query = 8 x its algorithmic
+// input; profiles/r06_a2_floor.txt).  Here XCD x takes the elements x, x + 8, ...: an element's rows, cells and records stay in ONE L2
+// (FETCH_SIZE -36 % / -83 % for the cell-centric / query-centric kernel, WRITE_SIZE -24 %: the 68-byte rows of neighbouring queries merge in
+// one L2).  The price is the imbalance between the XCDs' element sums (+2 % / +7 % time at 64 elements of 9-12 k points).  Also tried: XCD x
+// takes the x-th eighth of EVERY element's chunk range (no division, balanced by construction -- but the launch is as wide as the LARGEST
+// element, so the last XCD's slab is mostly empty for the others: +16 %).  A bijection on the grid whenever the element count is a multiple
+// of 8 (pairs: always); other grids keep the plain mapping.
+__device__ __forceinline__ void grid2d_xcd_block(int& chunk, int& elem)
+{
+    chunk = blockIdx.x; elem = blockIdx.y;
+    if ((gridDim.y & 7u) == 0u) {
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, x = L & 7u, idx = L >> 3;
+        elem = (int)(8u * (idx / gridDim.x) + x);
+        chunk = (int)(idx % gridDim.x);
+    }
+}
+
 template <int CAP>
 __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellGrid* __restrict__ grids, const int* __restrict__ table,
                                                                   const float4* __restrict__ sorted, const float* __restrict__ queries,
@@ -255,10 +274,11 @@ __global__ void __launch_bounds__(QW_WAVES * WAVE) k_grid_query_wave(const CellG
     __shared__ int cur[QW_WAVES][QPW][QG];                                                         // scatter cursors
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int grp = lane / QG, l16 = lane & (QG - 1);
-    const int b = blockIdx.y;                                             // batch element: wave-uniform
+    int bx, b;                                                            // chunk, batch element: wave-uniform
+    grid2d_xcd_block(bx, b);
     const int e_lo = q_off[b], e_n = q_off[b + 1] - e_lo;                 // scalar loads
-    if ((int)blockIdx.x * QW_QPB >= e_n) return;                          // chunk past this element's queries
-    const int tl = (blockIdx.x * QW_WAVES + w) * QPW + grp;               // query number inside the element
+    if (bx * QW_QPB >= e_n) return;                                       // chunk past this element's queries
+    const int tl = (bx * QW_WAVES + w) * QPW + grp;                       // query number inside the element
     bool active = tl < e_n;
     const int t = e_lo + tl;
     int qi = 0;
@@ -466,9 +486,10 @@ __global__ void __launch_bounds__(QC_WAVES * WAVE) k_grid_query_cell(const CellG
     __shared__ int cur[QC_WAVES][QPW][QG];
     const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const int grp = lane / QG, l16 = lane & (QG - 1);
-    const int b = blockIdx.y;
+    int bx, b;
+    grid2d_xcd_block(bx, b);
     const int e_lo = q_off[b], e_n = q_off[b + 1] - e_lo;
-    const int base = (blockIdx.x * QC_WAVES + w) * QC_QPW;
+    const int base = (bx * QC_WAVES + w) * QC_QPW;
     if (base >= e_n) return;
     const int nq_w = min(QC_QPW, e_n - base);
     (void)grids; (void)table;            // (round 6: the neighbourhood of a cell comes from its record, not from the dense table)

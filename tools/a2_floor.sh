@@ -17,7 +17,7 @@ for v in old new; do
         case $pass in sq) cnt="$C";; fetch) cnt="FETCH_SIZE";; write) cnt="WRITE_SIZE";; esac
         timeout 300 tools/prof.sh a2f_${v}_$pass pmc "$cnt" -- python3 tools/bench_ops.py radius $pairs 3 > /dev/null 2>&1
         echo "-- $v $pass" >> $out
-        python3 tools/pmc_sum.py gpurun_out/a2f_${v}_$pass k_grid_query_cell >> $out 2>&1
+        python3 tools/pmc_sum.py gpurun_out/a2f_${v}_$pass k_grid_query_ >> $out 2>&1
         rm -rf gpurun_out/a2f_${v}_$pass
     done
 done

@@ -38,7 +38,7 @@ if which == 'cyl':
 if which == 'radius':
     npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-    samples = [synth.make_pair(3000 + i) for i in range(min(npairs, 4))]
+    samples = [synth.make_pair(3000 + i) for i in range(min(npairs, int(os.environ.get('BENCH_OPS_SAMPLES', 4))))]      # distinct pairs, repeated
     pts, lens = [], []
     for i in range(npairs):
         s = samples[i % len(samples)]
