@@ -139,9 +139,9 @@ def cpu_baseline(sample, cfg, limits, hip_register=None, hip_register_split=None
         # patch coordinates differ in the last bit (torch's CPU matmul vs the kernel's Rodrigues product): a handful of rows in 10^4
         # see another sample there (tools/desc_diff_probe.py); every other row agrees to fp32 round-off
         ddesc = torch.cat([(gd['desc'][i]['desc'].cpu() - wd['desc'][i]['desc']).abs().amax(1) for i in range(2)]) if kp_equal else None
-        # ... and the cause is SHOWN for every such row (round 6, buffer_amd/diagnose.py): the two aligned patches differ in their last
-        # bits only, the fp32 hit masks of the 420 x 512 (centre, point) pairs differ in at least one pair, and every differing pair
-        # lies on a voxel ball's surface within the alignment's last-bit uncertainty.  A row over tolerance WITHOUT that is counted as
+        # ... and the cause is SHOWN for every such row (round 6, buffer_amd/diagnose.py): the two aligned patches agree to the accuracy of
+        # two fp32 Rodrigues rotations (4e-6), the fp32 hit masks of the 420 x 512 (centre, point) pairs differ in at least one pair, and
+        # every differing pair's margin |d^2 - r^2| is within what the observed coordinate difference of that point can move.  A row over tolerance WITHOUT that is counted as
         # unexplained (the bench-contract test requires 0).
         over, unexplained, shown = [], 0, []
         if kp_equal:

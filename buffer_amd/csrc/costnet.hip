@@ -410,10 +410,10 @@ __device__ long long* cv_stamp_ptr;       // development build (-DCV_STAMP): s_m
 #define CV_STAMP_AT(SLOT)
 #endif
 
-__global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restrict__ s_eq, const float* __restrict__ t_eq, CostNetParams P,
-                                                        float* __restrict__ ind_out)
+__device__ __forceinline__ void cost_net_body(const float* __restrict__ s_eq, const float* __restrict__ t_eq, const CostNetParams& P,
+                                              float* __restrict__ ind_out, float* __restrict__ lds)
 {
-    extern __shared__ float lds[];           // ONE buffer of CV_BUF floats (75 KB): two workgroups per CU
+    // lds: ONE buffer of CV_BUF floats (75 KB): two workgroups per CU
     float* bufA = lds;                       // every map from layer 1 on (layers 2..6 rewrite it in place)
     float* bufB = lds;                       // phase A: the maps of the separated layer 0 and the row chunks live here first
     float* SP = bufB + CVA_SP;
@@ -421,7 +421,6 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
     float* SM = bufB + CVA_SM;
     float* TB = bufB + CVA_TB;
     const int match = blockIdx.x;
-    if (P.only_if && P.only_if[match] == 0) return;       // masked re-run: the matches the split-f16 kernel flagged, nothing else
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), li = lane & 15, lk = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid / WAVE);        // wavefront-uniform for the compiler too (scalar weight offsets)
     {   // both maps, transposed on the way in: global [c][k][l] -> LDS [k][l][c]; S with its two wrap-around columns per side
@@ -670,6 +669,22 @@ __global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restr
     }
 }
 
+__global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net(const float* __restrict__ s_eq, const float* __restrict__ t_eq, CostNetParams P,
+                                                        float* __restrict__ ind_out)
+{
+    extern __shared__ float lds[];
+    cost_net_body(s_eq, t_eq, P, ind_out, lds);
+}
+
+// The masked re-run of buf_cost_volume_net_split_safe (matches the split-f16 kernel flagged): its own kernel name, see k_cyl_net_wg_rerun.
+__global__ void __launch_bounds__(CV_THREADS, 2) k_cost_net_rerun(const float* __restrict__ s_eq, const float* __restrict__ t_eq, CostNetParams P,
+                                                              float* __restrict__ ind_out)
+{
+    extern __shared__ float lds[];
+    if (P.only_if[blockIdx.x] == 0) return;
+    cost_net_body(s_eq, t_eq, P, ind_out, lds);
+}
+
 // N-tiles per group in the Winograd filter tiling of layer l (2..5): what buf_winograd_tile_filters is to be called with
 extern "C" int buf_cost_winograd_group(int layer)
 {
@@ -691,8 +706,8 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
     P.skip_floats = s_rows ? 20 : 0;                         // elevation row 0 of every channel is not part of the cost volume
     P.only_if = only_if;
     size_t lds = sizeof(float) * CV_BUF;
-    static LdsGrant grant;
-    if (int rc = grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
+    static LdsGrant grant, grant_rerun;
+    if (int rc = only_if ? grant_dynamic_lds((const void*)k_cost_net_rerun, lds, grant_rerun) : grant_dynamic_lds((const void*)k_cost_net, lds, grant)) return rc;
     // EXECUTED flops per match: layer 0 in its separated form (S-term 60 x 480 x 32, T-term 54 x 288 x 32 MAC instead of the
     // dense 972 x 864 x 32), then the valid convolutions 18x3x18 -> 16x1x16 -> 14 -> 12 -> 10 -> 8 -> 6 -> 4 -> 2 -> 1:
     // 2 * sum(out positions * K * Cout), layers 1..5 with 16 products per 2 x 2 output tile (Winograd) = 0.0519 GFLOP.  The dense algorithmic count of SURVEY 8d is 0.160 GFLOP/match
@@ -708,7 +723,8 @@ static int cost_net_launch(const float* s_eq, const float* t_eq, int m, const fl
     BUF_CHECK_HIP(hipMalloc(&stamps, (size_t)m * 16 * sizeof(long long)));
     BUF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cv_stamp_ptr), &stamps, sizeof(stamps)));
 #endif
-    k_cost_net<<<m, CV_THREADS, lds, (hipStream_t)stream>>>(s_eq, t_eq, P, ind_out);
+    if (only_if) k_cost_net_rerun<<<m, CV_THREADS, lds, (hipStream_t)stream>>>(s_eq, t_eq, P, ind_out);
+    else k_cost_net<<<m, CV_THREADS, lds, (hipStream_t)stream>>>(s_eq, t_eq, P, ind_out);
     if (timed) timing_end((hipStream_t)stream, &span);
     BUF_LAUNCH_CHECK();
 #ifdef CV_STAMP

@@ -14,5 +14,5 @@ python tools/a1_time.py 32 > gpurun_out/$tag/a1_time.txt 2>&1
 python tests/eval_recall.py --backend gpu --out gpurun_out/$tag/recall_gpu.json > gpurun_out/$tag/recall_gpu.log 2>&1
 python tests/eval_ransac_rr.py --out gpurun_out/$tag/ransac_rr.json > gpurun_out/$tag/ransac_rr.log 2>&1
 python tests/eval_ransac_rr.py --overlaps 0.35,0.3,0.25,0.2 --out gpurun_out/$tag/ransac_rr_low_overlap.json > gpurun_out/$tag/ransac_rr_low.log 2>&1
-tail -2 gpurun_out/$tag/recall_gpu.log gpurun_out/$tag/ransac_rr.log gpurun_out/$tag/ransac_rr_low.log
+for f in recall_gpu ransac_rr ransac_rr_low; do tail -n 2 gpurun_out/$tag/$f.log; done
 cat gpurun_out/${tag}_tests.log
