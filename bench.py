@@ -717,6 +717,7 @@ def surface_cpu_leg(calls):
         'grouping_operation': cpu.grouping_operation,
         'KNN': lambda ref, query: cpu.knn(ref, query, 1),
         'svd': lambda m: np.linalg.svd(m.astype(np.float32)),
+        'three_nn': lambda unknown, known: cpu.three_nn(unknown, known),
     }
     for c in calls:
         fn = impl[c['fn']]
@@ -733,6 +734,8 @@ def surface_cpu_leg(calls):
                               and all(np.array_equal(rows_sorted(got[0][lo:hi]), rows_sorted(want[0][lo:hi]))
                                       for lo, hi in zip(np.cumsum(got[1]) - got[1], np.cumsum(got[1]))))
         elif c['fn'] == 'KNN':
+            c['equal'] = bool(np.array_equal(got[1], want[1]) and np.allclose(got[0], want[0], rtol=1e-6, atol=1e-7))
+        elif c['fn'] == 'three_nn':               # (dist f32[B,n,3], idx int32[B,n,3])
             c['equal'] = bool(np.array_equal(got[1], want[1]) and np.allclose(got[0], want[0], rtol=1e-6, atol=1e-7))
         elif c['fn'] == 'svd':                    # signs are free: singular values, and U S V^T = A
             u, sv, v = got
@@ -863,6 +866,7 @@ def run_surface(a, dev, L):
              patches.transpose(1, 2).contiguous(), vi)
         covs.append(torch.matmul(patches.transpose(-1, -2), patches))
 
+    cp = [pts0[lo:hi][torch.where(score[lo:hi] > cfg.keypts_th)[0]].contiguous() for lo, hi in ((0, n_src), (n_src, int(pts0.shape[0])))]
     # ---- mutual matching (models/BUFFER.py:347,352)
     des = [d['desc'][i]['desc'].contiguous() for i in range(2)]
     knn = KNN(k=1, transpose_mode=True)
@@ -870,6 +874,10 @@ def run_surface(a, dev, L):
     call('knn_cuda.KNN(k=1)', 'KNN', 'models/BUFFER.py:352', f'ref [1,{keypts},32], query [1,{keypts},32]', knn, des[0][None], des[1][None])
     for i in range(2):
         call('torch_batch_svd.svd', 'svd', 'utils/common.py:715 (cal_Z_axis: off the inference path, z_axis is given)', f'[{keypts},3,3]', svd, covs[i])
+    for i in range(2):                                                      # the fifth pointnet2 operator of the surface: no call site in the reference's inference
+        unknown = cp[i][None].contiguous()
+        call('pnt2.three_nn', 'three_nn', 'README.md:31 (pointnet2_ops; no call site on the inference path)', f'[1,{unknown.shape[1]},3] vs [1,{keypts},3]',
+             pnt2.three_nn, unknown, kp[i])
 
     # ---- the fused device forms BufferPipeline runs in place of those calls (same pair, same inputs already in HBM)
     def med(fn):
@@ -883,7 +891,6 @@ def run_surface(a, dev, L):
             ts.append((time.perf_counter() - t0) * 1e3)
         return float(np.median(ts))
 
-    cp = [pts0[lo:hi][torch.where(score[lo:hi] > cfg.keypts_th)[0]] for lo, hi in ((0, n_src), (n_src, int(pts0.shape[0])))]
     cat_cand, kp_cat, ka_cat = torch.cat(cp).contiguous(), torch.cat([k[0] for k in kp]).contiguous(), torch.cat([k[0] for k in ka]).contiguous()
     sup = torch.cat([raws[i][perms[i]] for i in range(2)]).contiguous()
     sup_len = [int(raws[0].shape[0]), int(raws[1].shape[0])]
@@ -927,7 +934,7 @@ def run_surface(a, dev, L):
     for t in rows:
         t['ms_gpu'] = round(t['ms_gpu'], 3)
         t['ms_cpu'] = None if t['ms_cpu'] is None else round(t['ms_cpu'], 2)
-    on_path = [t for t in rows if 'svd' not in t['op']]
+    on_path = [t for t in rows if 'svd' not in t['op'] and 'three_nn' not in t['op']]
     sum_gpu = sum(t['ms_gpu'] for t in on_path)
     sum_cpu = sum(t['ms_cpu'] for t in on_path) if kind else None
     sum_fused = sum(f['ms'] for f in fused)
@@ -942,7 +949,7 @@ def run_surface(a, dev, L):
                    'candidates_above_threshold': cand, 'neighbor_limits': limits, 'repetitions_per_call': reps,
                    'timing': 'host clock around each call, device synchronised on both sides, median; cpp_wrappers calls include their numpy <-> device copies'},
         'surface': {'ops': rows, 'sum_ms_gpu': round(sum_gpu, 3), 'sum_ms_cpu': None if sum_cpu is None else round(sum_cpu, 1),
-                    'sum_excludes': 'torch_batch_svd.svd (no call on the inference path)',
+                    'sum_excludes': 'torch_batch_svd.svd and pnt2.three_nn (no call on the inference path)',
                     'fused': [dict(f, ms=round(f['ms'], 3)) for f in fused], 'sum_ms_fused': round(sum_fused, 3),
                     'buffer_pipeline_whole_pair_ms': round(whole, 3),
                     'buffer_pipeline_note': 'BufferPipeline.register_batch([pair]): the WHOLE inference of this pair (operators + both CNNs + pose recovery), '
