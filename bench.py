@@ -334,8 +334,11 @@ def compact(e, algo_key=None):
     by = e.get('avg_algorithmic_bytes')
     if e.get('traffic') and by:
         tr = round(e['traffic'] / by, 2)
-    return {'kernel': e['kernel'].split(' ')[0], 'bound': e['bound'], 'frac': None if e.get('frac') is None else round(e['frac'], 4),
-            'avg_us': round(e['avg_us'], 1), 'traffic_ratio': tr}
+    out = {'kernel': e['kernel'].split(' ')[0], 'bound': e['bound'], 'frac': None if e.get('frac') is None else round(e['frac'], 4),
+           'avg_us': round(e['avg_us'], 1), 'traffic_ratio': tr}
+    if 'traffic_ratio_vs_algorithmic_plus_pf' in e:      # k_vn_gather: against algorithmic + the hoisted form's PF table (see main())
+        out['traffic_ratio_incl_pf'] = round(e['traffic_ratio_vs_algorithmic_plus_pf'], 2)
+    return out
 
 
 def dgr_ok(poses, gts, rre_deg=15.0):
@@ -568,13 +571,17 @@ def main():
     # share the chip with the CNN kernels of step i: their event spans there measure the contention, not the kernel.
     timed_alone = timed
     latency = {}
+    pf_bytes = None
     if rank == 0 and pool is None and not a.no_pipeline and pps:
+        from buffer_amd import ops as _ops
+        _ops.PF_BYTES[0] = 0.0
         L.buf_timing_enable(1)
         for i in range(2):
             step(pipe, a.warmup + a.steps + i)
         torch.cuda.synchronize()
         L.buf_timing_enable(0)
         timed_alone = collect_timed(L)
+        pf_bytes = _ops.PF_BYTES[0]                   # bytes of the VN gather's hoisted-form table (written + re-read) over those two steps
     if rank == 0 and pps and not os.environ.get('BUF_NO_TRAFFIC'):      # (not in the PMC-profiled runs: full-step launches only there)
         # what ONE caller of models/BUFFER.py:231-333 sees: one pair, un-batched, un-pipelined, host clock around a synchronised
         # call (median of 10); and the keypoint stage alone (pyramid, point learner, FPS), for one pair and for a whole step
@@ -641,6 +648,13 @@ def main():
             main_roof = roofline_split(timed, pmc, units, None)
         units['patches_per_select'] = 2 * keypts * per_launch
         _, other = rooflines(timed_alone, pmc, fps_bytes, units, int(L.buf_version()))     # the others: each kernel alone on the chip
+        for e in other:
+            # A4: the hoisted form of the four resnet blocks writes PF = [Wf f | Wd f] once per support row and reads it back (a deliberate trade
+            # that halved the kernel's time, csrc/vn.hip): its traffic is judged against algorithmic + PF bytes
+            if e['kernel'].startswith('k_vn_gather') and pf_bytes and e.get('traffic') and e.get('launches'):
+                e['pf_bytes_per_launch'] = pf_bytes / e['launches']
+                e['traffic_ratio_vs_algorithmic'] = e['traffic'] / e['avg_algorithmic_bytes']
+                e['traffic_ratio_vs_algorithmic_plus_pf'] = e['traffic'] / (e['avg_algorithmic_bytes'] + e['pf_bytes_per_launch'])
         alone_steps = 2 if timed_alone is not timed else a.steps
         label = ('KITTI-shape scan pair (~120k returns per scan, 0.05 / 0.30 m voxels, KITTI constants), full BUFFER inference '
                  '(BASELINE configs[3])') if kitti else 'one 3DMatch-shape fragment pair, full BUFFER inference (BASELINE configs[1])'

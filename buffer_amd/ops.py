@@ -333,6 +333,9 @@ class VnLayer:
         self.slope = float(slope)
 
 
+PF_BYTES = [0.0]           # diagnostics (bench.py): bytes of the hoisted form's PF table written + re-read by the calls so far (48 * cout * ns each)
+
+
 def vn_gather_block(layer, q_pts, s_pts, feats, idx, mode, scale=1.0):
     """VNNBlock / conv half of VNNResnetBlock -> f32[nq, 3*cout]."""
     L = _lib.lib()
@@ -344,6 +347,7 @@ def vn_gather_block(layer, q_pts, s_pts, feats, idx, mode, scale=1.0):
         # the channel contraction once per support point instead of once per neighbour slot (csrc/vn.hip, round 4)
         wsb = L.buf_vn_gather_pre_ws_bytes(ns, layer.cout)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=feats.device)
+        PF_BYTES[0] += 48.0 * layer.cout * ns               # PF[j] = [Wf f_j | Wd f_j]: 2 * cout vectors of 12 B per support row, written once and read back
         check(L.buf_vn_gather_block_pre(_ptr(q_pts), _ptr(s_pts), _ptr(feats), _ptr(idx), nq, ns, k, cin, layer.cout, float(scale),
                                         _ptr(layer.wf), _ptr(layer.wd), _ptr(layer.bsc), _ptr(layer.bsh), layer.slope, _ptr(out),
                                         _ptr(ws), wsb, _stream()), "buf_vn_gather_block_pre")
