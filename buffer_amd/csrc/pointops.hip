@@ -944,7 +944,7 @@ __global__ void __launch_bounds__(256) k_nn1f_sweep(const float* __restrict__ re
     if (hdr->bad) return;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     const int groups = nqpad / NNF_QW;
-    const int task = blockIdx.x * 4 + w;                         // (batch element, query group): consecutive groups of one element
+    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + w;     // (batch element, query group): the groups of one element on ONE XCD (its planes stay in that L2: -2 % per call, round 6)
     const int e = task / groups, g = task - e * groups;
     if (e >= b) return;
     const int col = lane & 15, kg = lane >> 4;
