@@ -3,6 +3,8 @@
 # wall time (tools/bench_ops.py radius 32), SQ counters and the two HBM-traffic counters (separate PMC passes, kernel trace only) of
 # k_grid_query_cell for the library in build/pk/cur.so (dense-table lookups at every cell change: rounds 4-5) and the shipped one.
 #   tools/a2_floor.sh [pairs]   (on the GPU box)   -> gpurun_out/r06/a2_floor_raw.txt
+# build/pk/cur.so is not kept in the tree: build it from the round-5 sources first (git stash; git checkout 28b95c4 -- buffer_amd/csrc;
+# python3 -c "from buffer_amd import build; build.build(force=True, out='build/pk/cur.so')"; git checkout HEAD -- buffer_amd/csrc; git stash pop).
 cd "$(dirname "$0")/.."
 pairs=${1:-32}
 mkdir -p gpurun_out/r06
