@@ -293,7 +293,8 @@ int     buf_cylindrical_net_wg_supports(const int* cin_host, const int* cout_hos
  * three v_mfma_f32_16x16x32_f16 per (16 outputs x 16 positions x 32 channels), direct 9-tap form.  Measured against the float64
  * stack: not worse than the fp32 kernels (tests/test_model_gpu.py, profiles/r04_f16_split.txt).  Requires every activation and
  * weight below 65504 in magnitude (f16 range): weights are checked by the tiler, an activation that leaves the range sets bit 0
- * of *status_dev (DEVICE int32, nullable; the caller clears and reads it).
+ * of *status_dev (DEVICE int32, nullable; the caller clears and reads it) -- the BARE kernel: a caller that does not manage the range
+ * itself uses buf_cylindrical_net_split_safe below, which re-runs such patches on the fp32 kernel.
  * x f32[np,Cin0,140] -> y f32[np,32,140]; bias_host[l]: DEVICE f32[Cout]; wt_host[l]: DEVICE u16 planes as buf_split_tile_filters
  * lays them out from the BN-folded filters [Cout,Cin,3,3]:
  *   out[((((g 9 + tap) KS + ks) 2 + n2) 2 + plane) 512 + (kg 16 + row) 8 + i] = plane(w[32 g + 16 n2 + row][32 ks + 8 kg + i][tap]),
