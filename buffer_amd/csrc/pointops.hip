@@ -27,18 +27,61 @@ __device__ __forceinline__ unsigned int fps_tie_rank(unsigned int t, int T)     
     return T > 1 ? __brev(t) >> (__clz(T) + 1) : 0u;       // T = 2^b: clz = 31 - b, shift = 32 - b
 }
 
+// One instruction per step: the DPP operand rides on the v_max itself (the builtin form compiles to v_mov_dpp + a canonicalising v_max v, v, v +
+// the v_max: 18 dependent instructions on the round's critical path instead of 6).  Lanes a step does not address are not written and keep v;
+// the s_nop covers the two wait states between a vector write and a DPP read of the same register (the hazard recogniser does not see
+// into inline assembly).
 __device__ __forceinline__ float wave_max_f32(float v)
 {
-#define DPP_MAX(ctrl, rmask, bmask) \
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, bmask, false)))
-    DPP_MAX(0x111, 0xf, 0xf);   // row_shr:1
-    DPP_MAX(0x112, 0xf, 0xf);   // row_shr:2
-    DPP_MAX(0x114, 0xf, 0xe);   // row_shr:4
-    DPP_MAX(0x118, 0xf, 0xc);   // row_shr:8
-    DPP_MAX(0x142, 0xa, 0xf);   // row_bcast:15
-    DPP_MAX(0x143, 0xc, 0xf);   // row_bcast:31
-#undef DPP_MAX
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1" : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// fminf() whose operands the compiler cannot prove quiet costs a canonicalising v_max_f32 v, v, v in front of the v_min_f32 (1 of the 13 vector
+// instructions a slot of k_fps costs per round; the running minimum comes round the loop through a phi).  The instruction itself already
+// returns the other operand for a NaN: same results.
+__device__ __forceinline__ float min_f32_raw(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float max_f32_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float max3_f32_raw(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// maximum of N registers as a tree of v_max3_f32 (25 values: 8 + 3 + 1 instructions, depth 3)
+template <int N>
+__device__ __forceinline__ float max_tree_f32(const float (&v)[N])
+{
+    if constexpr (N == 1) return v[0];
+    else if constexpr (N == 2) return max_f32_raw(v[0], v[1]);
+    else {
+        constexpr int M = (N + 2) / 3;
+        float t[M];
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            t[i] = 3 * i + 2 < N ? max3_f32_raw(v[3 * i], v[3 * i + 1], v[3 * i + 2])
+                 : 3 * i + 1 < N ? max_f32_raw(v[3 * i], v[3 * i + 1]) : v[3 * i];
+        return max_tree_f32<M>(t);
+    }
 }
 
 // Per lane the candidates k = tid + j*FPS_THREADS share (k mod T) because T divides FPS_THREADS, so
@@ -81,17 +124,10 @@ __global__ void __launch_bounds__(THREADS) k_fps(const float* __restrict__ xyz, 
         float d2[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
-            d2[j] = fminf(sqdist3(px[j], py[j], pz[j], x1, y1, z1), temp[j]);
+            d2[j] = min_f32_raw(sqdist3(px[j], py[j], pz[j], x1, y1, z1), temp[j]);
             temp[j] = d2[j];
         }
-        float tr[PPT];
-#pragma unroll
-        for (int j = 0; j < PPT; j++) tr[j] = d2[j];
-#pragma unroll
-        for (int w2 = 1; w2 < PPT; w2 <<= 1)
-#pragma unroll
-            for (int j = 0; j + w2 < PPT; j += 2 * w2) tr[j] = fmaxf(tr[j], tr[j + w2]);
-        const float best = tr[0];
+        const float best = max_tree_f32<PPT>(d2);
         int bj = PPT;
 #pragma unroll
         for (int j = PPT - 1; j >= 0; j--) bj = d2[j] == best ? j : bj;   // independent compares, short select chain

@@ -8,7 +8,7 @@ from buffer_amd import ops, synth
 dev = torch.device('cuda:0')
 which = sys.argv[1] if len(sys.argv) > 1 else 'fps'
 if which == 'fps':
-    for n in (8000, 11000):
+    for n in (8000, 11000, 13300):
         rng = np.random.default_rng(0)
         pts = torch.from_numpy((rng.random((n, 3)) * 2 + 0.5).astype(np.float32)).to(dev)
         for m in (1500, 5000):
@@ -20,6 +20,19 @@ if which == 'fps':
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t) / 3
             print(f'fps n={n} m={m}: {dt*1e3:.2f} ms  {dt/m*1e6:.2f} us/round')
+    # a ragged batch the way the step launches it (one workgroup per cloud, the kernel tier picked by the largest)
+    rng = np.random.default_rng(1)
+    lens = [int(v) for v in rng.integers(6500, 13300, 32)]
+    pts = torch.from_numpy((rng.random((sum(lens), 3)) * 2 + 0.5).astype(np.float32)).to(dev)
+    for m in (1500, 5000):
+        ref = ops.furthest_point_sample_ragged(pts, lens, m)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            ops.furthest_point_sample_ragged(pts, lens, m)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / 3
+        print(f'fps ragged 32 clouds {min(lens)}..{max(lens)} m={m}: {dt*1e3:.2f} ms  checksum {int(ref.long().sum())}')
 if which == 'cyl':
     from buffer_amd.config import THREEDMATCH
     from buffer_amd.patch_embedder import PatchEmbedder
