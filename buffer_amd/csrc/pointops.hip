@@ -16,7 +16,7 @@
 // bitrev_log2T(k mod T) << 22 | k.
 #define FPS_THREADS 512           // fallback kernel + the >16k-point register-resident variants
 #define FPS_WAVES (FPS_THREADS / WAVE)
-#define FPS_LDS_POINTS 12800      // clouds up to this size keep an xyz copy in LDS for the winner lookup
+#define FPS_LDS_POINTS 13600      // clouds up to this size keep an xyz copy in LDS for the winner lookup (163 200 + 128 of the CU's 163 840 bytes)
 #define FPS_MAXB 64
 
 struct FpsBatch { int off[FPS_MAXB]; int n[FPS_MAXB]; };   // per-cloud row offset and length (ragged batch)
@@ -87,6 +87,12 @@ __device__ __forceinline__ float max_tree_f32(const float (&v)[N])
 // Per lane the candidates k = tid + j*FPS_THREADS share (k mod T) because T divides FPS_THREADS, so
 // inside a lane the upstream tie rule reduces to "first j wins" = strict '>' in ascending j.
 // Points the upstream kernel skips carry temp = -1, which never beats the initial best of -1.
+// Cross-wave stage of a round: with the LDS copy of the cloud, one ordered 64-bit key per wavefront and a depth-3 tree of maxima (11 k points:
+// 1.31 -> 1.18 us per round); WITHOUT the copy (13 600 < n <= 16 384: the winner's coordinates are a scalar load) the tree measured 1.85 us per
+// round against 1.52 for the compare-and-branch chain over (distance, tie key) pairs, which stays there (tools/bench_ops.py fps, n = 15 000).
+#ifndef FPS_KEY_REDUCE
+#define FPS_KEY_REDUCE(lds) (lds)
+#endif
 template <int THREADS, int PPT, bool LDSPTS>
 __global__ void __launch_bounds__(THREADS) k_fps(const float* __restrict__ xyz, FpsBatch B, int m, int* __restrict__ idx_out)
 {
@@ -113,6 +119,9 @@ __global__ void __launch_bounds__(THREADS) k_fps(const float* __restrict__ xyz, 
     if (LDSPTS) {
         for (int i = tid; i < 3 * n; i += THREADS) spts[i] = P[i];
     }
+    // a wavefront's round result as ONE ordered key: distance bits << 32 | ~tie key (distances are >= +0: their bit patterns order like the
+    // values; 0 = no candidate).  The cross-wave arg-max is a depth-3 tree of 64-bit maxima instead of eight dependent compare-and-branch steps.
+    __shared__ __attribute__((aligned(16))) unsigned long long skey[2][NW];
     __shared__ float sbest[2][NW];
     __shared__ unsigned int stie[2][NW];
     float x1 = n > 0 ? P[0] : 0.f, y1 = n > 0 ? P[1] : 0.f, z1 = n > 0 ? P[2] : 0.f;
@@ -144,26 +153,43 @@ __global__ void __launch_bounds__(THREADS) k_fps(const float* __restrict__ xyz, 
                 for (int d = WAVE / 2; d > 0; d >>= 1) v = min(v, (unsigned int)__shfl_xor((int)v, d, WAVE));
                 win = __ffsll((long long)__ballot(best == wmax && tk == v)) - 1;
             }
-            if (lane == win) { sbest[buf][w] = wmax; stie[buf][w] = tk; }
+            if (lane == win) {
+                if (FPS_KEY_REDUCE(LDSPTS)) skey[buf][w] = ((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned int)~tk;
+                else { sbest[buf][w] = wmax; stie[buf][w] = tk; }
+            }
         } else if (lane == 0) {
-            sbest[buf][w] = -1.0f; stie[buf][w] = 0xffffffffu;
+            if (FPS_KEY_REDUCE(LDSPTS)) skey[buf][w] = 0ull;
+            else { sbest[buf][w] = -1.0f; stie[buf][w] = 0xffffffffu; }
         }
         __syncthreads();
-        float g = -1.0f;
-        unsigned int gt = 0xffffffffu;
-        int gw = 0;
+        int old;
+        if (FPS_KEY_REDUCE(LDSPTS)) {
+            unsigned long long kk[NW];
 #pragma unroll
-        for (int i = 0; i < NW; i++) {
-            float v = sbest[buf][i];
-            unsigned int t = stie[buf][i];
-            bool better = v > g || (v == g && t < gt);
-            g = better ? v : g; gt = better ? t : gt; gw = better ? i : gw;
+            for (int i = 0; i < NW; i++) kk[i] = skey[buf][i];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2 <<= 1)
+#pragma unroll
+                for (int i = 0; i + w2 < NW; i += 2 * w2) kk[i] = kk[i] > kk[i + w2] ? kk[i] : kk[i + w2];
+            old = kk[0] == 0ull ? 0 : (int)(~(unsigned int)kk[0] & 0x3fffffu);      // nobody competing -> index 0
+        } else {
+            float g = -1.0f;
+            unsigned int gt = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                float v = sbest[buf][i];
+                unsigned int t = stie[buf][i];
+                bool better = v > g || (v == g && t < gt);
+                g = better ? v : g; gt = better ? t : gt;
+            }
+            old = g < 0.f ? 0 : (int)(gt & 0x3fffffu);
         }
-        // winner's coordinates: one broadcast read of the cloud (L1/L2 resident), nobody competing -> index 0
-        const int old = g < 0.f ? 0 : (int)(gt & 0x3fffffu);
-        if (LDSPTS) { x1 = spts[3 * old]; y1 = spts[3 * old + 1]; z1 = spts[3 * old + 2]; }
-        else { x1 = P[3 * (size_t)old]; y1 = P[3 * (size_t)old + 1]; z1 = P[3 * (size_t)old + 2]; }
-        (void)gw;
+        // winner's coordinates: one broadcast read of the cloud (LDS copy, or L2 resident through the scalar cache)
+        if (LDSPTS) { const unsigned int o3 = __umul24((unsigned int)old, 3u); x1 = spts[o3]; y1 = spts[o3 + 1]; z1 = spts[o3 + 2]; }   // (full-rate multiply)
+        else {      // the index is wavefront-uniform: said so, the lookup is a scalar load (as a vector load it cost 0.3 us more per round)
+            const size_t o3 = 3 * (size_t)__builtin_amdgcn_readfirstlane(old);
+            x1 = P[o3]; y1 = P[o3 + 1]; z1 = P[o3 + 2];
+        }
         if (tid == 0) out[r] = old;
     }
 }
@@ -244,7 +270,7 @@ extern "C" int buf_fps_ragged(const float* xyz, const int* lengths_host, int b, 
         int* out = idx_out + (size_t)c0 * m;
         TimedSpan span;
         bool timed = timing_begin(s, &span, (double)m, BUF_TIMED_FPS);            // work = rounds; bytes follow from the lengths
-        // <= 12800 points: an xyz copy in LDS serves the winner lookup (one broadcast ds_read instead of an L2 round trip)
+        // <= FPS_LDS_POINTS points: an xyz copy in LDS serves the winner lookup (one broadcast ds_read instead of an L2 round trip)
         const size_t lds = sizeof(float) * 3 * (size_t)nmax;
 #define FPS_LAUNCH(TH, PPT_, L) \
     do { if (L) { static LdsGrant grant_; if (int rc_ = grant_dynamic_lds((const void*)k_fps<TH, PPT_, L>, FPS_LDS_POINTS * 12, grant_)) return rc_; } \
@@ -252,7 +278,8 @@ extern "C" int buf_fps_ragged(const float* xyz, const int* lengths_host, int b, 
         if (nmax <= 4 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 4, true);
         else if (nmax <= 8 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 8, true);
         else if (nmax <= 16 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 16, true);
-        else if (nmax <= FPS_LDS_POINTS) FPS_LAUNCH(FPS_THREADS, 25, true);
+        else if (nmax <= 25 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 25, true);
+        else if (nmax <= FPS_LDS_POINTS) FPS_LAUNCH(FPS_THREADS, 32, true);
         else if (nmax <= 32 * FPS_THREADS) FPS_LAUNCH(FPS_THREADS, 32, false);
 #undef FPS_LAUNCH
         else {

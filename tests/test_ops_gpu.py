@@ -17,7 +17,8 @@ def _cloud(seed, n):
     return p[rng.permutation(len(p))[:n]]
 
 
-@pytest.mark.parametrize("n,m", [(1000, 64), (5000, 1500), (9000, 1500), (20000, 300), (40000, 64)])
+@pytest.mark.parametrize("n,m", [(1000, 64), (3000, 200), (5000, 1500), (9000, 1500), (13300, 300), (15000, 300), (20000, 300),
+                                 (40000, 64)])       # (every tier of the launcher: 4 / 8 / 16 / 25 / 32 slots with the LDS copy, 32 without, global)
 def test_fps_index_exact(n, m, oracle, dev):
     from buffer_amd import ops
     xyz = np.stack([_cloud(1, n), _cloud(2, n)])
@@ -37,7 +38,7 @@ def test_fps_duplicates_and_small(oracle, dev):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("n,m", [(6, 5), (150, 100), (1536, 400), (6000, 900), (17000, 200)])
+@pytest.mark.parametrize("n,m", [(6, 5), (150, 100), (1536, 400), (6000, 900), (13000, 200), (15500, 200), (17000, 200)])
 def test_fps_cross_thread_ties(n, m, oracle, dev):
     """exact d2 ties between DIFFERENT upstream threads (duplicates at k, k+1, k+2): the upstream tree keeps the
     thread that is smallest in bit-reversed order, not the smallest thread id"""

@@ -8,7 +8,7 @@ from buffer_amd import ops, synth
 dev = torch.device('cuda:0')
 which = sys.argv[1] if len(sys.argv) > 1 else 'fps'
 if which == 'fps':
-    for n in (8000, 11000, 13300):
+    for n in (8000, 11000, 13300, 15000):
         rng = np.random.default_rng(0)
         pts = torch.from_numpy((rng.random((n, 3)) * 2 + 0.5).astype(np.float32)).to(dev)
         for m in (1500, 5000):
