@@ -284,7 +284,7 @@ def rooflines(timed, pmc, fps_bytes_per_launch, units, lib_version=None):
                                             if timed['cost_net'][0] else None)),
         roof_entry(timed, 'grid_query', 'k_grid_query_cell + k_grid_query_wave (A2 radius neighbours: cell-centric self queries, query-centric others)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_grid_query', units.get('pairs'))),
-        roof_entry(timed, 'grid_subsample', 'k_vox_* + scan + k_cell_scatter (A1 grid subsample, whole call)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9),
+        roof_entry(timed, 'grid_subsample', 'k_vox_fused + k_vox_concat (A1 grid subsample, whole call: one workgroup per element, sorted in LDS)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9),
         roof_entry(timed, 'vn_gather', 'k_vn_gather (A4 fused VN neighbour block)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,
                    traffic_of(pmc, 'k_vn_gather', units.get('pairs'))),
         roof_entry(timed, 'select_patches', 'k_select_patches_grid (A8 ball query + grouping)', 'hbm', HBM_PEAK_GBS, 'GB/s', 1e9,

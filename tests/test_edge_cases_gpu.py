@@ -10,11 +10,23 @@ pytestmark = pytest.mark.gpu
 
 
 def _eq_sub(oracle, dev, pts, lens, dl, **kw):
+    """both forms of the operator against the oracle: one workgroup per element with its bucket table in LDS (the default when every element
+    has <= 16384 points) and the global-table counting sort (BUF_VOX_FUSED=0)"""
+    import os
     from buffer_amd import ops
     want, wl = oracle.grid_subsample_batch(pts, lens, dl, **{k: v for k, v in kw.items() if k == 'max_p'})
-    got, gl = ops.grid_subsample_batch(torch.from_numpy(pts).to(dev), lens, dl, **kw)
-    assert np.array_equal(gl, wl)
-    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    old = os.environ.get('BUF_VOX_FUSED')
+    try:
+        for form in ('1', '0'):
+            os.environ['BUF_VOX_FUSED'] = form
+            got, gl = ops.grid_subsample_batch(torch.from_numpy(pts).to(dev), lens, dl, **kw)
+            assert np.array_equal(gl, wl), form
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), form
+    finally:
+        if old is None:
+            os.environ.pop('BUF_VOX_FUSED', None)
+        else:
+            os.environ['BUF_VOX_FUSED'] = old
 
 
 def test_subsample_sparse_extent_uses_key_buckets(oracle, dev):
@@ -51,6 +63,40 @@ def test_subsample_max_p_and_single_voxel(oracle, dev):
     _eq_sub(oracle, dev, pts, lens, 100.0)                          # everything in one voxel: a 2000-term ordered sum
     same = np.tile(np.array([[0.3, 0.4, 0.5]], np.float32), (500, 1))
     _eq_sub(oracle, dev, same, np.array([500], np.int32), 0.1)
+
+
+def test_subsample_forms_agree_on_ragged_batches_features_and_large_elements(oracle, dev):
+    """the LDS form and the global-table form: ragged batch with empty elements, features, max_p, an element over the LDS form's 16384
+    points (the call falls back as a whole), a fragment-sized batch"""
+    import os
+    from buffer_amd import ops, synth
+    rng = np.random.default_rng(7)
+    pts = (rng.random((9000, 3)) * np.array([3.0, 2.0, 1.0])).astype(np.float32)
+    lens = np.array([0, 4000, 0, 1, 4999, 0], np.int32)
+    _eq_sub(oracle, dev, pts, lens, 0.07)
+    _eq_sub(oracle, dev, pts, lens, 0.15, max_p=37)
+    feats = rng.normal(size=(9000, 5)).astype(np.float32)
+    res = {}
+    for form in ('1', '0'):
+        os.environ['BUF_VOX_FUSED'] = form
+        try:
+            for mp in (0, 23):
+                p_, l_, f_ = ops.grid_subsample_batch(torch.from_numpy(pts).to(dev), lens, 0.1, max_p=mp, features=torch.from_numpy(feats).to(dev))
+                res[form, mp] = (p_.cpu().numpy(), l_.copy(), f_.cpu().numpy())
+        finally:
+            os.environ.pop('BUF_VOX_FUSED', None)
+    for mp in (0, 23):
+        for a, b_ in zip(res['1', mp], res['0', mp]):
+            assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b_.view(np.uint32) if b_.dtype == np.float32 else b_)
+    big = (rng.random((40000 + 3000, 3)) * 2).astype(np.float32)          # 40000 > 16384: global-table form for the whole call
+    _eq_sub(oracle, dev, big, np.array([40000, 3000], np.int32), 0.05)
+    d = synth.make_pair(11)
+    for key, dls in (('sds', (0.07, 0.14, 0.6)), ('fds', (0.07,))):       # sds: 9-15 k points per element (LDS form); fds: > 16384 (global-table form)
+        frag = np.concatenate([d[f'src_{key}_pts'][:, :3], d[f'tgt_{key}_pts'][:, :3]]).astype(np.float32)
+        for dl in dls:
+            _eq_sub(oracle, dev, frag, np.array([len(d[f'src_{key}_pts']), len(d[f'tgt_{key}_pts'])], np.int32), dl)
+    dense = (rng.random((16384, 3)) * 0.2).astype(np.float32)             # the LDS form's largest element, 2500 points per voxel
+    _eq_sub(oracle, dev, dense, np.array([16384], np.int32), 0.1)
 
 
 def test_degenerate_point_ops(oracle, dev):

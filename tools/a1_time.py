@@ -23,9 +23,12 @@ def timeit(f, reps=30):
     return float(np.median(ts))
 
 
-for dl in (0.07, 0.14):
-    sub, sl = ops.grid_subsample_batch(P, lens, dl)
-    print(f'A1 grid_subsample_batch {npairs} pairs, {P.shape[0]} -> {sub.shape[0]} rows, dl {dl}: {timeit(lambda: ops.grid_subsample_batch(P, lens, dl)):.1f} us per call (host clock, incl. the row-count round trip)')
+for form in ('1', '0'):                # one workgroup per element, table in LDS | global-table counting sort
+    os.environ['BUF_VOX_FUSED'] = form
+    for dl in (0.07, 0.14):
+        sub, sl = ops.grid_subsample_batch(P, lens, dl)
+        print(f'A1 grid_subsample_batch (BUF_VOX_FUSED={form}) {npairs} pairs, {P.shape[0]} -> {sub.shape[0]} rows, dl {dl}: {timeit(lambda: ops.grid_subsample_batch(P, lens, dl)):.1f} us per call (host clock, incl. the row-count round trip)')
+os.environ.pop('BUF_VOX_FUSED')
 print(f'A2 grid build r=0.07: {timeit(lambda: ops.CellGrid(P, lens, 0.07)):.1f} us')
 g = ops.CellGrid(P, lens, 0.07)
 print(f'A2 self query K=17 in grid order: {timeit(lambda: g.query(P, lens, 17, q_order=g.order)):.1f} us')
