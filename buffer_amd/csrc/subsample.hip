@@ -253,6 +253,21 @@ __global__ void k_vox_counts(const int* __restrict__ rowidx, const int* __restri
 #define VOXF_LDS_BYTES (sizeof(int) * (VOXF_TABLE_WORDS + 1 + VOXF_MAX_N) + sizeof(unsigned short) * VOXF_MAX_N + 12)
 #define VOXF_U 4                  // points per lane whose loads are issued together
 
+// inclusive prefix sum over the 64 lanes through DPP row shifts / broadcasts (__shfl_up is an LDS permute: ~120 cycles a step, six dependent
+// steps per 64 entries were most of the scans' 4 us)
+__device__ __forceinline__ int wave_scan_incl_i32(int v)
+{
+#define DPP_ADD(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, true)
+    DPP_ADD(0x111, 0xf);   // row_shr:1
+    DPP_ADD(0x112, 0xf);   // row_shr:2
+    DPP_ADD(0x114, 0xf);   // row_shr:4
+    DPP_ADD(0x118, 0xf);   // row_shr:8   -> inclusive sums inside each row of 16
+    DPP_ADD(0x142, 0xa);   // row_bcast:15: row 0's total into row 1, row 2's into row 3
+    DPP_ADD(0x143, 0xc);   // row_bcast:31: the total of rows 0-1 into rows 2-3
+#undef DPP_ADD
+    return v;
+}
+
 // exclusive scan of cnt ints (LDS or global) by the whole workgroup, 64 consecutive entries per wavefront step; returns the total
 __device__ int voxf_scan(int* __restrict__ a, int cnt, int* __restrict__ wsum)
 {
@@ -270,10 +285,9 @@ __device__ int voxf_scan(int* __restrict__ a, int cnt, int* __restrict__ wsum)
     for (int i0 = s0; i0 < s1; i0 += WAVE) {
         const int i = i0 + lane;
         const int v = i < s1 ? a[i] : 0;
-        int inc = v;
-        for (int d = 1; d < WAVE; d <<= 1) { const int t = __shfl_up(inc, d, WAVE); if (lane >= d) inc += t; }
+        const int inc = wave_scan_incl_i32(v);
         if (i < s1) a[i] = carry + inc - v;
-        carry += __shfl(inc, WAVE - 1, WAVE);
+        carry += __builtin_amdgcn_readlane(inc, WAVE - 1);
     }
     __syncthreads();
     return total;
@@ -297,11 +311,10 @@ __device__ void voxf_scan16(int* __restrict__ a, int cnt, int* __restrict__ wsum
         const int i = i0 + lane;
         const unsigned int v = i < s1 ? (unsigned int)a[i] : 0u;
         const int c0 = (int)(v & 0xffffu), c1 = (int)(v >> 16);
-        int inc = c0 + c1;
-        for (int d = 1; d < WAVE; d <<= 1) { const int t = __shfl_up(inc, d, WAVE); if (lane >= d) inc += t; }
+        const int inc = wave_scan_incl_i32(c0 + c1);
         const int ex = carry + inc - c0 - c1;
         if (i < s1) a[i] = (int)((unsigned int)ex | (unsigned int)(ex + c0) << 16);
-        carry += __shfl(inc, WAVE - 1, WAVE);
+        carry += __builtin_amdgcn_readlane(inc, WAVE - 1);
     }
     __syncthreads();
 }
