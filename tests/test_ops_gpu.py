@@ -51,6 +51,33 @@ def test_fps_cross_thread_ties(n, m, oracle, dev):
     assert len(set(map(tuple, xyz[0][want[0][:min(m, (n + 2) // 3)]]))) == min(m, (n + 2) // 3)   # distinct locations first
 
 
+def test_fps_corner_cases(oracle, dev):
+    """clouds beyond the ordinary ones: more samples than points (the maxima reach 0 and stay there), a cloud
+    of few distinct locations (every box degenerate), points the upstream kernel skips spread through the cloud, a ragged batch whose
+    clouds fall into different slot tiers, NaN-free but far-flung outliers (one huge cell range)"""
+    from buffer_amd import ops
+    rng = np.random.default_rng(11)
+    a = _cloud(7, 3000)
+    got = ops.furthest_point_sample(torch.from_numpy(a[None]).to(dev), 3400).cpu().numpy()
+    assert np.array_equal(got, oracle.fps(a[None], 3400))
+    few = np.repeat(rng.random((7, 3)).astype(np.float32) + 1, 400, axis=0)[rng.permutation(2800)]
+    assert np.array_equal(ops.furthest_point_sample(torch.from_numpy(few[None]).to(dev), 300).cpu().numpy(), oracle.fps(few[None], 300))
+    sk = _cloud(8, 6000).copy()
+    sk[rng.permutation(6000)[:900]] *= 0.001                       # |p|^2 <= 1e-3: never compete, never update
+    assert np.array_equal(ops.furthest_point_sample(torch.from_numpy(sk[None]).to(dev), 700).cpu().numpy(), oracle.fps(sk[None], 700))
+    out = _cloud(9, 5000).copy()
+    out[17] = [900.0, -700.0, 300.0]
+    out[4000] = [-2000.0, 5.0, 1.0]
+    assert np.array_equal(ops.furthest_point_sample(torch.from_numpy(out[None]).to(dev), 500).cpu().numpy(), oracle.fps(out[None], 500))
+    lens = [1500, 9000, 2500, 12900, 700]
+    pts = np.concatenate([_cloud(20 + i, n) for i, n in enumerate(lens)])
+    got = ops.furthest_point_sample_ragged(torch.from_numpy(pts).to(dev), lens, 400).cpu().numpy()
+    o = 0
+    for i, n in enumerate(lens):
+        assert np.array_equal(got[i], oracle.fps(pts[None, o:o + n], 400)[0]), i
+        o += n
+
+
 @pytest.mark.parametrize("radius,nsample", [(0.3, 512), (0.1, 16), (0.05, 10)])
 def test_ball_query_and_group(radius, nsample, oracle, dev):
     from buffer_amd import ops

@@ -20,6 +20,21 @@ if which == 'fps':
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t) / 3
             print(f'fps n={n} m={m}: {dt*1e3:.2f} ms  {dt/m*1e6:.2f} us/round')
+    # fragment-shaped clouds (surfaces): what the pruned form is built for
+    for seed in (3000, 3001):
+        d = synth.make_pair(seed)
+        for key in ('src_sds_pts', 'tgt_sds_pts'):
+            c = torch.from_numpy(d[key][:, :3].astype(np.float32)).to(dev)
+            n = c.shape[0]
+            for m in (1500, 5000):
+                ref = ops.furthest_point_sample_ragged(c, [n], m)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(3):
+                    ops.furthest_point_sample_ragged(c, [n], m)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t) / 3
+                print(f'fps fragment {seed} {key} n={n} m={m}: {dt*1e3:.2f} ms  {dt/m*1e6:.2f} us/round  checksum {int(ref.long().sum())}')
     # a ragged batch the way the step launches it (one workgroup per cloud, the kernel tier picked by the largest)
     rng = np.random.default_rng(1)
     lens = [int(v) for v in rng.integers(6500, 13300, 32)]
