@@ -128,6 +128,9 @@ int     buf_radius_neighbors(const float* queries, int nq, const float* supports
  * libstdc++ unordered_map order: same multiset of rows, bit for bit).
  * out_pts f32[n,3] (capacity n rows); out_batches_host int32[nb]; returns M via *out_m_host.
  * `max_cells` bounds the dense voxel table (sum over elements); BUF_ECAPACITY if exceeded.
+ * When every element has <= 16384 points the call is one workgroup per element with the sort in LDS (k_vox_fused:
+ * no table in global memory, `max_cells` unused, no capacity to exceed); otherwise, or with BUF_VOX_FUSED=0 in the
+ * environment, the global-table counting sort.  Both forms emit the same rows.
  * Synchronises `stream` (the row count has to reach the host).
  */
 size_t  buf_grid_subsample_ws_bytes(int n, int nb, int64_t max_cells, int fdim);
