@@ -700,26 +700,57 @@ extern "C" int buf_select_patches_batched(const float* pts, const int* lengths_h
 }
 
 // ------------------------------------------------------------------------------------------ A18
+// Four lanes per query, each scanning every fourth known point of an LDS tile; the three best of the four lanes are merged by (distance,
+// index) order, which is what the upstream sequential scan with its strict '<' keeps (round 6: one lane per query reading the known points
+// from global memory, fp64 compares and three-way branches took 275 us for 10 055 queries x 1500 points -- 157 wavefronts on the whole chip).
+#define TNN_PARTS 4
+#define TNN_TILE 2048
+__device__ __forceinline__ void tnn_insert(float d, int k, bool lt1, bool lt2, bool lt3, float& b1, float& b2, float& b3, int& i1, int& i2, int& i3)
+{
+    // the list is sorted: lt1 implies lt2 implies lt3
+    b3 = lt2 ? b2 : (lt3 ? d : b3); i3 = lt2 ? i2 : (lt3 ? k : i3);
+    b2 = lt1 ? b1 : (lt2 ? d : b2); i2 = lt1 ? i1 : (lt2 ? k : i2);
+    b1 = lt1 ? d : b1;              i1 = lt1 ? k : i1;
+}
+
 __global__ void __launch_bounds__(256) k_three_nn(const float* __restrict__ unknown, const float* __restrict__ known,
                                                 int n, int m, float* __restrict__ dist, int* __restrict__ idx)
 {
-    int b = blockIdx.y;
-    int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const float* u = unknown + ((size_t)b * n + j) * 3;
+    __shared__ float tile[3 * TNN_TILE];
+    const int b = blockIdx.y, tid = threadIdx.x, part = tid & (TNN_PARTS - 1);
+    const int j = blockIdx.x * (256 / TNN_PARTS) + tid / TNN_PARTS;
+    const bool active = j < n;
+    const float* u = unknown + ((size_t)b * n + (active ? j : 0)) * 3;
     const float* K = known + (size_t)b * m * 3;
-    float ux = u[0], uy = u[1], uz = u[2];
-    double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float inf = __int_as_float(0x7f800000);          // (the upstream 1e40 as a float: a distance has to be below it to enter the list)
+    float b1 = inf, b2 = inf, b3 = inf;
     int i1 = 0, i2 = 0, i3 = 0;
-    for (int k = 0; k < m; k++) {
-        float d = sqdist3(ux, uy, uz, K[3 * (size_t)k], K[3 * (size_t)k + 1], K[3 * (size_t)k + 2]);
-        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
-        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
-        else if (d < b3) { b3 = d; i3 = k; }
+    for (int base = 0; base < m; base += TNN_TILE) {
+        const int cnt = min(TNN_TILE, m - base);
+        __syncthreads();
+        for (int t = tid; t < 3 * cnt; t += 256) tile[t] = K[3 * (size_t)base + t];
+        __syncthreads();
+#pragma unroll 4
+        for (int k = part; k < cnt; k += TNN_PARTS) {
+            const float d = sqdist3(ux, uy, uz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]);
+            tnn_insert(d, base + k, d < b1, d < b2, d < b3, b1, b2, b3, i1, i2, i3);
+        }
     }
+#pragma unroll
+    for (int mask = 1; mask < TNN_PARTS; mask <<= 1) {      // the partner's three, in its order, by (distance, index)
+        const float o1 = __shfl_xor(b1, mask), o2 = __shfl_xor(b2, mask), o3 = __shfl_xor(b3, mask);
+        const int k1 = __shfl_xor(i1, mask), k2 = __shfl_xor(i2, mask), k3 = __shfl_xor(i3, mask);
+#define TNN_LEX(d, k, bb, ii) ((d) < (bb) || ((d) == (bb) && (k) < (ii)))
+        tnn_insert(o1, k1, TNN_LEX(o1, k1, b1, i1), TNN_LEX(o1, k1, b2, i2), TNN_LEX(o1, k1, b3, i3), b1, b2, b3, i1, i2, i3);
+        tnn_insert(o2, k2, TNN_LEX(o2, k2, b1, i1), TNN_LEX(o2, k2, b2, i2), TNN_LEX(o2, k2, b3, i3), b1, b2, b3, i1, i2, i3);
+        tnn_insert(o3, k3, TNN_LEX(o3, k3, b1, i1), TNN_LEX(o3, k3, b2, i2), TNN_LEX(o3, k3, b3, i3), b1, b2, b3, i1, i2, i3);
+#undef TNN_LEX
+    }
+    if (!active || part != 0) return;
     float* D = dist + ((size_t)b * n + j) * 3;
     int* I = idx + ((size_t)b * n + j) * 3;
-    D[0] = sqrtf((float)b1); D[1] = sqrtf((float)b2); D[2] = sqrtf((float)b3);
+    D[0] = sqrtf(b1); D[1] = sqrtf(b2); D[2] = sqrtf(b3);
     I[0] = i1; I[1] = i2; I[2] = i3;
 }
 
@@ -728,7 +759,7 @@ extern "C" int buf_three_nn(const float* unknown, const float* known, int b, int
     BUF_REQUIRE(b >= 0 && n >= 0 && m >= 0, BUF_EINVAL, "buf_three_nn: negative size");
     if ((long long)b * n == 0) return BUF_OK;
     BUF_REQUIRE(unknown && dist && idx && (m == 0 || known), BUF_EINVAL, "buf_three_nn: null argument");
-    dim3 grid(cdiv(n, 256), b);
+    dim3 grid(cdiv(n, 256 / TNN_PARTS), b);
     k_three_nn<<<grid, 256, 0, (hipStream_t)stream>>>(unknown, known, n, m, dist, idx);
     BUF_LAUNCH_CHECK();
     return BUF_OK;

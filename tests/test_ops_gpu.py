@@ -211,6 +211,17 @@ def test_three_nn(oracle, dev):
     gd, gi = ops.three_nn(torch.from_numpy(u).to(dev), torch.from_numpy(kn).to(dev))
     assert np.array_equal(gi.cpu().numpy(), wi)
     np.testing.assert_allclose(gd.cpu().numpy(), wd, rtol=1e-6, atol=0)
+    # the kernel splits the known points over four lanes per query and LDS tiles of 2048: exact ties between the parts and across tiles
+    # (duplicated known points: the smaller index has to win), fewer than three known points, sizes off every multiple
+    base = rng.random((700, 3)).astype(np.float32)
+    for n, kn in ((333, np.concatenate([base, base[::-1], base])[None]),            # every distance three times, 2100 points: two tiles
+                  (65, rng.random((1, 2, 3)).astype(np.float32)), (1, rng.random((1, 1, 3)).astype(np.float32)),
+                  (1000, rng.random((1, 5003, 3)).astype(np.float32)), (130, np.repeat(rng.random((1, 1, 3)).astype(np.float32), 9, axis=1))):
+        u = rng.random((kn.shape[0], n, 3)).astype(np.float32)
+        wd, wi = oracle.three_nn(u, kn)
+        gd, gi = ops.three_nn(torch.from_numpy(u).to(dev), torch.from_numpy(kn).to(dev))
+        assert np.array_equal(gi.cpu().numpy(), wi), kn.shape
+        np.testing.assert_allclose(gd.cpu().numpy(), wd, rtol=1e-6, atol=0)
 
 
 def test_svd3x3(dev):
