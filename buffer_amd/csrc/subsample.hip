@@ -243,6 +243,8 @@ __global__ void k_vox_counts(const int* __restrict__ rowidx, const int* __restri
 // keys, which land in the last bucket) take the same steps through global arrays in the same launch (voxf_element_global: slow, exact,
 // rare).  k_vox_concat stacks the elements' rows.  One element of 13 k points: 49 us at 3.6 points per voxel, 60 us at 15 (rank 15 / 30 us:
 // one compare per pair of bucket mates, on ONE CU; tools/a1_phases.py); a call of 64 elements 221 -> 101 us and 276 -> 110 us host clock.
+// Worst case, both forms: the rank is quadratic in a bucket's population -- 16 384 points in ONE voxel (a voxel size far beyond the cloud's
+// extent) take 21 ms here and 8 ms on the global-table path (tools/a1_worst.py); a voxel of 2500 points costs 0.4 ms.
 #define VOXF_THREADS 1024
 #define VOXF_WAVES (VOXF_THREADS / WAVE)
 #define VOXF_TABLE 24576          // buckets per element, LDS form: 16-bit counters, two per LDS word (populations and positions are < 2^16)
